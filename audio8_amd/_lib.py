@@ -1,0 +1,90 @@
+"""ctypes binding of liba8hip.so (the C ABI declared in include/a8hip.h).
+
+The product path has no fallback: if the HIP library is missing or a call fails, a RuntimeError
+is raised (never a silent PyTorch/CPU substitute).
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liba8hip.so")
+
+F32, BF16 = 0, 1
+NT, NN, TN = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_MUL_GELU_GRAD = 0, 1, 2
+
+_lib = None
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int), ("layout", C.c_int),
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("A", C.c_void_p), ("lda", C.c_int64), ("a_rpb", C.c_int64), ("a_bs", C.c_int64),
+        ("B", C.c_void_p), ("ldb", C.c_int64), ("b_rpb", C.c_int64), ("b_bs", C.c_int64),
+        ("C", C.c_void_p), ("ldc", C.c_int64), ("c_rpb", C.c_int64), ("c_bs", C.c_int64),
+        ("bias", C.c_void_p), ("bias_rows", C.c_int),
+        ("act", C.c_int),
+        ("zin", C.c_void_p), ("zout", C.c_void_p), ("ldz", C.c_int64),
+        ("out_f32", C.c_int), ("accumulate", C.c_int), ("splitk", C.c_int),
+        ("alpha", C.c_float),
+    ]
+
+
+def lib():
+    """Load (once) and return the HIP library; raise if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"a8hip: {LIB_PATH} is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C audio8_amd/csrc`).  There is no CPU/PyTorch fallback for the hot path.")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.a8_last_error.restype = C.c_char_p
+        _lib.a8_version.restype = C.c_int
+    return _lib
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = lib().a8_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"a8hip {what} failed (status {status}): {msg}")
+
+
+def dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"a8hip: unsupported activation dtype {t.dtype}")
+
+
+def ptr(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("a8hip: tensors must live on the GPU (no CPU fallback in the product path)")
+
+
+EXPORTS = [
+    "a8_version", "a8_last_error", "a8_gemm",
+    "a8_conv0_gn_gelu_fwd", "a8_conv0_gn_gelu_bwd", "a8_col2im_gelu_grad",
+    "a8_layernorm_fwd", "a8_layernorm_bwd",
+    "a8_cast", "a8_dropout", "a8_mask_fill_rows", "a8_mask_fill_rows_bwd", "a8_mask_zero_cols", "a8_zero_rows",
+    "a8_gather_rows", "a8_scatter_add_rows", "a8_add",
+    "a8_posconv_fwd", "a8_posconv_wgrad", "a8_gelu_bwd_bias",
+    "a8_attn_fwd", "a8_attn_bwd",
+    "a8_vq_select", "a8_vq_gather", "a8_vq_ppl", "a8_vq_bwd",
+    "a8_contrastive_fwd", "a8_contrastive_bwd",
+    "a8_ctc_fwd_bwd", "a8_log_softmax_fwd", "a8_log_softmax_bwd",
+    "a8_sumsq", "a8_adamw",
+]

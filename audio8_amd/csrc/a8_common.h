@@ -1,0 +1,155 @@
+// a8hip -- common device/host helpers for the MI355X (gfx950) wav2vec2 hot path.
+// Wave = 64 lanes everywhere.  All MFMA code is written once against Mma<T> for
+// T = bf16 (v_mfma_f32_16x16x32_bf16) and T = float (v_mfma_f32_16x16x4_f32, exact f32).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#define A8_DEV __device__ __forceinline__
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+// ---------------------------------------------------------------- status / errors (host)
+enum { A8_OK = 0, A8_ERR_ARG = 1, A8_ERR_LAUNCH = 2, A8_ERR_UNSUPPORTED = 3 };
+enum { A8_F32 = 0, A8_BF16 = 1 };
+int a8_set_error(int code, const char* fmt, ...);
+int a8_check_launch(const char* what);
+#define A8_REQUIRE(cond, ...) do { if (!(cond)) return a8_set_error(A8_ERR_ARG, __VA_ARGS__); } while (0)
+
+// ---------------------------------------------------------------- small math
+A8_DEV float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+A8_DEV float gelu_grad_f(float x) {
+    // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+template <typename T> A8_DEV float to_f(T v) { return (float)v; }
+template <typename T> A8_DEV T from_f(float v) { return (T)v; }
+
+A8_DEV float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+A8_DEV float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// block-wide sum for blockDim.x = NW*64 threads; `red` is NW floats of LDS scratch.
+template <int NW> A8_DEV float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) s += red[i];
+    return s;
+}
+
+// ---------------------------------------------------------------- counter-based RNG (dropout)
+// 32-bit mix of (seed, stream, index): the same function regenerates a mask in backward.
+A8_DEV uint32_t a8_hash(uint32_t seed, uint32_t stream, uint32_t idx) {
+    uint32_t h = seed ^ (stream * 0x9E3779B9u) ^ (idx * 0x85EBCA6Bu);
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    h += idx; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+// keep-mask: true with probability (1 - p); thr = p * 2^32
+A8_DEV bool a8_keep(uint32_t seed, uint32_t stream, uint32_t idx, uint32_t thr) {
+    return a8_hash(seed, stream, idx) >= thr;
+}
+
+// ---------------------------------------------------------------- vector load/store of 16 bytes
+template <typename T> struct Vec16;                 // 16-byte chunk of T
+template <> struct Vec16<bf16> { static constexpr int N = 8; };
+template <> struct Vec16<float> { static constexpr int N = 4; };
+
+A8_DEV u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+A8_DEV void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+
+// ---------------------------------------------------------------- MFMA abstraction
+// D[i][j] += sum_k A[i][k] * B[k][j] on a 16x16 tile.
+//   a-fragment: lane l holds A[i = l&15][k-slots of group g = l>>4]
+//   b-fragment: lane l holds B[k-slots of group g][j = l&15]
+//   accumulator: lane l, reg r holds D[i = 4*g + r][j = l&15]
+// bf16: 8 k-slots per lane per instruction (K = 32); f32: 1 (K = 4).
+template <typename T> struct Mma;
+template <> struct Mma<bf16> {
+    static constexpr int KI = 32, KPL = 8;
+    typedef bf16x8 Frag;
+    static A8_DEV f32x4 mma(Frag a, Frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mma<float> {
+    static constexpr int KI = 4, KPL = 1;
+    typedef float Frag;
+    static A8_DEV f32x4 mma(Frag a, Frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+};
+
+// ---------------------------------------------------------------- LDS tile images
+// (1) "KC" tile: [ROWS][BK] with the reduction index contiguous.
+//     bf16: BK = 64 -> 128-byte rows, 16-byte chunk c stored at c ^ (row & 7)  (conflict-free b128 reads)
+//     f32 : BK = 16 -> rows of 20 floats (80 B)
+// (2) "KS" tile: [BK][128] with the row index contiguous (operand is K-strided in global memory).
+//     bf16: 256-byte k-rows, 32-byte chunk c stored at c ^ key(k); read with ds_read_b64_tr_b16
+//     f32 : k-rows of 144 floats
+template <typename T> struct Tile;
+template <> struct Tile<bf16> {
+    static constexpr int BK = 64;
+    static constexpr int KC_ROW_BYTES = 128;
+    static constexpr int KS_ROW_BYTES = 256;
+    static A8_DEV int kc_off(int row, int chunk16) { return row * 128 + ((chunk16 ^ (row & 7)) << 4); }
+    static A8_DEV int ks_key(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+    static A8_DEV int ks_off(int k, int piece16) { return k * 256 + ((((piece16 >> 1) ^ ks_key(k))) << 5) + ((piece16 & 1) << 4); }
+    // fragment of 16 rows starting at rb for the 32-wide k-step ks of a KC tile
+    static A8_DEV bf16x8 kc_frag(const char* tile, int rb, int ks, int lane) {
+        const int row = rb + (lane & 15);
+        return *reinterpret_cast<const bf16x8*>(tile + kc_off(row, ks * 4 + (lane >> 4)));
+    }
+    // same fragment from a KS tile (k-slot j of group g = k 8g + j), via two transposed reads
+    static A8_DEV bf16x8 ks_frag(const char* tile, int rb, int ks, int lane) {
+        const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+        const int nb = rb >> 4;
+        const int k0 = ks * 32 + 8 * g + q, k1 = k0 + 4;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, tile + k0 * 256 + ((nb ^ ks_key(k0)) << 5) + 8 * p));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, tile + k1 * 256 + ((nb ^ ks_key(k1)) << 5) + 8 * p));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    }
+};
+template <> struct Tile<float> {
+    static constexpr int BK = 16;
+    static constexpr int KC_ROW_BYTES = 80;
+    static constexpr int KS_ROW_BYTES = 576;
+    static A8_DEV int kc_off(int row, int chunk16) { return row * 80 + (chunk16 << 4); }
+    static A8_DEV int ks_off(int k, int piece16) { return k * 576 + (piece16 << 4); }
+    static A8_DEV float kc_frag(const char* tile, int rb, int ks, int lane) {
+        return *reinterpret_cast<const float*>(tile + (rb + (lane & 15)) * 80 + (ks * 4 + (lane >> 4)) * 4);
+    }
+    static A8_DEV float ks_frag(const char* tile, int rb, int ks, int lane) {
+        return *reinterpret_cast<const float*>(tile + (ks * 4 + (lane >> 4)) * 576 + (rb + (lane & 15)) * 4);
+    }
+};
+
+// XCD-aware bijective remap of a 1-D block id: consecutive logical ids land on one XCD
+// (blocks b and b+8 share an XCD under round-robin dispatch; speed only, never correctness).
+A8_DEV int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

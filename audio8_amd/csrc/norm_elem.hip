@@ -1,0 +1,581 @@
+// a8hip: HBM-bound row kernels -- LayerNorm fwd/bwd (with fused residual add + dropout), GELU backward
+// with bias reduction, mask fill / gather / scatter, col2im for the strided-conv dgrad, casts,
+// log-softmax, grad-norm and AdamW.  All loads/stores are 16 bytes per lane along the channel axis;
+// one wave owns a row, statistics and column sums stay in registers (wavefront shuffles), and column
+// sums leave the block as one f32 atomic per column.
+#include "a8_common.h"
+#include "a8hip_internal.h"
+
+namespace {
+
+template <typename T> A8_DEV void load8(const T* p, float (&v)[8]);
+template <> A8_DEV void load8<bf16>(const bf16* p, float (&v)[8]) {
+    const bf16x8 x = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)x[i];
+}
+template <> A8_DEV void load8<float>(const float* p, float (&v)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[i + 4] = b[i]; }
+}
+template <typename T> A8_DEV void store8(T* p, const float (&v)[8]);
+template <> A8_DEV void store8<bf16>(bf16* p, const float (&v)[8]) {
+    bf16x8 x;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = (bf16)v[i];
+    *reinterpret_cast<bf16x8*>(p) = x;
+}
+template <> A8_DEV void store8<float>(float* p, const float (&v)[8]) {
+    *reinterpret_cast<f32x4*>(p) = (f32x4){v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+}
+
+constexpr int MAXC = 3;   // chunks of 8 columns per lane -> cols <= 1536
+
+struct Drop { float scale; uint32_t thr, seed, stream; };
+static Drop make_drop(float p, uint32_t seed, uint32_t stream) {
+    Drop d;
+    d.scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    d.thr = p > 0.f ? (uint32_t)((double)p * 4294967296.0) : 0u;
+    d.seed = seed; d.stream = stream;
+    return d;
+}
+
+// ------------------------------------------------------------------ LayerNorm forward
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
+                                                     int rows, int cols, float eps, Drop dr) {
+    const int lane = threadIdx.x & 63, nch = cols >> 3;
+    const float inv = 1.0f / (float)cols;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+        float v[MAXC][8];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nch) {
+                const long long off = (long long)row * cols + ch * 8;
+                load8(x + off, v[c]);
+                if (dr.thr) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[c][i] = a8_keep(dr.seed, dr.stream, (uint32_t)(off + i), dr.thr) ? v[c][i] * dr.scale : 0.f;
+                }
+                if (res) {
+                    float r[8];
+                    load8(res + off, r);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[c][i] += r[i];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s += v[c][i];
+            }
+        }
+        const float mu = wave_sum(s) * inv;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (lane + 64 * c < nch) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const float d = v[c][i] - mu; q += d * d; }
+            }
+        const float rs = rsqrtf(wave_sum(q) * inv + eps);
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nch) {
+                float gm[8], bt[8], o[8];
+                load8(gamma + ch * 8, gm);
+                load8(beta + ch * 8, bt);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = (v[c][i] - mu) * rs * gm[i] + bt[i];
+                store8(y + (long long)row * cols + ch * 8, o);
+            }
+        }
+        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    }
+}
+
+// Column sums held per wave in registers -> LDS -> one atomic per column per block.
+// acc[c][i] belongs to column (lane + 64c)*8 + i.  lds: float[cols].
+A8_DEV void flush_colsum(float (&acc)[MAXC][8], float* lds, float* __restrict__ out, int cols) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nch = cols >> 3;
+    for (int i = threadIdx.x; i < cols; i += 256) lds[i] = 0.f;
+    __syncthreads();
+    for (int ww = 0; ww < 4; ++ww) {
+        if (w == ww) {
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c)
+                if (lane + 64 * c < nch) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) lds[(lane + 64 * c) * 8 + i] += acc[c][i];
+                }
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < cols; i += 256) atomicAdd(out + i, lds[i]);
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------ LayerNorm backward
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ dy2,
+                                                     const T* __restrict__ x, const T* __restrict__ res,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, T* __restrict__ dx, T* __restrict__ dres,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     int rows, int cols, Drop dr) {
+    __shared__ float lds[MAXC * 512];
+    const int lane = threadIdx.x & 63, nch = cols >> 3;
+    const float inv = 1.0f / (float)cols;
+    float ag[MAXC][8], ab[MAXC][8];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { ag[c][i] = 0.f; ab[c][i] = 0.f; }
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float xh[MAXC][8], g[MAXC][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nch) {
+                const long long off = (long long)row * cols + ch * 8;
+                float v[8], gm[8];
+                load8(x + off, v);
+                if (dr.thr) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = a8_keep(dr.seed, dr.stream, (uint32_t)(off + i), dr.thr) ? v[i] * dr.scale : 0.f;
+                }
+                if (res) {
+                    float r[8];
+                    load8(res + off, r);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] += r[i];
+                }
+                load8(dy + off, g[c]);
+                if (dy2) {
+                    float r[8];
+                    load8(dy2 + off, r);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) g[c][i] += r[i];
+                }
+                load8(gamma + ch * 8, gm);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    xh[c][i] = (v[i] - mu) * rs;
+                    ag[c][i] += g[c][i] * xh[c][i];
+                    ab[c][i] += g[c][i];
+                    g[c][i] *= gm[i];
+                    s1 += g[c][i];
+                    s2 += g[c][i] * xh[c][i];
+                }
+            }
+        }
+        const float a = wave_sum(s1) * inv, b = wave_sum(s2) * inv;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nch) {
+                const long long off = (long long)row * cols + ch * 8;
+                float o[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = rs * (g[c][i] - a - xh[c][i] * b);
+                if (dres) store8(dres + off, o);
+                if (dx) {
+                    if (dr.thr) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) o[i] = a8_keep(dr.seed, dr.stream, (uint32_t)(off + i), dr.thr) ? o[i] * dr.scale : 0.f;
+                    }
+                    store8(dx + off, o);
+                }
+            }
+        }
+    }
+    flush_colsum(ag, lds, dgamma, cols);
+    flush_colsum(ab, lds, dbeta, cols);
+}
+
+// ------------------------------------------------------------------ dz = dy * gelu'(z); dbias += colsum(dz)
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_bwd_bias_kernel(const T* __restrict__ dy, const T* __restrict__ z, T* __restrict__ dz,
+                                                            float* __restrict__ dbias, int rows, int cols) {
+    __shared__ float lds[MAXC * 512];
+    const int lane = threadIdx.x & 63, nch = cols >> 3;
+    float ab[MAXC][8];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ab[c][i] = 0.f;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nch) {
+                const long long off = (long long)row * cols + ch * 8;
+                float g[8], zz[8];
+                load8(dy + off, g);
+                load8(z + off, zz);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { g[i] *= gelu_grad_f(zz[i]); ab[c][i] += g[i]; }
+                store8(dz + off, g);
+            }
+        }
+    }
+    flush_colsum(ab, lds, dbias, cols);
+}
+
+// ------------------------------------------------------------------ mask fill (+ backward)
+template <typename T>
+__global__ void mask_fill_rows_kernel(T* __restrict__ x, const uint8_t* __restrict__ mask, const float* __restrict__ emb, int rows, int cols) {
+    const int nch = cols >> 3;
+    const long long total = (long long)rows * nch;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(i / nch), ch = (int)(i % nch);
+        if (mask[row]) {
+            float e[8];
+            load8(emb + ch * 8, e);
+            store8(x + (long long)row * cols + ch * 8, e);
+        }
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void mask_fill_rows_bwd_kernel(T* __restrict__ dy, const uint8_t* __restrict__ mask, float* __restrict__ demb, int rows, int cols) {
+    __shared__ float lds[MAXC * 512];
+    const int lane = threadIdx.x & 63, nch = cols >> 3;
+    float ab[MAXC][8];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ab[c][i] = 0.f;
+    const float zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+        if (!mask[row]) continue;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nch) {
+                const long long off = (long long)row * cols + ch * 8;
+                float g[8];
+                load8(dy + off, g);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ab[c][i] += g[i];
+                store8(dy + off, zero);
+            }
+        }
+    }
+    flush_colsum(ab, lds, demb, cols);
+}
+
+template <typename T>
+__global__ void mask_zero_cols_kernel(T* __restrict__ x, const uint8_t* __restrict__ cmask, int B, int Tn, int cols) {
+    const long long total = (long long)B * Tn * cols;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cols);
+        const int b = (int)(i / ((long long)Tn * cols));
+        if (cmask[b * cols + c]) x[i] = from_f<T>(0.f);
+    }
+}
+template <typename T>
+__global__ void zero_rows_kernel(T* __restrict__ x, const uint8_t* __restrict__ keep, int rows, int cols) {
+    const int nch = cols >> 3;
+    const long long total = (long long)rows * nch;
+    const float zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(i / nch), ch = (int)(i % nch);
+        if (!keep[row]) store8(x + (long long)row * cols + ch * 8, zero);
+    }
+}
+
+// ------------------------------------------------------------------ row gather / scatter-add
+template <typename T, bool SCATTER>
+__global__ void gather_rows_kernel(const T* __restrict__ src, const int32_t* __restrict__ idx, T* __restrict__ dst, int n, int cols) {
+    const int nch = cols >> 3;
+    const long long total = (long long)n * nch;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / nch), ch = (int)(i % nch);
+        float v[8];
+        if (!SCATTER) {
+            load8(src + (long long)idx[r] * cols + ch * 8, v);
+            store8(dst + (long long)r * cols + ch * 8, v);
+        } else {
+            float d[8];
+            T* dp = dst + (long long)idx[r] * cols + ch * 8;
+            load8(src + (long long)r * cols + ch * 8, v);
+            load8(dp, d);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[j] += v[j];
+            store8(dp, d);
+        }
+    }
+}
+
+template <typename T>
+__global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, long long n8) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        float u[8], v[8];
+        load8(a + i * 8, u);
+        load8(b + i * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) u[j] += v[j];
+        store8(y + i * 8, u);
+    }
+}
+
+template <typename T>
+__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, long long n8, Drop dr) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        float v[8];
+        load8(x + i * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = a8_keep(dr.seed, dr.stream, (uint32_t)(i * 8 + j), dr.thr) ? v[j] * dr.scale : 0.f;
+        store8(y + i * 8, v);
+    }
+}
+
+template <typename S, typename D>
+__global__ void cast_kernel(const S* __restrict__ s, D* __restrict__ d, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        d[i] = (D)(float)s[i];
+}
+
+// ------------------------------------------------------------------ col2im * gelu'(z) for the strided conv dgrad
+template <typename T>
+__global__ void col2im_kernel(const T* __restrict__ dcol, const T* __restrict__ z, T* __restrict__ dx,
+                              int B, int Lin, int Lout, int Cc, int k, int stride) {
+    const int nch = Cc >> 3;
+    const long long total = (long long)B * Lin * nch;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % nch);
+        const long long bp = i / nch;
+        const int p = (int)(bp % Lin), b = (int)(bp / Lin);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int kk = 0; kk < k; ++kk) {
+            const int q = p - kk;
+            if (q < 0 || q % stride) continue;
+            const int tt = q / stride;
+            if (tt >= Lout) continue;
+            float v[8];
+            load8(dcol + ((long long)(b * Lout + tt) * k + kk) * Cc + ch * 8, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += v[j];
+        }
+        const long long off = bp * Cc + ch * 8;
+        if (z) {
+            float zz[8];
+            load8(z + off, zz);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] *= gelu_grad_f(zz[j]);
+        }
+        store8(dx + off, acc);
+    }
+}
+
+// ------------------------------------------------------------------ log-softmax (cols <= 64), one wave per row
+template <typename T>
+__global__ void log_softmax_fwd_kernel(const T* __restrict__ x, float* __restrict__ y, int rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+        const float v = lane < cols ? to_f(x[(long long)row * cols + lane]) : -INFINITY;
+        const float m = wave_max(v);
+        const float s = wave_sum(lane < cols ? __expf(v - m) : 0.f);
+        if (lane < cols) y[(long long)row * cols + lane] = v - m - __logf(s);
+    }
+}
+template <typename T>
+__global__ void log_softmax_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, T* __restrict__ dx, int rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+        const float g = lane < cols ? dy[(long long)row * cols + lane] : 0.f;
+        const float s = wave_sum(g);
+        if (lane < cols) dx[(long long)row * cols + lane] = from_f<T>(g - __expf(y[(long long)row * cols + lane]) * s);
+    }
+}
+
+// ------------------------------------------------------------------ grad-norm + AdamW
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long long n, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const long long n4 = n >> 2;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += gridDim.x * 256ll) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = x[n4 * 4 + threadIdx.x]; s += v * v; }
+    s = block_sum<4>(s, red);
+    if (threadIdx.x == 0) atomicAdd(out, s);
+}
+
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                             long long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s,
+                             const float* __restrict__ gnorm_sq, float max_norm, float grad_scale) {
+    float clip = grad_scale;
+    if (gnorm_sq && max_norm > 0.f) {
+        const float nrm = sqrtf(gnorm_sq[0]) * grad_scale;
+        clip *= fminf(1.0f, max_norm / (nrm + 1e-6f));     // torch.nn.utils.clip_grad_norm_
+    }
+    const float step = lr / bc1;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * clip;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float pi = p[i] * (1.f - lr * wd);
+        p[i] = pi - step * mi / (sqrtf(vi) / bc2s + eps);
+    }
+}
+
+int grid_for(long long work, int per_block) {
+    long long b = (work + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > 4096) b = 4096;
+    return (int)b;
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, ...)                                             \
+    do {                                                                   \
+        if ((dtype) == A8_BF16) { typedef bf16 T; __VA_ARGS__; }           \
+        else if ((dtype) == A8_F32) { typedef float T; __VA_ARGS__; }      \
+        else return a8_set_error(A8_ERR_ARG, "bad dtype %d", (dtype));     \
+    } while (0)
+
+extern "C" int a8_layernorm_fwd(int dtype, const void* x, const void* res, const float* gamma, const float* beta, void* y,
+                                float* mean, float* rstd, int rows, int cols, float eps, float p, uint32_t seed, uint32_t rng_stream, void* stream) {
+    A8_REQUIRE(cols % 8 == 0 && cols <= MAXC * 512, "a8_layernorm_fwd: cols=%d must be a multiple of 8 and <= %d", cols, MAXC * 512);
+    A8_REQUIRE(p >= 0.f && p < 1.f, "a8_layernorm_fwd: bad dropout p");
+    if (rows == 0) return A8_OK;
+    const Drop dr = make_drop(p, seed, rng_stream);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(ln_fwd_kernel<T>, dim3(grid_for(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                                         (const T*)x, (const T*)res, gamma, beta, (T*)y, mean, rstd, rows, cols, eps, dr));
+    return a8_check_launch("a8_layernorm_fwd");
+}
+
+extern "C" int a8_layernorm_bwd(int dtype, const void* dy, const void* dy2, const void* x, const void* res, const float* gamma,
+                                const float* mean, const float* rstd, void* dx, void* dres, float* dgamma, float* dbeta,
+                                int rows, int cols, float p, uint32_t seed, uint32_t rng_stream, void* stream) {
+    A8_REQUIRE(cols % 8 == 0 && cols <= MAXC * 512, "a8_layernorm_bwd: cols=%d must be a multiple of 8 and <= %d", cols, MAXC * 512);
+    if (rows == 0) return A8_OK;
+    const Drop dr = make_drop(p, seed, rng_stream);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(ln_bwd_kernel<T>, dim3(grid_for(rows, 32)), dim3(256), 0, (hipStream_t)stream,
+                                         (const T*)dy, (const T*)dy2, (const T*)x, (const T*)res, gamma, mean, rstd, (T*)dx, (T*)dres,
+                                         dgamma, dbeta, rows, cols, dr));
+    return a8_check_launch("a8_layernorm_bwd");
+}
+
+extern "C" int a8_gelu_bwd_bias(int dtype, const void* dy, const void* z, void* dz, float* dbias, int rows, int cols, void* stream) {
+    A8_REQUIRE(cols % 8 == 0 && cols <= MAXC * 512, "a8_gelu_bwd_bias: cols=%d unsupported", cols);
+    if (rows == 0) return A8_OK;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(gelu_bwd_bias_kernel<T>, dim3(grid_for(rows, 32)), dim3(256), 0, (hipStream_t)stream,
+                                         (const T*)dy, (const T*)z, (T*)dz, dbias, rows, cols));
+    return a8_check_launch("a8_gelu_bwd_bias");
+}
+
+extern "C" int a8_mask_fill_rows(int dtype, void* x, const uint8_t* mask, const float* emb, int rows, int cols, void* stream) {
+    A8_REQUIRE(cols % 8 == 0, "a8_mask_fill_rows: cols must be a multiple of 8");
+    if (rows == 0) return A8_OK;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(mask_fill_rows_kernel<T>, dim3(grid_for((long long)rows * cols / 8, 256)), dim3(256), 0,
+                                         (hipStream_t)stream, (T*)x, mask, emb, rows, cols));
+    return a8_check_launch("a8_mask_fill_rows");
+}
+extern "C" int a8_mask_fill_rows_bwd(int dtype, void* dy, const uint8_t* mask, float* demb, int rows, int cols, void* stream) {
+    A8_REQUIRE(cols % 8 == 0 && cols <= MAXC * 512, "a8_mask_fill_rows_bwd: cols=%d unsupported", cols);
+    if (rows == 0) return A8_OK;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(mask_fill_rows_bwd_kernel<T>, dim3(grid_for(rows, 32)), dim3(256), 0, (hipStream_t)stream,
+                                         (T*)dy, mask, demb, rows, cols));
+    return a8_check_launch("a8_mask_fill_rows_bwd");
+}
+extern "C" int a8_mask_zero_cols(int dtype, void* x, const uint8_t* cmask, int B, int T_, int cols, void* stream) {
+    if ((long long)B * T_ * cols == 0) return A8_OK;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(mask_zero_cols_kernel<T>, dim3(grid_for((long long)B * T_ * cols, 256)), dim3(256), 0,
+                                         (hipStream_t)stream, (T*)x, cmask, B, T_, cols));
+    return a8_check_launch("a8_mask_zero_cols");
+}
+extern "C" int a8_zero_rows(int dtype, void* x, const uint8_t* keep, int rows, int cols, void* stream) {
+    A8_REQUIRE(cols % 8 == 0, "a8_zero_rows: cols must be a multiple of 8");
+    if (rows == 0) return A8_OK;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(zero_rows_kernel<T>, dim3(grid_for((long long)rows * cols / 8, 256)), dim3(256), 0,
+                                         (hipStream_t)stream, (T*)x, keep, rows, cols));
+    return a8_check_launch("a8_zero_rows");
+}
+extern "C" int a8_gather_rows(int dtype, const void* src, const int32_t* idx, void* dst, int n, int cols, void* stream) {
+    A8_REQUIRE(cols % 8 == 0, "a8_gather_rows: cols must be a multiple of 8");
+    if (n == 0) return A8_OK;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((gather_rows_kernel<T, false>), dim3(grid_for((long long)n * cols / 8, 256)), dim3(256), 0,
+                                         (hipStream_t)stream, (const T*)src, idx, (T*)dst, n, cols));
+    return a8_check_launch("a8_gather_rows");
+}
+extern "C" int a8_scatter_add_rows(int dtype, const void* src, const int32_t* idx, void* dst, int n, int cols, void* stream) {
+    A8_REQUIRE(cols % 8 == 0, "a8_scatter_add_rows: cols must be a multiple of 8");
+    if (n == 0) return A8_OK;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((gather_rows_kernel<T, true>), dim3(grid_for((long long)n * cols / 8, 256)), dim3(256), 0,
+                                         (hipStream_t)stream, (const T*)src, idx, (T*)dst, n, cols));
+    return a8_check_launch("a8_scatter_add_rows");
+}
+extern "C" int a8_add(int dtype, const void* a, const void* b, void* y, int64_t n, void* stream) {
+    A8_REQUIRE(n % 8 == 0, "a8_add: n must be a multiple of 8");
+    if (n == 0) return A8_OK;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(add_kernel<T>, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream,
+                                         (const T*)a, (const T*)b, (T*)y, (long long)(n / 8)));
+    return a8_check_launch("a8_add");
+}
+extern "C" int a8_dropout(int dtype, const void* x, void* y, int64_t n, float p, uint32_t seed, uint32_t rng_stream, void* stream) {
+    A8_REQUIRE(n % 8 == 0, "a8_dropout: n must be a multiple of 8");
+    A8_REQUIRE(p >= 0.f && p < 1.f && n < (1ll << 32), "a8_dropout: bad p or n");
+    if (n == 0) return A8_OK;
+    const Drop dr = make_drop(p, seed, rng_stream);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(dropout_kernel<T>, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream,
+                                         (const T*)x, (T*)y, (long long)(n / 8), dr));
+    return a8_check_launch("a8_dropout");
+}
+extern "C" int a8_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream) {
+    if (n == 0) return A8_OK;
+    const dim3 g(grid_for(n, 256)), b(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (src_dtype == A8_F32 && dst_dtype == A8_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16>), g, b, 0, s, (const float*)src, (bf16*)dst, (long long)n);
+    else if (src_dtype == A8_BF16 && dst_dtype == A8_F32) hipLaunchKernelGGL((cast_kernel<bf16, float>), g, b, 0, s, (const bf16*)src, (float*)dst, (long long)n);
+    else if (src_dtype == A8_F32 && dst_dtype == A8_F32) hipLaunchKernelGGL((cast_kernel<float, float>), g, b, 0, s, (const float*)src, (float*)dst, (long long)n);
+    else if (src_dtype == A8_BF16 && dst_dtype == A8_BF16) hipLaunchKernelGGL((cast_kernel<bf16, bf16>), g, b, 0, s, (const bf16*)src, (bf16*)dst, (long long)n);
+    else return a8_set_error(A8_ERR_ARG, "a8_cast: bad dtypes %d -> %d", src_dtype, dst_dtype);
+    return a8_check_launch("a8_cast");
+}
+extern "C" int a8_col2im_gelu_grad(int dtype, const void* dcol, const void* z, void* dx, int B, int Lin, int Lout, int C_, int k, int stride, void* stream) {
+    A8_REQUIRE(C_ % 8 == 0 && k >= 1 && stride >= 1, "a8_col2im_gelu_grad: bad shape");
+    A8_REQUIRE((Lout - 1) * stride + k <= Lin, "a8_col2im_gelu_grad: Lout=%d does not fit Lin=%d", Lout, Lin);
+    if ((long long)B * Lin == 0) return A8_OK;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(col2im_kernel<T>, dim3(grid_for((long long)B * Lin * C_ / 8, 256)), dim3(256), 0, (hipStream_t)stream,
+                                         (const T*)dcol, (const T*)z, (T*)dx, B, Lin, Lout, C_, k, stride));
+    return a8_check_launch("a8_col2im_gelu_grad");
+}
+extern "C" int a8_log_softmax_fwd(const void* x, int dtype, float* y, int rows, int cols, void* stream) {
+    A8_REQUIRE(cols >= 1 && cols <= 64, "a8_log_softmax_fwd: cols=%d must be in [1,64]", cols);
+    if (rows == 0) return A8_OK;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(log_softmax_fwd_kernel<T>, dim3(grid_for(rows, 4)), dim3(256), 0, (hipStream_t)stream, (const T*)x, y, rows, cols));
+    return a8_check_launch("a8_log_softmax_fwd");
+}
+extern "C" int a8_log_softmax_bwd(const float* y, const float* dy, void* dx, int dtype, int rows, int cols, void* stream) {
+    A8_REQUIRE(cols >= 1 && cols <= 64, "a8_log_softmax_bwd: cols=%d must be in [1,64]", cols);
+    if (rows == 0) return A8_OK;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(log_softmax_bwd_kernel<T>, dim3(grid_for(rows, 4)), dim3(256), 0, (hipStream_t)stream, y, dy, (T*)dx, rows, cols));
+    return a8_check_launch("a8_log_softmax_bwd");
+}
+extern "C" int a8_sumsq(const float* x, int64_t n, float* out, void* stream) {
+    if (n == 0) return A8_OK;
+    A8_REQUIRE(((uintptr_t)x % 16) == 0, "a8_sumsq: x must be 16-byte aligned");
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4 + 1, 1024)), dim3(256), 0, (hipStream_t)stream, x, (long long)n, out);
+    return a8_check_launch("a8_sumsq");
+}
+extern "C" int a8_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int step, const float* gnorm_sq, float max_norm, float grad_scale, void* stream) {
+    A8_REQUIRE(step >= 1, "a8_adamw: step counts from 1");
+    if (n == 0) return A8_OK;
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n, lr, beta1, beta2, eps,
+                       weight_decay, bc1, bc2s, gnorm_sq, max_norm, grad_scale);
+    return a8_check_launch("a8_adamw");
+}

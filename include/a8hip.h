@@ -1,0 +1,166 @@
+/* a8hip -- C ABI of the MI355X-native wav2vec2 hot path (drop-in for mead-ml/audio8's
+ * audio8/wav2vec2.py + audio8/ctc.py forward/backward).
+ *
+ * The reference has no FFI of its own (it is pure Python over ATen); this header is the
+ * boundary a maintainer binds with ctypes.  Every entry point takes raw device
+ * pointers, explicit sizes, a dtype enum and the HIP stream to launch on, and returns 0 on success
+ * or a non-zero status whose text a8_last_error() gives.  No entry point allocates, synchronises or
+ * aborts; a failed call leaves the stream usable (audio8/train.py:294,400 catches per-step errors
+ * and continues, so must we).
+ *
+ * Activation layout is channels-last everywhere: [B, T, C] row-major ("rows" = B*T).  dtype is the
+ * activation type (A8_BF16 or A8_F32); statistics, losses, weight gradients and optimizer state are
+ * always f32.  Each declaration cites the reference code it replaces.
+ */
+#ifndef A8HIP_H
+#define A8HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define A8HIP_VERSION 100
+
+enum { A8_DT_F32 = 0, A8_DT_BF16 = 1 };
+enum { A8_GEMM_NT = 0, A8_GEMM_NN = 1, A8_GEMM_TN = 2 };
+enum { A8_ACT_NONE = 0, A8_ACT_GELU = 1, A8_ACT_MUL_GELU_GRAD = 2 };
+
+int a8_version(void);
+const char* a8_last_error(void);      /* thread-local text of the last non-zero status */
+
+/* ---- dense contraction: every Linear / Dense / strided Conv1d(512->512) of the path -------------
+ * Replaces F.linear inside eight_mile Dense (audio8/wav2vec2.py:909,916-917,684,762), the q/k/v/o and
+ * FFN projections of TransformerEncoderStack (:613-622) and, through the row remap, nn.Conv1d layers
+ * 1..6 of ConvFeatureExtractionModel (:425-429).
+ * C[M,N] = epi(alpha * A . B^T + bias);  layout NT: A[M][K],B[N][K]; NN: A[M][K],B[K][N]; TN: A[K][M],B[K][N].
+ * Outer index o of an operand addresses (o / rpb) * bs + (o % rpb) * ld elements (rpb = 0: o * ld). */
+typedef struct a8_gemm_desc {
+    int dtype, layout;
+    int M, N, K;
+    const void* A; int64_t lda, a_rpb, a_bs;
+    const void* B; int64_t ldb, b_rpb, b_bs;
+    void* C;       int64_t ldc, c_rpb, c_bs;
+    const float* bias;  int bias_rows;   /* bias[N] (or bias[M] when bias_rows) */
+    int act;                              /* A8_ACT_* ; MUL_GELU_GRAD multiplies by gelu'(zin) */
+    const void* zin; void* zout; int64_t ldz;   /* zout: pre-activation copy (dtype), same rows as C */
+    int out_f32;                          /* C is f32 regardless of dtype */
+    int accumulate;                       /* C += (f32 atomics) */
+    int splitk;                           /* >1: split the K range over workgroups (f32 atomics) */
+    float alpha;
+} a8_gemm_desc;
+int a8_gemm(const a8_gemm_desc* d, void* stream);
+
+/* ---- conv layer 0 + GroupNorm + GELU (audio8/wav2vec2.py:417-423, Cin=1, k=10, s=5) --------------
+ * x f32 [B,L]; w f32 [C,10]; out dtype [B,L0,C] channels-last; stats f32 [B,C,2] = (mean, rstd).
+ * part is scratch f32 [B, nchunk, C, 2] with nchunk = ceil(L0 / 256). */
+int a8_conv0_gn_gelu_fwd(int dtype, const float* x, const float* w, const float* gn_w, const float* gn_b,
+                         void* out, float* stats, float* part, int B, int L, int C, float eps, void* stream);
+/* backward: dout dtype [B,L0,C] -> dw f32 [C,10], dgn_w, dgn_b f32 [C] (all accumulated, +=).
+ * red is scratch f32 [B,C,2] (zeroed by the call). */
+int a8_conv0_gn_gelu_bwd(int dtype, const float* x, const float* w, const float* gn_w, const float* gn_b,
+                         const float* stats, const void* dout, float* dw, float* dgn_w, float* dgn_b,
+                         float* red, int B, int L, int C, void* stream);
+
+/* ---- strided conv dgrad scatter (col2im) fused with GELU' (layers 1..6 backward) ----------------
+ * dcol dtype [B*Lout, k*C] (one GEMM row per output frame) -> dx dtype [B,Lin,C]:
+ * dx[b,p,c] = gelu'(z[b,p,c]) * sum_{t*stride+kk = p} dcol[b,t,kk,c]   (z = pre-activation of the layer below;
+ * z == NULL: no GELU' factor) */
+int a8_col2im_gelu_grad(int dtype, const void* dcol, const void* z, void* dx, int B, int Lin, int Lout, int C,
+                        int k, int stride, void* stream);
+
+/* ---- LayerNorm (nn.LayerNorm audio8/wav2vec2.py:904,623 and eight_mile ln1/ln2) ------------------
+ * y = LN(res + dropout(x)) * gamma + beta over the last dim; res may be NULL; p = 0 disables dropout.
+ * mean/rstd f32 [rows] are saved for backward. */
+int a8_layernorm_fwd(int dtype, const void* x, const void* res, const float* gamma, const float* beta, void* y,
+                     float* mean, float* rstd, int rows, int cols, float eps, float p, uint32_t seed, uint32_t rng_stream,
+                     void* stream);
+/* dy (+ dy2 if non-NULL) -> ds = d(res + dropout(x)); writes dres = ds (if dres) and dx = ds * keep/(1-p) (if dx);
+ * dgamma/dbeta f32 [cols] accumulated (+=). */
+int a8_layernorm_bwd(int dtype, const void* dy, const void* dy2, const void* x, const void* res, const float* gamma,
+                     const float* mean, const float* rstd, void* dx, void* dres, float* dgamma, float* dbeta,
+                     int rows, int cols, float p, uint32_t seed, uint32_t rng_stream, void* stream);
+
+/* ---- element-wise helpers ----------------------------------------------------------------------- */
+int a8_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream);
+/* y = x * keep / (1-p); the same call with the same (seed, rng_stream) is its own backward. (nn.Dropout) */
+int a8_dropout(int dtype, const void* x, void* y, int64_t n, float p, uint32_t seed, uint32_t rng_stream, void* stream);
+/* features[time_mask] = mask_emb (audio8/wav2vec2.py:939,717): x dtype [rows,cols] in place, mask u8[rows], emb f32[cols] */
+int a8_mask_fill_rows(int dtype, void* x, const uint8_t* mask, const float* emb, int rows, int cols, void* stream);
+/* backward: demb[cols] += sum over masked rows of dy; dy[masked rows] = 0 (in place) */
+int a8_mask_fill_rows_bwd(int dtype, void* dy, const uint8_t* mask, float* demb, int rows, int cols, void* stream);
+/* x[:, c] = 0 where cmask[b, c]  (channel mask, audio8/wav2vec2.py:718-721); cmask u8 [B, cols]; same call is its backward */
+int a8_mask_zero_cols(int dtype, void* x, const uint8_t* cmask, int B, int T, int cols, void* stream);
+/* x[row] = 0 where !keep[row]  (x[~pad_mask] = 0, audio8/wav2vec2.py:631-632) */
+int a8_zero_rows(int dtype, void* x, const uint8_t* keep, int rows, int cols, void* stream);
+/* dst[i] = src[idx[i]] (masked gather :946) / dst[idx[i]] += src[i] (its backward; dst dtype, unique idx) */
+int a8_gather_rows(int dtype, const void* src, const int32_t* idx, void* dst, int n, int cols, void* stream);
+int a8_scatter_add_rows(int dtype, const void* src, const int32_t* idx, void* dst, int n, int cols, void* stream);
+/* y = a + b */
+int a8_add(int dtype, const void* a, const void* b, void* y, int64_t n, void* stream);
+
+/* ---- positional conv (eight_mile Conv1DSame(d,d,k=128,groups=16)+GELU, audio8/wav2vec2.py:600-609,634-638)
+ * x dtype [B,T,d]; w dtype [G][d/G out][k][d/G in] (weight-normed, re-laid-out by the host); bias f32[d].
+ * y = x + gelu(conv(x) + bias) when add_residual, z (pre-GELU, dtype) saved for backward.
+ * The same kernel computes the data gradient when given the flipped/transposed weights and pads swapped. */
+int a8_posconv_fwd(int dtype, const void* x, const void* w, const float* bias, void* y, void* z,
+                   int B, int T, int d, int groups, int k, int pad_left, int add_residual, void* stream);
+/* dw f32 [G][dg_out][k][dg_in] += sum_{b,t} dz[b,t,co] x[b,t+kk-pad_left,ci] */
+int a8_posconv_wgrad(int dtype, const void* x, const void* dz, float* dw, int B, int T, int d, int groups, int k,
+                     int pad_left, void* stream);
+/* dz = dy * gelu'(z); dbias[d] += sum rows dz */
+int a8_gelu_bwd_bias(int dtype, const void* dy, const void* z, void* dz, float* dbias, int rows, int cols, void* stream);
+
+/* ---- multi-head self-attention core (eight_mile SeqScaledDotProductAttention) ----
+ * q,k,v,o dtype, element (b,t,h,c) at ((b*T + t) * ld + h*64 + c); head dim is 64.
+ * keymask u8 [B,T] (1 = attend) or NULL; masked scores are filled with -1e9 before softmax as the reference does.
+ * dropout on the attention probabilities with keep-prob 1-p (p = 0: off).  lse f32 [B,H,T] saved for backward. */
+int a8_attn_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* keymask,
+                int B, int T, int H, int64_t ld_qkv, int64_t ld_o, float scale, float p, uint32_t seed, void* stream);
+/* delta is scratch f32 [B,H,T] */
+int a8_attn_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                const uint8_t* keymask, void* dq, void* dk, void* dv, float* delta, int B, int T, int H, int64_t ld_qkv,
+                int64_t ld_o, int64_t ld_dqkv, float scale, float p, uint32_t seed, void* stream);
+
+/* ---- Gumbel-softmax product quantiser (GumbelVectorQuantizer.forward audio8/wav2vec2.py:547-576) ----
+ * logits f32 [R, V] (R = B*Tm*G rows), gumbel f32 [R,V] or NULL (eval: plain argmax);
+ * codes i32 [R]; ysoft_sel f32 [R] (y_soft at the chosen code); avg_probs f32 [V] (zeroed by the call) */
+int a8_vq_select(const float* logits, const float* gumbel, float tau, int32_t* codes, float* avg_probs, int R, int V, void* stream);
+/* q[n, g*D + :] = vars[g*V + codes[n*G+g], :]  (codebook gather; vars f32 [G*V, D]); q dtype [N, G*D] */
+int a8_vq_gather(int dtype, const float* vars, const int32_t* codes, void* q, int N, int G, int V, int D, void* stream);
+/* prob_ppl = sum exp(-sum p log(p + 1e-7)) over avg_probs[V] -> ppl[0]; dppl_davg[V] */
+int a8_vq_ppl(const float* avg_probs, float* ppl, float* dppl_davg, int V, void* stream);
+/* backward: dq dtype [N, G*D]; dvars f32 [G*V, D] += ; dlogits f32 [R,V] =
+ *   straight-through soft path: d/dlogits of sum_v ysoft_v * <dq_g, vars_v>  (ysoft = softmax((logits+gumbel)/tau))
+ * + diversity path: gppl * dppl/dlogits through avg_probs = mean softmax(logits). */
+int a8_vq_bwd(int dtype, const float* logits, const float* gumbel, float tau, const int32_t* codes, const float* vars,
+              const void* dq, const float* dppl_davg, const float* gppl, float* dlogits, float* dvars,
+              int N, int G, int V, int D, int training, void* stream);
+
+/* ---- negatives gather + cosine + cross-entropy (Sampler.negatives + Wav2Vec2Loss, audio8/wav2vec2.py:371-392,955-976)
+ * ctx dtype [B*Tm, C] (context at masked frames), lat dtype [B*Tm, C] (quantised latents), neg_idx i32 [B*Tm, N]
+ * (row indices into lat).  logits f32 [B*Tm, N+1] (column 0 = positive), loss_sum f32[1] += sum_rows CE(row, 0). */
+int a8_contrastive_fwd(int dtype, const void* ctx, const void* lat, const int32_t* neg_idx, float* logits,
+                       float* loss_sum, int rows, int N, int C, void* stream);
+/* dctx, dlat f32 [rows, C] (dlat accumulated with atomics: zero it first); gscale multiplies d(loss_sum). */
+int a8_contrastive_bwd(int dtype, const void* ctx, const void* lat, const int32_t* neg_idx, const float* logits,
+                       const float* gscale, float* dctx, float* dlat, int rows, int N, int C, void* stream);
+
+/* ---- CTC (F.ctc_loss native path, audio8/ctc.py:186-206) + log_softmax head (audio8/wav2vec2.py:770) ----
+ * lp f32 [T,B,V] log-probs; targets i32 flat (PAD/EOS already stripped), tgt_off i32 [B+1]; nll f32 [B];
+ * alpha is scratch f32 [B, T, 2*Smax+1]; grad f32 [T,B,V] = d nll_b / d lp (zero_infinity applied). */
+int a8_ctc_fwd_bwd(const float* lp, const int32_t* targets, const int32_t* tgt_off, const int32_t* in_len,
+                   float* nll, float* grad, float* alpha, int T, int B, int V, int Smax, int blank, int zero_infinity,
+                   void* stream);
+int a8_log_softmax_fwd(const void* x, int dtype, float* y, int rows, int cols, void* stream);
+int a8_log_softmax_bwd(const float* y, const float* dy, void* dx, int dtype, int rows, int cols, void* stream);
+
+/* ---- optimizer step either side of the path (clip_grad_norm_ + AdamW, audio8/pretrain.py:182-184) ----
+ * a8_sumsq: out[0] += sum x^2 ;  a8_adamw: p,m,v updated in place with g * min(1, max_norm / (sqrt(gnorm_sq[0]) + 1e-6)). */
+int a8_sumsq(const float* x, int64_t n, float* out, void* stream);
+int a8_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+             float weight_decay, int step, const float* gnorm_sq, float max_norm, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,105 @@
+"""GPU parity of a8_gemm against a CPU fp64 matmul (the oracle for a plain contraction)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(shape, dtype, seed, integer=False):
+    g = torch.Generator().manual_seed(seed)
+    if integer:
+        t = torch.randint(-3, 4, shape, generator=g).float()
+    else:
+        t = torch.randn(shape, generator=g)
+    return t.to(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("layout", ["NT", "NN", "TN"])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 104), (781, 768, 512), (48, 32, 2056), (130, 260, 72)])
+def test_gemm_layouts_exact_integers(dtype, layout, M, N, K):
+    """Small-integer operands: every product and partial sum is exact in bf16-in/f32-acc and f32,
+    so any wrong lane map / k-slot / transposed read shows up as a hard mismatch."""
+    from audio8_amd import kernels as Kn, _lib as L
+    if layout == "TN" and (M % 8 or N % 8):
+        M, N = (M + 7) // 8 * 8, (N + 7) // 8 * 8
+    if layout == "NN" and N % 8:
+        N = (N + 7) // 8 * 8
+    A = _mk((M, K), dtype, 1, integer=True)
+    B = _mk((N, K), dtype, 2, integer=True)
+    ref = A.double() @ B.double().T
+    dev = "cuda"
+    if layout == "NT":
+        out = Kn.gemm(L.NT, A.to(dev), B.to(dev), M, N, K)
+    elif layout == "NN":
+        out = Kn.gemm(L.NN, A.to(dev), B.T.contiguous().to(dev), M, N, K)
+    else:
+        out = Kn.gemm(L.TN, A.T.contiguous().to(dev), B.T.contiguous().to(dev), M, N, K, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    got = out.cpu().double()
+    if dtype == torch.bfloat16 and layout != "TN":
+        ref = ref.to(torch.bfloat16).double()   # output rounding only
+    assert torch.equal(got, ref), f"max diff {(got - ref).abs().max().item()}"
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 1.5e-2)])
+def test_gemm_epilogues(dtype, tol):
+    from audio8_amd import kernels as Kn, _lib as L
+    M, N, K = 300, 256, 192
+    A, B = _mk((M, K), dtype, 3), _mk((N, K), dtype, 4)
+    bias = _mk((N,), torch.float32, 5)
+    z_ref = (A.double() @ B.double().T) / math.sqrt(K) + bias.double()
+    dev = "cuda"
+    zout = torch.empty((M, N), device=dev, dtype=dtype)
+    out = Kn.gemm(L.NT, A.to(dev), B.to(dev), M, N, K, bias=bias.to(dev), act=L.ACT_GELU, zout=zout, alpha=1 / math.sqrt(K))
+    np.testing.assert_allclose(zout.float().cpu().numpy(), z_ref.float().numpy(), rtol=tol, atol=tol)
+    np.testing.assert_allclose(out.float().cpu().numpy(), torch.nn.functional.gelu(z_ref).float().numpy(), rtol=tol, atol=tol)
+    # dgrad with fused gelu'(z): dx = (dy . W) * gelu'(z)
+    dY = _mk((M, N), dtype, 6)
+    W = _mk((N, K), dtype, 7)
+    Z = _mk((M, K), dtype, 8)
+    zz = Z.double().requires_grad_(True)
+    torch.nn.functional.gelu(zz).sum().backward()
+    ref = (dY.double() @ W.double()) / math.sqrt(N) * zz.grad
+    got = Kn.gemm(L.NN, dY.to(dev), W.to(dev), M, K, N, act=L.ACT_MUL_GELU_GRAD, zin=Z.to(dev), ldz=K, alpha=1 / math.sqrt(N))
+    np.testing.assert_allclose(got.float().cpu().numpy(), ref.float().numpy(), rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_splitk_wgrad_and_accumulate(dtype):
+    from audio8_amd import kernels as Kn, _lib as L
+    Mred, N, K = 1000, 64, 136          # dW[N,K] = dY^T[N,Mred] . X[Mred,K]
+    dY, X = _mk((Mred, N), dtype, 9, integer=True), _mk((Mred, K), dtype, 10, integer=True)
+    ref = dY.double().T @ X.double()
+    dev = "cuda"
+    out = torch.ones((N, K), device=dev, dtype=torch.float32)
+    Kn.gemm(L.TN, dY.to(dev), X.to(dev), N, K, Mred, out=out, accumulate=True, splitk=5)
+    assert torch.equal(out.cpu().double(), ref + 1.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_as_gemm_row_remap(dtype):
+    """Strided Conv1d(C->C, k=3, s=2) over a channels-last activation as one NT GEMM over overlapping rows."""
+    from audio8_amd import kernels as Kn, _lib as L
+    Bn, Lin, Cc, k, s = 3, 41, 64, 3, 2
+    Lout = (Lin - k) // s + 1
+    x = _mk((Bn, Lin, Cc), dtype, 11, integer=True)
+    w = _mk((Cc, Cc, k), dtype, 12, integer=True)                # [Cout, Cin, k]
+    ref = torch.nn.functional.conv1d(x.double().transpose(1, 2), w.double(), stride=s).transpose(1, 2)   # [B,Lout,C]
+    w2 = w.permute(0, 2, 1).contiguous().view(Cc, k * Cc)        # [Cout][kk*C + ci]
+    dev = "cuda"
+    out = Kn.gemm(L.NT, x.to(dev), w2.to(dev), Bn * Lout, Cc, k * Cc, lda=s * Cc, a_rpb=Lout, a_bs=Lin * Cc)
+    got = out.view(Bn, Lout, Cc).cpu().double()
+    if dtype == torch.bfloat16:
+        ref = ref.to(torch.bfloat16).double()
+    assert torch.equal(got, ref)
+
+
+def test_gemm_rejects_bad_args():
+    from audio8_amd import kernels as Kn, _lib as L
+    A = torch.zeros((16, 12), device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="multiple of"):
+        Kn.gemm(L.NT, A, A, 16, 16, 12)
