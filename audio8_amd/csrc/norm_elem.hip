@@ -216,16 +216,21 @@ __global__ __launch_bounds__(256) void gelu_bwd_bias_kernel(const T* __restrict_
             const int ch = lane + 64 * c;
             if (ch < nch) {
                 const long long off = (long long)row * cols + ch * 8;
-                float g[8], zz[8];
+                float g[8];
                 load8(dy + off, g);
-                load8(z + off, zz);
+                if (z) {
+                    float zz[8];
+                    load8(z + off, zz);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { g[i] *= gelu_grad_f(zz[i]); ab[c][i] += g[i]; }
-                store8(dz + off, g);
+                    for (int i = 0; i < 8; ++i) g[i] *= gelu_grad_f(zz[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ab[c][i] += g[i];
+                if (dz) store8(dz + off, g);
             }
         }
     }
-    flush_colsum(ab, lds, dbias, cols);
+    if (dbias) flush_colsum(ab, lds, dbias, cols);
 }
 
 // ------------------------------------------------------------------ mask fill (+ backward)

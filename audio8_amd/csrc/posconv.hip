@@ -1,0 +1,288 @@
+// a8hip: convolutional positional embedding (grouped Conv1d(d, d, k=128, groups=16) + bias + GELU, "same"
+// padding) of AudioTransformerEncoder -- audio8/wav2vec2.py:599-609 (ctor), 634-638 (use).
+//
+// Implicit GEMM per group on MFMA: out[t][co] = sum_{kk,ci} xpad[t+kk][ci] * W[co][kk][ci].
+// A block owns 256 frames of one (utterance, group): the 256+127-row sliding window of the group's dg
+// channels is staged ONCE in LDS and every tap kk reads it at a row offset (no im2col anywhere); the
+// group's weights stream through LDS in 512-byte-per-row chunks (register-prefetched), shared by 8 waves.
+// The data gradient is the same kernel run on dz with flipped/transposed weights and the pads swapped.
+// The weight gradient contracts over time with both operands read transposed from LDS.
+#include "a8_common.h"
+#include "a8hip_internal.h"
+
+namespace {
+
+constexpr int KW = 128;
+constexpr int BM = 256;
+
+struct PosP {
+    const char *x, *w, *res;
+    const float* bias;
+    char *y, *z;
+    int B, T, d, pad_left, add_residual, apply_gelu;
+};
+
+template <typename T, int DG> struct PCfg {
+    static constexpr int EPC = 16 / (int)sizeof(T);
+    static constexpr int CPX = DG / EPC;                        // 16-byte chunks per window row
+    static constexpr int XROW = DG * (int)sizeof(T) + 16;       // padded window row (bytes)
+    static constexpr int KCH = 512 / (int)sizeof(T);            // reduction elements per weight chunk
+    static constexpr int NB = DG / 16;
+    static constexpr int WIN = BM + KW - 1;
+    static constexpr int NCHUNK = KW * DG / KCH;
+    static constexpr int WPT = DG * 32 / 512;                   // weight 16-byte chunks per thread per chunk
+};
+
+template <typename T, int DG>
+__global__ __launch_bounds__(512) void posconv_fwd_kernel(const PosP P) {
+    typedef PCfg<T, DG> Cf;
+    typedef Mma<T> MM;
+    __shared__ __attribute__((aligned(16))) char xwin[Cf::WIN * Cf::XROW];
+    __shared__ __attribute__((aligned(16))) char wt[DG * 512];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g4 = lane >> 4, li = lane & 15;
+    const int grp = blockIdx.y, b = blockIdx.z, t0 = blockIdx.x * BM;
+    const T* xb = reinterpret_cast<const T*>(P.x) + (long long)b * P.T * P.d + grp * DG;
+    for (int c = tid; c < Cf::WIN * Cf::CPX; c += 512) {
+        const int r = c / Cf::CPX, cc = c % Cf::CPX;
+        const int ts = t0 + r - P.pad_left;
+        const u32x4 v = (ts >= 0 && ts < P.T) ? ld16(xb + (long long)ts * P.d + cc * Cf::EPC) : (u32x4){0u, 0u, 0u, 0u};
+        st16(xwin + r * Cf::XROW + cc * 16, v);
+    }
+    const T* wg = reinterpret_cast<const T*>(P.w) + (long long)grp * DG * (KW * DG);
+    u32x4 wr[Cf::WPT];
+    auto wload = [&](int ch) {
+#pragma unroll
+        for (int j = 0; j < Cf::WPT; ++j) {
+            const int idx = tid + 512 * j, co = idx >> 5, c16 = idx & 31;
+            wr[j] = ld16(wg + (long long)co * (KW * DG) + ch * Cf::KCH + c16 * Cf::EPC);
+        }
+    };
+    auto wstore = [&]() {
+#pragma unroll
+        for (int j = 0; j < Cf::WPT; ++j) {
+            const int idx = tid + 512 * j, co = idx >> 5, c16 = idx & 31;
+            st16(wt + co * 512 + ((c16 ^ (co & 15)) << 4), wr[j]);
+        }
+    };
+    f32x4 acc[2][Cf::NB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < Cf::NB; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    wload(0);
+    wstore();
+    __syncthreads();
+    for (int ch = 0; ch < Cf::NCHUNK; ++ch) {
+        if (ch + 1 < Cf::NCHUNK) wload(ch + 1);
+#pragma unroll 4
+        for (int ks = 0; ks < Cf::KCH / MM::KI; ++ks) {
+            typename MM::Frag xa[2], wb[Cf::NB];
+            if constexpr (sizeof(T) == 2) {
+                const int chi = (ch * Cf::KCH + ks * 32) / 8 + g4;          // 16-byte chunk index along kappa
+                const int kk = chi / Cf::CPX, cic = chi % Cf::CPX;
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    xa[mi] = *reinterpret_cast<const bf16x8*>(xwin + (wv * 32 + 16 * mi + li + kk) * Cf::XROW + cic * 16);
+#pragma unroll
+                for (int nb = 0; nb < Cf::NB; ++nb) {
+                    const int co = 16 * nb + li;
+                    wb[nb] = *reinterpret_cast<const bf16x8*>(wt + co * 512 + (((ks * 4 + g4) ^ (co & 15)) << 4));
+                }
+            } else {
+                const int kap = ch * Cf::KCH + ks * 4 + g4;
+                const int kk = kap / DG, ci = kap % DG;
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    xa[mi] = *reinterpret_cast<const float*>(xwin + (wv * 32 + 16 * mi + li + kk) * Cf::XROW + ci * 4);
+#pragma unroll
+                for (int nb = 0; nb < Cf::NB; ++nb) {
+                    const int co = 16 * nb + li;
+                    wb[nb] = *reinterpret_cast<const float*>(wt + co * 512 + ((ks ^ (co & 15)) << 4) + g4 * 4);
+                }
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int nb = 0; nb < Cf::NB; ++nb) acc[mi][nb] = MM::mma(wb[nb], xa[mi], acc[mi][nb]);
+        }
+        __syncthreads();
+        if (ch + 1 < Cf::NCHUNK) wstore();
+        __syncthreads();
+    }
+    // epilogue: lane holds 4 consecutive output channels of frame t
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int t = t0 + wv * 32 + 16 * mi + li;
+        if (t >= P.T) continue;
+#pragma unroll
+        for (int nb = 0; nb < Cf::NB; ++nb) {
+            const int c = grp * DG + 16 * nb + 4 * g4;
+            const long long off = ((long long)b * P.T + t) * P.d + c;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[mi][nb][r] + (P.bias ? P.bias[c + r] : 0.f);
+            if (P.z) {
+                T* zp = reinterpret_cast<T*>(P.z) + off;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) zp[r] = from_f<T>(v[r]);
+            }
+            if (P.apply_gelu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+            }
+            if (P.add_residual) {
+                const T* rp = reinterpret_cast<const T*>(P.res) + off;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += to_f(rp[r]);
+            }
+            T* yp = reinterpret_cast<T*>(P.y) + off;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) yp[r] = from_f<T>(v[r]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ weight gradient
+// dw[grp][co][kk][ci] += sum_{b,t} dz[b,t,grp*DG+co] * xpad[b,t+kk,grp*DG+ci]
+// block = (group, 8 taps); wave = 2 taps; loops over (b, 64-frame chunks); both operands via transposed LDS reads.
+constexpr int WG_TAPS = 8, WG_BT = 64;
+template <typename T, int DG>
+__global__ __launch_bounds__(256) void posconv_wgrad_kernel(const char* __restrict__ xp, const char* __restrict__ dzp, float* __restrict__ dw,
+                                                            int B, int Tn, int d, int pad_left) {
+    constexpr int EPC = 16 / (int)sizeof(T), CPX = DG / EPC, XROW = DG * (int)sizeof(T) + 16, NB = DG / 16;
+    constexpr int XR = WG_BT + WG_TAPS - 1;
+    __shared__ __attribute__((aligned(16))) char xs[XR * XROW];
+    __shared__ __attribute__((aligned(16))) char zs[WG_BT * XROW];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g4 = lane >> 4, li = lane & 15;
+    const int grp = blockIdx.y, kk0 = blockIdx.x * WG_TAPS;
+    f32x4 acc[2][NB][NB];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[a][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nt = (Tn + WG_BT - 1) / WG_BT;
+    for (int it = 0; it < B * nt; ++it) {
+        const int b = it / nt, t0 = (it % nt) * WG_BT;
+        const T* xb = reinterpret_cast<const T*>(xp) + (long long)b * Tn * d + grp * DG;
+        const T* zb = reinterpret_cast<const T*>(dzp) + (long long)b * Tn * d + grp * DG;
+        __syncthreads();
+        for (int c = tid; c < XR * CPX; c += 256) {
+            const int r = c / CPX, cc = c % CPX, ts = t0 + r + kk0 - pad_left;
+            st16(xs + r * XROW + cc * 16, (ts >= 0 && ts < Tn) ? ld16(xb + (long long)ts * d + cc * EPC) : (u32x4){0u, 0u, 0u, 0u});
+        }
+        for (int c = tid; c < WG_BT * CPX; c += 256) {
+            const int r = c / CPX, cc = c % CPX, ts = t0 + r;
+            st16(zs + r * XROW + cc * 16, ts < Tn ? ld16(zb + (long long)ts * d + cc * EPC) : (u32x4){0u, 0u, 0u, 0u});
+        }
+        __syncthreads();
+        if constexpr (sizeof(T) == 2) {
+            const int q = li >> 2, p = li & 3;
+#pragma unroll
+            for (int ks = 0; ks < WG_BT / 32; ++ks) {
+                bf16x8 za[NB];
+                const int r0 = ks * 32 + 8 * g4 + q;
+#pragma unroll
+                for (int cb = 0; cb < NB; ++cb) {
+                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, zs + r0 * XROW + (16 * cb + 4 * p) * 2));
+                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, zs + (r0 + 4) * XROW + (16 * cb + 4 * p) * 2));
+                    typedef short s16x8 __attribute__((ext_vector_type(8)));
+                    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    za[cb] = __builtin_bit_cast(bf16x8, v);
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int kk = wv * 2 + a;
+#pragma unroll
+                    for (int ib = 0; ib < NB; ++ib) {
+                        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, xs + (r0 + kk) * XROW + (16 * ib + 4 * p) * 2));
+                        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, xs + (r0 + kk + 4) * XROW + (16 * ib + 4 * p) * 2));
+                        typedef short s16x8 __attribute__((ext_vector_type(8)));
+                        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        const bf16x8 xbv = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+                        for (int cb = 0; cb < NB; ++cb) acc[a][cb][ib] = Mma<bf16>::mma(za[cb], xbv, acc[a][cb][ib]);
+                    }
+                }
+            }
+        } else {
+#pragma unroll 4
+            for (int ks = 0; ks < WG_BT / 4; ++ks) {
+                float za[NB];
+                const int r0 = ks * 4 + g4;
+#pragma unroll
+                for (int cb = 0; cb < NB; ++cb) za[cb] = *reinterpret_cast<const float*>(zs + r0 * XROW + (16 * cb + li) * 4);
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int kk = wv * 2 + a;
+#pragma unroll
+                    for (int ib = 0; ib < NB; ++ib) {
+                        const float xbv = *reinterpret_cast<const float*>(xs + (r0 + kk) * XROW + (16 * ib + li) * 4);
+#pragma unroll
+                        for (int cb = 0; cb < NB; ++cb) acc[a][cb][ib] = Mma<float>::mma(za[cb], xbv, acc[a][cb][ib]);
+                    }
+                }
+            }
+        }
+    }
+    // acc[a][cb][ib][r] = dW[co = 16cb + 4g4 + r][kk][ci = 16ib + li]
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int kk = kk0 + wv * 2 + a;
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+            for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = 16 * cb + 4 * g4 + r, ci = 16 * ib + li;
+                    atomicAdd(dw + (((long long)grp * DG + co) * KW + kk) * DG + ci, acc[a][cb][ib][r]);
+                }
+    }
+}
+
+}  // namespace
+
+extern "C" int a8_posconv_fwd(int dtype, const void* x, const void* w, const float* bias, void* y, void* z,
+                              int B, int T_, int d, int groups, int k, int pad_left, int add_residual, void* stream) {
+    A8_REQUIRE(k == KW, "a8_posconv_fwd: kernel width must be %d (got %d)", KW, k);
+    A8_REQUIRE(groups >= 1 && d % groups == 0, "a8_posconv_fwd: d=%d not divisible by groups=%d", d, groups);
+    const int dg = d / groups;
+    A8_REQUIRE(dg == 48 || dg == 64, "a8_posconv_fwd: channels per group must be 48 or 64 (got %d)", dg);
+    A8_REQUIRE(pad_left >= 0 && pad_left < KW, "a8_posconv_fwd: bad pad_left");
+    A8_REQUIRE(dtype == A8_F32 || dtype == A8_BF16, "a8_posconv_fwd: bad dtype");
+    PosP P = {};
+    P.x = (const char*)x; P.w = (const char*)w; P.res = (const char*)x; P.bias = bias; P.y = (char*)y; P.z = (char*)z;
+    P.B = B; P.T = T_; P.d = d; P.pad_left = pad_left; P.add_residual = add_residual; P.apply_gelu = add_residual >= 0 ? 1 : 0;
+    if (add_residual < 0) { P.add_residual = 0; }      // add_residual = -1: plain conv (data-gradient mode)
+    const dim3 grid(cdiv(T_, BM), groups, B);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == A8_BF16) {
+        if (dg == 48) hipLaunchKernelGGL((posconv_fwd_kernel<bf16, 48>), grid, dim3(512), 0, s, P);
+        else hipLaunchKernelGGL((posconv_fwd_kernel<bf16, 64>), grid, dim3(512), 0, s, P);
+    } else {
+        if (dg == 48) hipLaunchKernelGGL((posconv_fwd_kernel<float, 48>), grid, dim3(512), 0, s, P);
+        else hipLaunchKernelGGL((posconv_fwd_kernel<float, 64>), grid, dim3(512), 0, s, P);
+    }
+    return a8_check_launch("a8_posconv_fwd");
+}
+
+extern "C" int a8_posconv_wgrad(int dtype, const void* x, const void* dz, float* dw, int B, int T_, int d, int groups, int k,
+                                int pad_left, void* stream) {
+    A8_REQUIRE(k == KW, "a8_posconv_wgrad: kernel width must be %d (got %d)", KW, k);
+    A8_REQUIRE(groups >= 1 && d % groups == 0, "a8_posconv_wgrad: d=%d not divisible by groups=%d", d, groups);
+    const int dg = d / groups;
+    A8_REQUIRE(dg == 48 || dg == 64, "a8_posconv_wgrad: channels per group must be 48 or 64 (got %d)", dg);
+    A8_REQUIRE(dtype == A8_F32 || dtype == A8_BF16, "a8_posconv_wgrad: bad dtype");
+    const dim3 grid(KW / WG_TAPS, groups);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == A8_BF16) {
+        if (dg == 48) hipLaunchKernelGGL((posconv_wgrad_kernel<bf16, 48>), grid, dim3(256), 0, s, (const char*)x, (const char*)dz, dw, B, T_, d, pad_left);
+        else hipLaunchKernelGGL((posconv_wgrad_kernel<bf16, 64>), grid, dim3(256), 0, s, (const char*)x, (const char*)dz, dw, B, T_, d, pad_left);
+    } else {
+        if (dg == 48) hipLaunchKernelGGL((posconv_wgrad_kernel<float, 48>), grid, dim3(256), 0, s, (const char*)x, (const char*)dz, dw, B, T_, d, pad_left);
+        else hipLaunchKernelGGL((posconv_wgrad_kernel<float, 64>), grid, dim3(256), 0, s, (const char*)x, (const char*)dz, dw, B, T_, d, pad_left);
+    }
+    return a8_check_launch("a8_posconv_wgrad");
+}

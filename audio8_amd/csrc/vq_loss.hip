@@ -1,0 +1,335 @@
+// a8hip: Gumbel-softmax product quantiser (GumbelVectorQuantizer.forward, audio8/wav2vec2.py:547-576) and the
+// negatives-gather + cosine + cross-entropy loss (Sampler.negatives :955-976, Wav2Vec2Loss :371-392).
+// Wavefront-shuffle kernels: one wave owns one row (one (frame, group) of logits / one masked frame),
+// all reductions are xor-shuffles, nothing of size [rows, G*V, D] or [N, B, Tm, C] is ever materialised
+// (the reference's broadcast codebook product is 241 M elements, its negatives tensor 75 M).
+#include "a8_common.h"
+#include "a8hip_internal.h"
+
+namespace {
+
+constexpr int VMAX_PER_LANE = 8;   // V <= 512
+
+// ------------------------------------------------------------------ VQ: argmax + mean softmax
+__global__ __launch_bounds__(256) void vq_select_kernel(const float* __restrict__ logits, const float* __restrict__ gumbel,
+                                                        int32_t* __restrict__ codes, float* __restrict__ avg, int R, int V) {
+    __shared__ float s_avg[64 * VMAX_PER_LANE];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < V; i += 256) s_avg[i] = 0.f;
+    __syncthreads();
+    const float invR = 1.0f / (float)R;
+    for (int row = blockIdx.x * 4 + wv; row < R; row += gridDim.x * 4) {
+        float x[VMAX_PER_LANE];
+        float mx = -INFINITY, best = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < VMAX_PER_LANE; ++j) {
+            const int v = lane + 64 * j;
+            x[j] = v < V ? logits[(long long)row * V + v] : -INFINITY;
+            mx = fmaxf(mx, x[j]);
+            if (v < V) {
+                const float y = gumbel ? x[j] + gumbel[(long long)row * V + v] : x[j];
+                if (y > best) { best = y; bi = v; }
+            }
+        }
+        mx = wave_max(mx);
+        // argmax with first-index tie-break (torch.max semantics)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < VMAX_PER_LANE; ++j) { x[j] = (lane + 64 * j < V) ? __expf(x[j] - mx) : 0.f; s += x[j]; }
+        s = wave_sum(s);
+        const float inv = invR / s;
+#pragma unroll
+        for (int j = 0; j < VMAX_PER_LANE; ++j)
+            if (lane + 64 * j < V) atomicAdd(&s_avg[lane + 64 * j], x[j] * inv);
+        if (lane == 0) codes[row] = bi;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < V; i += 256) atomicAdd(avg + i, s_avg[i]);
+}
+
+template <typename T>
+__global__ void vq_gather_kernel(const float* __restrict__ vars, const int32_t* __restrict__ codes, T* __restrict__ q, int N, int G, int V, int D) {
+    const long long total = (long long)N * G * D;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int dd = (int)(i % D);
+        const long long ng = i / D;
+        const int g = (int)(ng % G);
+        q[i] = from_f<T>(vars[((long long)g * V + codes[ng]) * D + dd]);
+    }
+}
+
+// prob_ppl = exp(-sum p log(p + 1e-7)),  dppl/dp_v = -ppl * (log(p_v + 1e-7) + p_v / (p_v + 1e-7))
+__global__ __launch_bounds__(256) void vq_ppl_kernel(const float* __restrict__ avg, float* __restrict__ ppl, float* __restrict__ dppl, int V) {
+    __shared__ float red[4];
+    float h = 0.f;
+    for (int i = threadIdx.x; i < V; i += 256) h += avg[i] * logf(avg[i] + 1e-7f);
+    h = block_sum<4>(h, red);
+    const float pp = expf(-h);
+    if (threadIdx.x == 0) ppl[0] = pp;
+    for (int i = threadIdx.x; i < V; i += 256) dppl[i] = -pp * (logf(avg[i] + 1e-7f) + avg[i] / (avg[i] + 1e-7f));
+}
+
+// backward through the straight-through soft path and the diversity path; one wave per (frame, group) row
+template <typename T>
+__global__ __launch_bounds__(256) void vq_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ gumbel, float tau,
+                                                     const int32_t* __restrict__ codes, const float* __restrict__ vars,
+                                                     const T* __restrict__ dq, const float* __restrict__ eproj, const float* __restrict__ dppl, const float* __restrict__ gppl,
+                                                     float* __restrict__ dlogits, float* __restrict__ dvars,
+                                                     int R, int G, int V, int D, int training) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const float gp = gppl ? gppl[0] / (float)R : 0.f;
+    const float itau = 1.0f / tau;
+    for (int row = blockIdx.x * 4 + wv; row < R; row += gridDim.x * 4) {
+        const int g = row % G;
+        const long long n = row / G;
+        // dq_g slice of this row: D <= 128 -> 2 per lane
+        float dqv[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) dqv[j] = (lane + 64 * j < D) ? to_f(dq[(n * G + g) * D + lane + 64 * j]) : 0.f;
+        // codebook gradient: only the chosen entry (value of the straight-through one-hot is exactly the hard one-hot)
+        const int code = codes[row];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (lane + 64 * j < D) atomicAdd(dvars + ((long long)g * V + code) * D + lane + 64 * j, dqv[j]);
+        float x[VMAX_PER_LANE], ys[VMAX_PER_LANE], e[VMAX_PER_LANE];
+        float mx = -INFINITY, my = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < VMAX_PER_LANE; ++j) {
+            const int v = lane + 64 * j;
+            x[j] = v < V ? logits[(long long)row * V + v] : -INFINITY;
+            ys[j] = (v < V && training) ? (x[j] + gumbel[(long long)row * V + v]) * itau : -INFINITY;
+            mx = fmaxf(mx, x[j]);
+            my = fmaxf(my, ys[j]);
+            e[j] = 0.f;
+        }
+        mx = wave_max(mx);
+        float sx = 0.f, sy = 0.f;
+#pragma unroll
+        for (int j = 0; j < VMAX_PER_LANE; ++j) { x[j] = (lane + 64 * j < V) ? __expf(x[j] - mx) : 0.f; sx += x[j]; }
+        sx = wave_sum(sx);
+        float dpp = 0.f;      // sum_v p_v dppl_v
+#pragma unroll
+        for (int j = 0; j < VMAX_PER_LANE; ++j) {
+            x[j] /= sx;
+            if (lane + 64 * j < V) dpp += x[j] * dppl[lane + 64 * j];
+        }
+        dpp = wave_sum(dpp);
+        float se = 0.f;
+        if (training) {
+            my = wave_max(my);
+#pragma unroll
+            for (int j = 0; j < VMAX_PER_LANE; ++j) { ys[j] = (lane + 64 * j < V) ? __expf(ys[j] - my) : 0.f; sy += ys[j]; }
+            sy = wave_sum(sy);
+            // e_v = <dq_g, vars[g, v, :]> was computed by a8_gemm (eproj [R, V])
+#pragma unroll
+            for (int j = 0; j < VMAX_PER_LANE; ++j)
+                if (lane + 64 * j < V) e[j] = eproj[(long long)row * V + lane + 64 * j];
+#pragma unroll
+            for (int j = 0; j < VMAX_PER_LANE; ++j) { ys[j] /= sy; se += ys[j] * e[j]; }
+            se = wave_sum(se);
+        }
+#pragma unroll
+        for (int j = 0; j < VMAX_PER_LANE; ++j) {
+            const int v = lane + 64 * j;
+            if (v < V) {
+                float gl = gp * x[j] * (dppl[v] - dpp);
+                if (training) gl += itau * ys[j] * (e[j] - se);
+                dlogits[(long long)row * V + v] = gl;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ contrastive: cosine logits + CE
+// one wave per masked frame; the 4 quarter-waves take targets n = quarter, quarter+4, ...; C <= 16*EPL*... (C = 256 -> 16 per lane)
+constexpr int CPL = 16;     // channels per lane within a quarter wave (C = 256)
+template <typename T> A8_DEV void load16f(const T* p, float (&v)[CPL]) {
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) v[i] = to_f(p[i]);
+}
+A8_DEV float quarter_sum(float v) {
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+    return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rownorm_kernel(const T* __restrict__ x, float* __restrict__ inv, int rows, int Cn) {
+    const int lane = threadIdx.x & 63;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+        float s = 0.f;
+        for (int c = lane; c < Cn; c += 64) { const float v = to_f(x[(long long)row * Cn + c]); s = fmaf(v, v, s); }
+        s = wave_sum(s);
+        if (lane == 0) inv[row] = 1.0f / fmaxf(sqrtf(s), 1e-8f);   // torch.cosine_similarity eps
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void contrastive_fwd_kernel(const T* __restrict__ ctx, const T* __restrict__ lat, const int32_t* __restrict__ idx,
+                                                              const float* __restrict__ inv_ctx, const float* __restrict__ inv_lat,
+                                                              float* __restrict__ logits, float* __restrict__ loss_sum, int rows, int N) {
+    __shared__ float s_log[4][128];
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, qt = lane >> 4, ql = lane & 15;
+    float lsum = 0.f;
+    for (int row = blockIdx.x * 4 + wv; row < rows; row += gridDim.x * 4) {
+        float c[CPL];
+        load16f(ctx + (long long)row * (16 * CPL) + ql * CPL, c);
+        const float ic = inv_ctx[row];
+        for (int n = qt; n <= N; n += 4) {
+            const int tr = n == 0 ? row : idx[(long long)row * N + n - 1];
+            float tv[CPL];
+            load16f(lat + (long long)tr * (16 * CPL) + ql * CPL, tv);
+            float d = 0.f;
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) d = fmaf(c[i], tv[i], d);
+            d = quarter_sum(d) * ic * inv_lat[tr];
+            if (ql == 0) { s_log[wv][n] = d; logits[(long long)row * (N + 1) + n] = d; }
+        }
+        __builtin_amdgcn_s_waitcnt(0);   // this wave's LDS writes are complete before its reads below
+        __builtin_amdgcn_wave_barrier();
+        float mx = -INFINITY;
+        for (int n = lane; n <= N; n += 64) mx = fmaxf(mx, s_log[wv][n]);
+        mx = wave_max(mx);
+        float s = 0.f;
+        for (int n = lane; n <= N; n += 64) s += __expf(s_log[wv][n] - mx);
+        s = wave_sum(s);
+        if (lane == 0) lsum += mx + __logf(s) - s_log[wv][0];
+        __builtin_amdgcn_wave_barrier();
+    }
+    lsum = block_sum<4>(lsum, red);
+    if (threadIdx.x == 0) atomicAdd(loss_sum, lsum);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void contrastive_bwd_kernel(const T* __restrict__ ctx, const T* __restrict__ lat, const int32_t* __restrict__ idx,
+                                                              const float* __restrict__ inv_ctx, const float* __restrict__ inv_lat,
+                                                              const float* __restrict__ logits, const float* __restrict__ gscale,
+                                                              float* __restrict__ dctx, float* __restrict__ dlat, int rows, int N) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, qt = lane >> 4, ql = lane & 15;
+    const float gs = gscale[0];
+    for (int row = blockIdx.x * 4 + wv; row < rows; row += gridDim.x * 4) {
+        // softmax over the N+1 logits of this row
+        float mx = -INFINITY;
+        for (int n = lane; n <= N; n += 64) mx = fmaxf(mx, logits[(long long)row * (N + 1) + n]);
+        mx = wave_max(mx);
+        float s = 0.f;
+        for (int n = lane; n <= N; n += 64) s += __expf(logits[(long long)row * (N + 1) + n] - mx);
+        s = wave_sum(s);
+        const float inv_s = 1.0f / s;
+        float c[CPL], dc[CPL];
+        load16f(ctx + (long long)row * (16 * CPL) + ql * CPL, c);
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) dc[i] = 0.f;
+        const float ic = inv_ctx[row];
+        for (int n = qt; n <= N; n += 4) {
+            const int tr = n == 0 ? row : idx[(long long)row * N + n - 1];
+            const float lg = logits[(long long)row * (N + 1) + n];
+            const float dl = gs * (__expf(lg - mx) * inv_s - (n == 0 ? 1.f : 0.f));
+            const float it = inv_lat[tr];
+            float tv[CPL];
+            load16f(lat + (long long)tr * (16 * CPL) + ql * CPL, tv);
+            // d cos/dc = t*ic*it - cos*c*ic^2 ; d cos/dt = c*ic*it - cos*t*it^2
+            const float a = dl * ic * it, bc = dl * lg * ic * ic, bt = dl * lg * it * it;
+            float* dlp = dlat + (long long)tr * (16 * CPL) + ql * CPL;
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) {
+                dc[i] += a * tv[i] - bc * c[i];
+                atomicAdd(dlp + i, a * c[i] - bt * tv[i]);
+            }
+        }
+        // combine the four quarter-waves' partial dctx
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) { dc[i] += __shfl_xor(dc[i], 16, 64); dc[i] += __shfl_xor(dc[i], 32, 64); }
+        if (qt == 0) {
+            float* dp = dctx + (long long)row * (16 * CPL) + ql * CPL;
+#pragma unroll
+            for (int i = 0; i < CPL; i += 4) *reinterpret_cast<f32x4*>(dp + i) = (f32x4){dc[i], dc[i + 1], dc[i + 2], dc[i + 3]};
+        }
+    }
+}
+
+int gridw(int rows) { int b = (rows + 3) / 4; return b < 1 ? 1 : (b > 2048 ? 2048 : b); }
+
+}  // namespace
+
+extern "C" int a8_vq_select(const float* logits, const float* gumbel, float tau, int32_t* codes, float* avg_probs, int R, int V, void* stream) {
+    A8_REQUIRE(V >= 1 && V <= 64 * VMAX_PER_LANE, "a8_vq_select: V=%d must be <= %d", V, 64 * VMAX_PER_LANE);
+    A8_REQUIRE(tau > 0.f, "a8_vq_select: tau must be positive");
+    if (hipMemsetAsync(avg_probs, 0, sizeof(float) * V, (hipStream_t)stream) != hipSuccess) return a8_set_error(A8_ERR_LAUNCH, "a8_vq_select: memset failed");
+    if (R == 0) return A8_OK;
+    hipLaunchKernelGGL(vq_select_kernel, dim3(gridw(R) > 256 ? 256 : gridw(R)), dim3(256), 0, (hipStream_t)stream, logits, gumbel, codes, avg_probs, R, V);
+    return a8_check_launch("a8_vq_select");
+}
+
+extern "C" int a8_vq_gather(int dtype, const float* vars, const int32_t* codes, void* q, int N, int G, int V, int D, void* stream) {
+    if ((long long)N * G * D == 0) return A8_OK;
+    const long long total = (long long)N * G * D;
+    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    if (dtype == A8_BF16) hipLaunchKernelGGL(vq_gather_kernel<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, vars, codes, (bf16*)q, N, G, V, D);
+    else if (dtype == A8_F32) hipLaunchKernelGGL(vq_gather_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, vars, codes, (float*)q, N, G, V, D);
+    else return a8_set_error(A8_ERR_ARG, "a8_vq_gather: bad dtype");
+    return a8_check_launch("a8_vq_gather");
+}
+
+extern "C" int a8_vq_ppl(const float* avg_probs, float* ppl, float* dppl_davg, int V, void* stream) {
+    hipLaunchKernelGGL(vq_ppl_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, avg_probs, ppl, dppl_davg, V);
+    return a8_check_launch("a8_vq_ppl");
+}
+
+extern "C" int a8_vq_bwd(int dtype, const float* logits, const float* gumbel, float tau, const int32_t* codes, const float* vars,
+                         const void* dq, const float* eproj, const float* dppl_davg, const float* gppl, float* dlogits, float* dvars,
+                         int N, int G, int V, int D, int training, void* stream) {
+    A8_REQUIRE(V >= 1 && V <= 64 * VMAX_PER_LANE && D <= 128, "a8_vq_bwd: V=%d D=%d unsupported", V, D);
+    A8_REQUIRE(!training || (gumbel && eproj), "a8_vq_bwd: training needs the gumbel noise used in forward and eproj");
+    const int R = N * G;
+    if (R == 0) return A8_OK;
+    if (dtype == A8_BF16) hipLaunchKernelGGL(vq_bwd_kernel<bf16>, dim3(gridw(R)), dim3(256), 0, (hipStream_t)stream, logits, gumbel, tau, codes, vars, (const bf16*)dq, eproj, dppl_davg, gppl, dlogits, dvars, R, G, V, D, training);
+    else if (dtype == A8_F32) hipLaunchKernelGGL(vq_bwd_kernel<float>, dim3(gridw(R)), dim3(256), 0, (hipStream_t)stream, logits, gumbel, tau, codes, vars, (const float*)dq, eproj, dppl_davg, gppl, dlogits, dvars, R, G, V, D, training);
+    else return a8_set_error(A8_ERR_ARG, "a8_vq_bwd: bad dtype");
+    return a8_check_launch("a8_vq_bwd");
+}
+
+extern "C" int a8_contrastive_fwd(int dtype, const void* ctx, const void* lat, const int32_t* neg_idx, float* logits,
+                                  float* loss_sum, float* inv_norms, int rows, int N, int Cn, void* stream) {
+    A8_REQUIRE(Cn == 16 * CPL, "a8_contrastive_fwd: C must be %d (got %d)", 16 * CPL, Cn);
+    A8_REQUIRE(N >= 1 && N + 1 <= 128, "a8_contrastive_fwd: N=%d must be in [1,127]", N);
+    if (rows == 0) return A8_OK;
+    float* ic = inv_norms; float* il = inv_norms + rows;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == A8_BF16) {
+        hipLaunchKernelGGL(rownorm_kernel<bf16>, dim3(gridw(rows)), dim3(256), 0, s, (const bf16*)ctx, ic, rows, Cn);
+        hipLaunchKernelGGL(rownorm_kernel<bf16>, dim3(gridw(rows)), dim3(256), 0, s, (const bf16*)lat, il, rows, Cn);
+        hipLaunchKernelGGL(contrastive_fwd_kernel<bf16>, dim3(gridw(rows)), dim3(256), 0, s, (const bf16*)ctx, (const bf16*)lat, neg_idx, ic, il, logits, loss_sum, rows, N);
+    } else if (dtype == A8_F32) {
+        hipLaunchKernelGGL(rownorm_kernel<float>, dim3(gridw(rows)), dim3(256), 0, s, (const float*)ctx, ic, rows, Cn);
+        hipLaunchKernelGGL(rownorm_kernel<float>, dim3(gridw(rows)), dim3(256), 0, s, (const float*)lat, il, rows, Cn);
+        hipLaunchKernelGGL(contrastive_fwd_kernel<float>, dim3(gridw(rows)), dim3(256), 0, s, (const float*)ctx, (const float*)lat, neg_idx, ic, il, logits, loss_sum, rows, N);
+    } else return a8_set_error(A8_ERR_ARG, "a8_contrastive_fwd: bad dtype");
+    return a8_check_launch("a8_contrastive_fwd");
+}
+
+extern "C" int a8_contrastive_bwd(int dtype, const void* ctx, const void* lat, const int32_t* neg_idx, const float* logits,
+                                  const float* gscale, float* dctx, float* dlat, float* inv_norms, int rows, int N, int Cn, void* stream) {
+    A8_REQUIRE(Cn == 16 * CPL, "a8_contrastive_bwd: C must be %d (got %d)", 16 * CPL, Cn);
+    A8_REQUIRE(N >= 1 && N + 1 <= 128, "a8_contrastive_bwd: N=%d must be in [1,127]", N);
+    if (rows == 0) return A8_OK;
+    float* ic = inv_norms; float* il = inv_norms + rows;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == A8_BF16) {
+        hipLaunchKernelGGL(rownorm_kernel<bf16>, dim3(gridw(rows)), dim3(256), 0, s, (const bf16*)ctx, ic, rows, Cn);
+        hipLaunchKernelGGL(rownorm_kernel<bf16>, dim3(gridw(rows)), dim3(256), 0, s, (const bf16*)lat, il, rows, Cn);
+        hipLaunchKernelGGL(contrastive_bwd_kernel<bf16>, dim3(gridw(rows)), dim3(256), 0, s, (const bf16*)ctx, (const bf16*)lat, neg_idx, ic, il, logits, gscale, dctx, dlat, rows, N);
+    } else if (dtype == A8_F32) {
+        hipLaunchKernelGGL(rownorm_kernel<float>, dim3(gridw(rows)), dim3(256), 0, s, (const float*)ctx, ic, rows, Cn);
+        hipLaunchKernelGGL(rownorm_kernel<float>, dim3(gridw(rows)), dim3(256), 0, s, (const float*)lat, il, rows, Cn);
+        hipLaunchKernelGGL(contrastive_bwd_kernel<float>, dim3(gridw(rows)), dim3(256), 0, s, (const float*)ctx, (const float*)lat, neg_idx, ic, il, logits, gscale, dctx, dlat, rows, N);
+    } else return a8_set_error(A8_ERR_ARG, "a8_contrastive_bwd: bad dtype");
+    return a8_check_launch("a8_contrastive_bwd");
+}

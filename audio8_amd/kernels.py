@@ -53,3 +53,259 @@ def gemm(layout, A, B, M, N, K, *, out=None, out_dtype=None, lda=None, ldb=None,
     d.alpha = alpha
     L.check(L.lib().a8_gemm(C.byref(d), L.stream()), "a8_gemm")
     return out
+
+
+# ----------------------------------------------------------------------------- helpers
+def _u32(x):
+    return C.c_uint32(int(x) & 0xFFFFFFFF)
+
+
+def _f(x):
+    return C.c_float(float(x))
+
+
+def conv_out_len(L, k, s):
+    return (L - k) // s + 1
+
+
+# ----------------------------------------------------------------------------- conv layer 0
+def conv0_gn_gelu_fwd(x, w, gn_w, gn_b, out_dtype, eps=1e-5):
+    """x f32 [B,L]; w f32 [512,1,10] -> (out [B,L0,512] channels-last, stats f32 [B,512,2])."""
+    L.require_cuda(x, w, gn_w, gn_b)
+    B, Ls = x.shape
+    Cn = w.shape[0]
+    L0 = conv_out_len(Ls, 10, 5)
+    out = torch.empty((B, L0, Cn), device=x.device, dtype=out_dtype)
+    stats = torch.empty((B, Cn, 2), device=x.device, dtype=torch.float32)
+    part = torch.empty((B, (L0 + 255) // 256, Cn, 2), device=x.device, dtype=torch.float32)
+    L.check(L.lib().a8_conv0_gn_gelu_fwd(L.dt(out), L.ptr(_c(x)), L.ptr(_c(w)), L.ptr(gn_w), L.ptr(gn_b), L.ptr(out), L.ptr(stats),
+                                         L.ptr(part), B, Ls, Cn, _f(eps), L.stream()), "a8_conv0_gn_gelu_fwd")
+    return out, stats
+
+
+def conv0_gn_gelu_bwd(x, w, gn_w, gn_b, stats, dout, dw, dgn_w, dgn_b):
+    """Accumulates (+=) into dw f32 [512,1,10], dgn_w, dgn_b f32 [512]."""
+    L.require_cuda(x, dout, dw)
+    B, Ls = x.shape
+    Cn = w.shape[0]
+    red = torch.empty((B, Cn, 2), device=x.device, dtype=torch.float32)
+    L.check(L.lib().a8_conv0_gn_gelu_bwd(L.dt(dout), L.ptr(_c(x)), L.ptr(_c(w)), L.ptr(gn_w), L.ptr(gn_b), L.ptr(stats), L.ptr(_c(dout)),
+                                         L.ptr(dw), L.ptr(dgn_w), L.ptr(dgn_b), L.ptr(red), B, Ls, Cn, L.stream()), "a8_conv0_gn_gelu_bwd")
+
+
+def col2im_gelu_grad(dcol, z, B, Lin, Lout, Cn, k, stride):
+    dx = torch.empty((B, Lin, Cn), device=dcol.device, dtype=dcol.dtype)
+    L.check(L.lib().a8_col2im_gelu_grad(L.dt(dcol), L.ptr(_c(dcol)), L.ptr(z), L.ptr(dx), B, Lin, Lout, Cn, k, stride, L.stream()),
+            "a8_col2im_gelu_grad")
+    return dx
+
+
+# ----------------------------------------------------------------------------- LayerNorm
+def layernorm_fwd(x, res, gamma, beta, eps, p=0.0, seed=0, rng_stream=0):
+    rows, cols = x.numel() // x.shape[-1], x.shape[-1]
+    y = torch.empty_like(x)
+    mean = torch.empty((rows,), device=x.device, dtype=torch.float32)
+    rstd = torch.empty((rows,), device=x.device, dtype=torch.float32)
+    L.check(L.lib().a8_layernorm_fwd(L.dt(x), L.ptr(_c(x)), L.ptr(_c(res)), L.ptr(gamma), L.ptr(beta), L.ptr(y), L.ptr(mean), L.ptr(rstd),
+                                     rows, cols, _f(eps), _f(p), _u32(seed), _u32(rng_stream), L.stream()), "a8_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, dy2, x, res, gamma, mean, rstd, dgamma, dbeta, p=0.0, seed=0, rng_stream=0, want_dx=True, want_dres=True):
+    rows, cols = x.numel() // x.shape[-1], x.shape[-1]
+    dx = torch.empty_like(x) if want_dx else None
+    dres = torch.empty_like(x) if want_dres else None
+    L.check(L.lib().a8_layernorm_bwd(L.dt(x), L.ptr(_c(dy)), L.ptr(_c(dy2)), L.ptr(_c(x)), L.ptr(_c(res)), L.ptr(gamma), L.ptr(mean), L.ptr(rstd),
+                                     L.ptr(dx), L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), rows, cols, _f(p), _u32(seed), _u32(rng_stream),
+                                     L.stream()), "a8_layernorm_bwd")
+    return dx, dres
+
+
+# ----------------------------------------------------------------------------- element-wise
+def cast(src, dst_dtype):
+    dst = torch.empty(src.shape, device=src.device, dtype=dst_dtype)
+    L.check(L.lib().a8_cast(L.dt(src), L.dt(dst), L.ptr(_c(src)), L.ptr(dst), C.c_int64(src.numel()), L.stream()), "a8_cast")
+    return dst
+
+
+def dropout(x, p, seed, rng_stream):
+    y = torch.empty_like(x)
+    L.check(L.lib().a8_dropout(L.dt(x), L.ptr(_c(x)), L.ptr(y), C.c_int64(x.numel()), _f(p), _u32(seed), _u32(rng_stream), L.stream()), "a8_dropout")
+    return y
+
+
+def mask_fill_rows_(x2d, mask_u8, emb):
+    rows, cols = x2d.shape
+    L.check(L.lib().a8_mask_fill_rows(L.dt(x2d), L.ptr(_c(x2d)), L.ptr(mask_u8), L.ptr(emb), rows, cols, L.stream()), "a8_mask_fill_rows")
+    return x2d
+
+
+def mask_fill_rows_bwd_(dy2d, mask_u8, demb):
+    rows, cols = dy2d.shape
+    L.check(L.lib().a8_mask_fill_rows_bwd(L.dt(dy2d), L.ptr(_c(dy2d)), L.ptr(mask_u8), L.ptr(demb), rows, cols, L.stream()), "a8_mask_fill_rows_bwd")
+    return dy2d
+
+
+def mask_zero_cols_(x3d, cmask_u8):
+    B, T, cols = x3d.shape
+    L.check(L.lib().a8_mask_zero_cols(L.dt(x3d), L.ptr(_c(x3d)), L.ptr(cmask_u8), B, T, cols, L.stream()), "a8_mask_zero_cols")
+    return x3d
+
+
+def zero_rows_(x2d, keep_u8):
+    rows, cols = x2d.shape
+    L.check(L.lib().a8_zero_rows(L.dt(x2d), L.ptr(_c(x2d)), L.ptr(keep_u8), rows, cols, L.stream()), "a8_zero_rows")
+    return x2d
+
+
+def gather_rows(src2d, idx_i32):
+    n, cols = idx_i32.numel(), src2d.shape[1]
+    dst = torch.empty((n, cols), device=src2d.device, dtype=src2d.dtype)
+    L.check(L.lib().a8_gather_rows(L.dt(src2d), L.ptr(_c(src2d)), L.ptr(idx_i32), L.ptr(dst), n, cols, L.stream()), "a8_gather_rows")
+    return dst
+
+
+def scatter_add_rows_(dst2d, idx_i32, src2d):
+    n, cols = idx_i32.numel(), src2d.shape[1]
+    L.check(L.lib().a8_scatter_add_rows(L.dt(src2d), L.ptr(_c(src2d)), L.ptr(idx_i32), L.ptr(_c(dst2d)), n, cols, L.stream()), "a8_scatter_add_rows")
+    return dst2d
+
+
+def add(a, b):
+    y = torch.empty_like(a)
+    L.check(L.lib().a8_add(L.dt(a), L.ptr(_c(a)), L.ptr(_c(b)), L.ptr(y), C.c_int64(a.numel()), L.stream()), "a8_add")
+    return y
+
+
+def gelu_bwd_bias(dy, z, dbias):
+    rows, cols = dy.numel() // dy.shape[-1], dy.shape[-1]
+    dz = torch.empty_like(dy)
+    L.check(L.lib().a8_gelu_bwd_bias(L.dt(dy), L.ptr(_c(dy)), L.ptr(_c(z)), L.ptr(dz), L.ptr(dbias), rows, cols, L.stream()), "a8_gelu_bwd_bias")
+    return dz
+
+
+# ----------------------------------------------------------------------------- positional conv
+def posconv_fwd(x, w_g, bias, groups, k, pad_left, mode, want_z=False):
+    """x [B,T,d]; w_g [G][dg][k][dg] (activation dtype).  mode 1: x + gelu(conv+b); 0: gelu(conv+b); -1: conv only."""
+    B, T, d = x.shape
+    y = torch.empty_like(x)
+    z = torch.empty_like(x) if want_z else None
+    L.check(L.lib().a8_posconv_fwd(L.dt(x), L.ptr(_c(x)), L.ptr(_c(w_g)), L.ptr(bias), L.ptr(y), L.ptr(z), B, T, d, groups, k, pad_left, mode,
+                                   L.stream()), "a8_posconv_fwd")
+    return y, z
+
+
+def posconv_wgrad(x, dz, dw_g, groups, k, pad_left):
+    B, T, d = x.shape
+    L.check(L.lib().a8_posconv_wgrad(L.dt(x), L.ptr(_c(x)), L.ptr(_c(dz)), L.ptr(dw_g), B, T, d, groups, k, pad_left, L.stream()), "a8_posconv_wgrad")
+
+
+# ----------------------------------------------------------------------------- attention
+def attn_fwd(q, k, v, B, T, H, ld_qkv, scale, keymask=None, p=0.0, seed=0):
+    """q,k,v: [B*T, ld_qkv] views (head h at columns h*64..); returns (o [B*T, H*64], lse f32 [B,H,T])."""
+    o = torch.empty((B * T, H * 64), device=q.device, dtype=q.dtype)
+    lse = torch.empty((B, H, T), device=q.device, dtype=torch.float32)
+    L.check(L.lib().a8_attn_fwd(L.dt(q), L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), L.ptr(lse), L.ptr(keymask), B, T, H, C.c_int64(ld_qkv),
+                                C.c_int64(H * 64), _f(scale), _f(p), _u32(seed), L.stream()), "a8_attn_fwd")
+    return o, lse
+
+
+def attn_bwd(q, k, v, o, dout, lse, B, T, H, ld_qkv, scale, keymask=None, p=0.0, seed=0, dqkv=None):
+    """Returns dq, dk, dv as column slices of one [B*T, 3*H*64] buffer (so the q/k/v weight-gradient GEMMs read them in place)."""
+    d = H * 64
+    if dqkv is None:
+        dqkv = torch.empty((B * T, 3 * d), device=q.device, dtype=q.dtype)
+    delta = torch.empty((B, H, T), device=q.device, dtype=torch.float32)
+    dq, dk, dv = dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:]
+    L.check(L.lib().a8_attn_bwd(L.dt(q), L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), L.ptr(_c(dout)), L.ptr(lse), L.ptr(keymask),
+                                L.ptr(dq), L.ptr(dk), L.ptr(dv), L.ptr(delta), B, T, H, C.c_int64(ld_qkv), C.c_int64(d), C.c_int64(3 * d),
+                                _f(scale), _f(p), _u32(seed), L.stream()), "a8_attn_bwd")
+    return dq, dk, dv, dqkv
+
+
+# ----------------------------------------------------------------------------- VQ
+def vq_select(logits, gumbel, tau):
+    R, V = logits.shape
+    codes = torch.empty((R,), device=logits.device, dtype=torch.int32)
+    avg = torch.empty((V,), device=logits.device, dtype=torch.float32)
+    L.check(L.lib().a8_vq_select(L.ptr(_c(logits)), L.ptr(_c(gumbel)), _f(tau), L.ptr(codes), L.ptr(avg), R, V, L.stream()), "a8_vq_select")
+    return codes, avg
+
+
+def vq_gather(vars2d, codes, N, G, V, D, dtype):
+    q = torch.empty((N, G * D), device=vars2d.device, dtype=dtype)
+    L.check(L.lib().a8_vq_gather(L.dt(q), L.ptr(_c(vars2d)), L.ptr(codes), L.ptr(q), N, G, V, D, L.stream()), "a8_vq_gather")
+    return q
+
+
+def vq_ppl(avg):
+    V = avg.numel()
+    ppl = torch.empty((1,), device=avg.device, dtype=torch.float32)
+    dppl = torch.empty((V,), device=avg.device, dtype=torch.float32)
+    L.check(L.lib().a8_vq_ppl(L.ptr(avg), L.ptr(ppl), L.ptr(dppl), V, L.stream()), "a8_vq_ppl")
+    return ppl, dppl
+
+
+def vq_bwd(logits, gumbel, tau, codes, vars2d, dq, eproj, dppl, gppl, dvars, N, G, V, D, training):
+    dlogits = torch.empty_like(logits)
+    L.check(L.lib().a8_vq_bwd(L.dt(dq), L.ptr(logits), L.ptr(gumbel), _f(tau), L.ptr(codes), L.ptr(_c(vars2d)), L.ptr(_c(dq)), L.ptr(eproj),
+                              L.ptr(dppl), L.ptr(gppl), L.ptr(dlogits), L.ptr(dvars), N, G, V, D, 1 if training else 0, L.stream()), "a8_vq_bwd")
+    return dlogits
+
+
+# ----------------------------------------------------------------------------- contrastive
+def contrastive_fwd(ctx, lat, neg_idx):
+    rows, Cn = ctx.shape
+    N = neg_idx.shape[1]
+    logits = torch.empty((rows, N + 1), device=ctx.device, dtype=torch.float32)
+    loss_sum = torch.zeros((1,), device=ctx.device, dtype=torch.float32)
+    scratch = torch.empty((2 * rows,), device=ctx.device, dtype=torch.float32)
+    L.check(L.lib().a8_contrastive_fwd(L.dt(ctx), L.ptr(_c(ctx)), L.ptr(_c(lat)), L.ptr(_c(neg_idx)), L.ptr(logits), L.ptr(loss_sum),
+                                       L.ptr(scratch), rows, N, Cn, L.stream()), "a8_contrastive_fwd")
+    return logits, loss_sum
+
+
+def contrastive_bwd(ctx, lat, neg_idx, logits, gscale):
+    rows, Cn = ctx.shape
+    N = neg_idx.shape[1]
+    dctx = torch.empty((rows, Cn), device=ctx.device, dtype=torch.float32)
+    dlat = torch.zeros((rows, Cn), device=ctx.device, dtype=torch.float32)
+    scratch = torch.empty((2 * rows,), device=ctx.device, dtype=torch.float32)
+    L.check(L.lib().a8_contrastive_bwd(L.dt(ctx), L.ptr(_c(ctx)), L.ptr(_c(lat)), L.ptr(_c(neg_idx)), L.ptr(logits), L.ptr(gscale),
+                                       L.ptr(dctx), L.ptr(dlat), L.ptr(scratch), rows, N, Cn, L.stream()), "a8_contrastive_bwd")
+    return dctx, dlat
+
+
+# ----------------------------------------------------------------------------- CTC + log-softmax
+def ctc_fwd_bwd(lp, targets_flat_i32, tgt_off_i32, in_len_i32, Smax, blank=0, zero_infinity=True):
+    T, B, V = lp.shape
+    nll = torch.empty((B,), device=lp.device, dtype=torch.float32)
+    grad = torch.empty_like(lp)
+    alpha = torch.empty((B, T, 2 * Smax + 2), device=lp.device, dtype=torch.float32)
+    L.check(L.lib().a8_ctc_fwd_bwd(L.ptr(_c(lp)), L.ptr(targets_flat_i32), L.ptr(tgt_off_i32), L.ptr(in_len_i32), L.ptr(nll), L.ptr(grad),
+                                   L.ptr(alpha), T, B, V, Smax, blank, 1 if zero_infinity else 0, L.stream()), "a8_ctc_fwd_bwd")
+    return nll, grad
+
+
+def log_softmax_fwd(x2d):
+    rows, cols = x2d.shape
+    y = torch.empty((rows, cols), device=x2d.device, dtype=torch.float32)
+    L.check(L.lib().a8_log_softmax_fwd(L.ptr(_c(x2d)), L.dt(x2d), L.ptr(y), rows, cols, L.stream()), "a8_log_softmax_fwd")
+    return y
+
+
+def log_softmax_bwd(y, dy, dtype):
+    rows, cols = y.shape
+    dx = torch.empty((rows, cols), device=y.device, dtype=dtype)
+    L.check(L.lib().a8_log_softmax_bwd(L.ptr(y), L.ptr(_c(dy)), L.ptr(dx), L.dt(dx), rows, cols, L.stream()), "a8_log_softmax_bwd")
+    return dx
+
+
+# ----------------------------------------------------------------------------- optimizer
+def sumsq_(x, out):
+    L.check(L.lib().a8_sumsq(L.ptr(x), C.c_int64(x.numel()), L.ptr(out), L.stream()), "a8_sumsq")
+
+
+def adamw_(p, g, m, v, lr, beta1, beta2, eps, wd, step, gnorm_sq=None, max_norm=0.0, grad_scale=1.0):
+    L.check(L.lib().a8_adamw(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), C.c_int64(p.numel()), _f(lr), _f(beta1), _f(beta2), _f(eps), _f(wd),
+                             int(step), L.ptr(gnorm_sq), _f(max_norm), _f(grad_scale), L.stream()), "a8_adamw")

@@ -1,0 +1,491 @@
+"""Autograd surface of the hot path: coarse torch.autograd.Functions whose forward/backward are
+fixed sequences of liba8hip kernel launches (audio8_amd/kernels.py).  PyTorch supplies device
+memory, the stream and the autograd tape; no arithmetic of the path runs in ATen, except
+O(#params)-sized weight preparation (weight-norm of the pos-conv, conv-weight re-layout, bias
+concatenation) which is left to torch ops on purpose: it is plumbing, differentiable by the
+tape, and three orders of magnitude below the activations in bytes.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import kernels as K
+
+# ------------------------------------------------------------------ global compute configuration
+_COMPUTE_DTYPE = torch.bfloat16
+_SEED_STATE = {"base": None, "ctr": 0}
+
+
+def set_compute_dtype(dtype):
+    """torch.bfloat16 (throughput mode: bf16 activations, f32 accumulate/statistics) or
+    torch.float32 (parity mode: exact-f32 MFMA everywhere)."""
+    global _COMPUTE_DTYPE
+    if dtype not in (torch.bfloat16, torch.float32):
+        raise ValueError("compute dtype must be torch.bfloat16 or torch.float32")
+    _COMPUTE_DTYPE = dtype
+
+
+def compute_dtype():
+    return _COMPUTE_DTYPE
+
+
+def next_seed():
+    """Dropout seeds: a counter stream derived from torch's seed.  Never touches numpy's global RNG,
+    whose draw order belongs to mask/negative sampling."""
+    st = _SEED_STATE
+    if st["base"] is None:
+        st["base"] = torch.initial_seed() & 0xFFFFFFFF
+    st["ctr"] += 1
+    return (st["base"] + st["ctr"] * 0x9E3779B1) & 0xFFFFFFFF
+
+
+def reset_seed_stream():
+    _SEED_STATE["base"] = None
+    _SEED_STATE["ctr"] = 0
+
+
+def _wcast(w, dtype):
+    """Working copy of an f32 master weight in the compute dtype."""
+    return w.detach() if dtype == torch.float32 else K.cast(w.detach().contiguous(), dtype)
+
+
+def _splitk(out_tiles, kred):
+    s = max(1, min(16, round(512 / max(1, out_tiles))))
+    while s > 1 and kred // s < 256:
+        s -= 1
+    return s
+
+
+def _tiles(m, n):
+    return ((m + 127) // 128) * ((n + 127) // 128)
+
+
+def wgrad(dy, x, n_out, n_in, m, lda=None, ldb=None, b_rpb=0, b_bs=0):
+    """dW[n_out, n_in] (f32) = dy[m, n_out]^T . x[m, n_in]   (split-K over m)."""
+    out = torch.zeros((n_out, n_in), device=dy.device, dtype=torch.float32)
+    K.gemm(L.TN, dy, x, n_out, n_in, m, out=out, lda=lda, ldb=ldb, b_rpb=b_rpb, b_bs=b_bs, splitk=_splitk(_tiles(n_out, n_in), m))
+    return out
+
+
+def colsum(x2d, cols=None):
+    """f32 column sums of a [rows, cols] activation (bias gradients)."""
+    out = torch.zeros((x2d.shape[-1],), device=x2d.device, dtype=torch.float32)
+    rows = x2d.numel() // x2d.shape[-1]
+    L.check(L.lib().a8_gelu_bwd_bias(L.dt(x2d), L.ptr(x2d), None, None, L.ptr(out), rows, x2d.shape[-1], L.stream()), "a8_gelu_bwd_bias")
+    return out
+
+
+# ------------------------------------------------------------------ Linear
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b (eight_mile Dense / nn.Linear).  x [M, K] compute dtype."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, out_f32):
+        M, Kd = x.shape
+        N = weight.shape[0]
+        wc = _wcast(weight, x.dtype)
+        y = K.gemm(L.NT, x, wc, M, N, Kd, bias=bias.detach() if bias is not None else None,
+                   out_dtype=torch.float32 if out_f32 else x.dtype)
+        ctx.save_for_backward(x, wc)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wc = ctx.saved_tensors
+        M, Kd = x.shape
+        N = wc.shape[0]
+        dy = dy.contiguous()
+        if dy.dtype != x.dtype:
+            dy = K.cast(dy, x.dtype)
+        dx = K.gemm(L.NN, dy, wc, M, Kd, N) if ctx.needs_input_grad[0] else None
+        dw = wgrad(dy, x, N, Kd, M) if ctx.needs_input_grad[1] else None
+        db = colsum(dy) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db, None
+
+
+def linear(x, weight, bias, out_f32=False):
+    shp = x.shape
+    y = LinearFn.apply(x.reshape(-1, shp[-1]), weight, bias, out_f32)
+    return y.view(*shp[:-1], weight.shape[0])
+
+
+# ------------------------------------------------------------------ LayerNorm / dropout / mask / gather
+class LayerNormFn(torch.autograd.Function):
+    """y = LN(res + dropout_p(x)); res may be None."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, eps, p):
+        seed = next_seed() if p > 0 else 0
+        y, mean, rstd = K.layernorm_fwd(x, res, gamma.detach(), beta.detach(), eps, p, seed, 1)
+        ctx.save_for_backward(x, res, gamma, mean, rstd)
+        ctx.p, ctx.seed = p, seed
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, res, gamma, mean, rstd = ctx.saved_tensors
+        dg = torch.zeros_like(gamma, dtype=torch.float32)
+        db = torch.zeros_like(gamma, dtype=torch.float32)
+        dx, dres = K.layernorm_bwd(dy.contiguous(), None, x, res, gamma.detach(), mean, rstd, dg, db, ctx.p, ctx.seed, 1,
+                                   want_dx=True, want_dres=res is not None and ctx.p > 0)
+        if res is not None and ctx.p == 0:
+            dres = dx
+        return dx, (dres if res is not None else None), dg, db, None, None
+
+
+def layer_norm(x, gamma, beta, eps, res=None, p=0.0):
+    return LayerNormFn.apply(x.contiguous(), res, gamma, beta, eps, p)
+
+
+class DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        ctx.p, ctx.seed = p, next_seed()
+        return K.dropout(x.contiguous(), p, ctx.seed, 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return K.dropout(dy.contiguous(), ctx.p, ctx.seed, 2), None
+
+
+def dropout(x, p, training):
+    if not training or p <= 0:
+        return x
+    return DropoutFn.apply(x, p)
+
+
+class MaskFillRowsFn(torch.autograd.Function):
+    """features[time_mask] = mask_emb  (audio8/wav2vec2.py:939,717).  x [rows, d]; mask uint8 [rows]."""
+
+    @staticmethod
+    def forward(ctx, x, mask_u8, emb):
+        y = K.mask_fill_rows_(x.clone(), mask_u8, emb.detach())
+        ctx.save_for_backward(mask_u8)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask_u8,) = ctx.saved_tensors
+        demb = torch.zeros((dy.shape[-1],), device=dy.device, dtype=torch.float32)
+        dx = K.mask_fill_rows_bwd_(dy.clone(), mask_u8, demb)
+        return dx, None, demb
+
+
+class GatherRowsFn(torch.autograd.Function):
+    """x[idx] for unique row indices (masked select of frames, audio8/wav2vec2.py:946,381)."""
+
+    @staticmethod
+    def forward(ctx, x, idx_i32):
+        ctx.save_for_backward(idx_i32)
+        ctx.rows = x.shape[0]
+        return K.gather_rows(x.contiguous(), idx_i32)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        dx = torch.zeros((ctx.rows, dy.shape[1]), device=dy.device, dtype=dy.dtype)
+        K.scatter_add_rows_(dx, idx, dy.contiguous())
+        return dx, None
+
+
+class ZeroFn(torch.autograd.Function):
+    """x[~keep_rows] = 0 and/or x[:, :, cmask] = 0; the same masking is its own backward."""
+
+    @staticmethod
+    def forward(ctx, x, keep_rows_u8, cmask_u8):
+        ctx.save_for_backward(keep_rows_u8, cmask_u8)
+        y = x.clone()
+        if keep_rows_u8 is not None:
+            K.zero_rows_(y.view(-1, y.shape[-1]), keep_rows_u8)
+        if cmask_u8 is not None:
+            K.mask_zero_cols_(y, cmask_u8)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        keep_rows_u8, cmask_u8 = ctx.saved_tensors
+        dx = dy.clone()
+        if keep_rows_u8 is not None:
+            K.zero_rows_(dx.view(-1, dx.shape[-1]), keep_rows_u8)
+        if cmask_u8 is not None:
+            K.mask_zero_cols_(dx, cmask_u8)
+        return dx, None, None
+
+
+# ------------------------------------------------------------------ conv feature extractor
+class ConvStackFn(torch.autograd.Function):
+    """ConvFeatureExtractionModel.forward (audio8/wav2vec2.py:448-456) -> channels-last [B, T, 512].
+    Layer 0 = fused conv+GroupNorm+GELU kernels; layers 1.. = one NT GEMM each over overlapping rows."""
+
+    @staticmethod
+    def forward(ctx, x, gn_w, gn_b, feats, *ws):
+        dtype = compute_dtype()
+        B, Ls = x.shape
+        x = x.contiguous().float()
+        a, stats = K.conv0_gn_gelu_fwd(x, ws[0].detach().contiguous(), gn_w.detach(), gn_b.detach(), dtype)
+        acts, zs, wcs, lens = [a], [None], [None], [a.shape[1]]
+        for i in range(1, len(ws)):
+            co, k, s = feats[i]
+            cin = ws[i].shape[1]
+            w2 = ws[i].detach().permute(0, 2, 1).reshape(co, k * cin)            # [co][kk*cin + ci]
+            wc = w2.contiguous() if dtype == torch.float32 else K.cast(w2.contiguous(), dtype)
+            Lin = lens[-1]
+            Lout = (Lin - k) // s + 1
+            z = torch.empty((B * Lout, co), device=x.device, dtype=dtype)
+            y = K.gemm(L.NT, acts[-1], wc, B * Lout, co, k * cin, lda=s * cin, a_rpb=Lout, a_bs=Lin * cin, act=L.ACT_GELU, zout=z)
+            acts.append(y.view(B, Lout, co))
+            zs.append(z)
+            wcs.append(wc)
+            lens.append(Lout)
+        ctx.feats, ctx.lens, ctx.B = feats, lens, B
+        ctx.save_for_backward(x, gn_w, gn_b, stats, ws[0], *acts[:-1], *zs[1:], *wcs[1:])
+        ctx.nl = len(ws)
+        return acts[-1]
+
+    @staticmethod
+    def backward(ctx, dout):
+        nl, B, feats, lens = ctx.nl, ctx.B, ctx.feats, ctx.lens
+        sv = ctx.saved_tensors
+        x, gn_w, gn_b, stats, w0 = sv[:5]
+        acts = sv[5:5 + nl - 1]                      # a_0 .. a_{nl-2}
+        zs = (None,) + sv[5 + nl - 1:5 + 2 * (nl - 1)]
+        wcs = (None,) + sv[5 + 2 * (nl - 1):]
+        dtype = acts[0].dtype
+        grads = [None] * nl
+        da = dout.contiguous()
+        if da.dtype != dtype:
+            da = K.cast(da, dtype)
+        co = feats[-1][0]
+        dz = K.gelu_bwd_bias(da.view(-1, co), zs[nl - 1], None)
+        for i in range(nl - 1, 0, -1):
+            co, k, s = feats[i]
+            cin = acts[i - 1].shape[-1]
+            Lin, Lout = lens[i - 1], lens[i]
+            M = B * Lout
+            dw2 = wgrad(dz, acts[i - 1], co, k * cin, M, ldb=s * cin, b_rpb=Lout, b_bs=Lin * cin)
+            grads[i] = dw2.view(co, k, cin).permute(0, 2, 1).contiguous()
+            dcol = K.gemm(L.NN, dz, wcs[i], M, k * cin, co)
+            dz = K.col2im_gelu_grad(dcol, zs[i - 1] if i - 1 >= 1 else None, B, Lin, Lout, cin, k, s).view(-1, cin)
+            del dcol
+        dw0 = torch.zeros_like(w0, dtype=torch.float32)
+        dgw = torch.zeros_like(gn_w, dtype=torch.float32)
+        dgb = torch.zeros_like(gn_b, dtype=torch.float32)
+        K.conv0_gn_gelu_bwd(x, w0.detach().contiguous(), gn_w.detach(), gn_b.detach(), stats, dz.view(B, lens[0], -1), dw0, dgw, dgb)
+        grads[0] = dw0
+        return (None, dgw, dgb, None, *grads)
+
+
+# ------------------------------------------------------------------ positional conv
+class PosConvFn(torch.autograd.Function):
+    """y = x + gelu(conv1d_same(x; w) + bias), grouped, k = 128  (audio8/wav2vec2.py:634-638).
+    w is the effective (weight-normed) kernel [d, d/G, k] in f32; the tape differentiates the weight-norm."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, groups, pad_left):
+        B, T, d = x.shape
+        dg, k = w.shape[1], w.shape[2]
+        wg = w.detach().view(groups, dg, dg, k)
+        wf = wg.permute(0, 1, 3, 2).contiguous()                       # [G][co][kk][ci]
+        wt = wg.flip(3).permute(0, 2, 3, 1).contiguous()               # [G][ci][kk'][co]  (data-gradient kernel)
+        if x.dtype != torch.float32:
+            wf, wt = K.cast(wf, x.dtype), K.cast(wt, x.dtype)
+        y, z = K.posconv_fwd(x.contiguous(), wf, bias.detach(), groups, k, pad_left, 1, want_z=True)
+        ctx.save_for_backward(x, z, wt)
+        ctx.groups, ctx.pad_left, ctx.k, ctx.dg = groups, pad_left, k, dg
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, z, wt = ctx.saved_tensors
+        B, T, d = x.shape
+        G, k, dg = ctx.groups, ctx.k, ctx.dg
+        dy = dy.contiguous()
+        dbias = torch.zeros((d,), device=x.device, dtype=torch.float32)
+        dz = K.gelu_bwd_bias(dy, z, dbias)
+        dxc, _ = K.posconv_fwd(dz, wt, None, G, k, k - 1 - ctx.pad_left, -1)
+        dx = K.add(dy, dxc)
+        dwg = torch.zeros((G, dg, k, dg), device=x.device, dtype=torch.float32)
+        K.posconv_wgrad(x, dz, dwg, G, k, ctx.pad_left)
+        dw = dwg.permute(0, 1, 3, 2).reshape(d, dg, k)
+        return dx, dw, dbias, None, None
+
+
+# ------------------------------------------------------------------ transformer encoder layer (post-LN)
+class EncoderLayerFn(torch.autograd.Function):
+    """One eight_mile TransformerEncoder with layer_norms_after=True:
+        h = W_O attn(W_Q x, W_K x, W_V x);  x1 = ln2(x + drop(h));  x2 = ln1(x1 + drop(W_2 gelu(W_1 x1)))
+    12 kernel launches forward, 21 backward; QKV run as one N = 3d GEMM on a concatenated working copy."""
+
+    @staticmethod
+    def forward(ctx, x, keymask, B, T, H, p, eps, wq, bq, wk, bk, wv, bv, wo, bo, w1, b1, w2, b2, g1, be1, g2, be2):
+        M, d = x.shape
+        dt = x.dtype
+        dff = w1.shape[0]
+        wqkv = torch.cat([wq.detach(), wk.detach(), wv.detach()], 0)
+        bqkv = torch.cat([bq.detach(), bk.detach(), bv.detach()], 0)
+        wqkv_c, wo_c, w1_c, w2_c = _wcast(wqkv, dt), _wcast(wo, dt), _wcast(w1, dt), _wcast(w2, dt)
+        qkv = K.gemm(L.NT, x, wqkv_c, M, 3 * d, d, bias=bqkv)
+        seed_a = next_seed() if p > 0 else 0
+        o, lse = K.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, T, H, 3 * d, 1.0 / math.sqrt(d // H), keymask, p, seed_a)
+        ao = K.gemm(L.NT, o, wo_c, M, d, d, bias=bo.detach())
+        seed1 = next_seed() if p > 0 else 0
+        x1, mean2, rstd2 = K.layernorm_fwd(ao, x, g2.detach(), be2.detach(), eps, p, seed1, 3)
+        z1 = torch.empty((M, dff), device=x.device, dtype=dt)
+        h = K.gemm(L.NT, x1, w1_c, M, dff, d, bias=b1.detach(), act=L.ACT_GELU, zout=z1)
+        f = K.gemm(L.NT, h, w2_c, M, d, dff, bias=b2.detach())
+        seed2 = next_seed() if p > 0 else 0
+        x2, mean1, rstd1 = K.layernorm_fwd(f, x1, g1.detach(), be1.detach(), eps, p, seed2, 4)
+        ctx.save_for_backward(x, keymask, qkv, o, lse, ao, x1, mean2, rstd2, z1, h, f, mean1, rstd1,
+                              wqkv_c, wo_c, w1_c, w2_c, g1, g2)
+        ctx.cfg = (B, T, H, p, seed_a, seed1, seed2)
+        return x2
+
+    @staticmethod
+    def backward(ctx, dx2):
+        (x, keymask, qkv, o, lse, ao, x1, mean2, rstd2, z1, h, f, mean1, rstd1, wqkv_c, wo_c, w1_c, w2_c, g1, g2) = ctx.saved_tensors
+        B, T, H, p, seed_a, seed1, seed2 = ctx.cfg
+        M, d = x.shape
+        dff = z1.shape[1]
+        dev = x.device
+        f32 = torch.float32
+        dx2 = dx2.contiguous()
+        dg1, dbe1 = torch.zeros(d, device=dev, dtype=f32), torch.zeros(d, device=dev, dtype=f32)
+        dg2, dbe2 = torch.zeros(d, device=dev, dtype=f32), torch.zeros(d, device=dev, dtype=f32)
+        # ln1: x2 = LN(x1 + drop(f))
+        df, dx1_res = K.layernorm_bwd(dx2, None, f, x1, g1.detach(), mean1, rstd1, dg1, dbe1, p, seed2, 4, want_dx=True, want_dres=p > 0)
+        if p == 0:
+            dx1_res = df
+        # FFN
+        db2 = colsum(df)
+        dw2 = wgrad(df, h, d, dff, M)
+        dz1 = K.gemm(L.NN, df, w2_c, M, dff, d, act=L.ACT_MUL_GELU_GRAD, zin=z1, ldz=dff)
+        db1 = colsum(dz1)
+        dw1 = wgrad(dz1, x1, dff, d, M)
+        dx1_ffn = K.gemm(L.NN, dz1, w1_c, M, d, dff)
+        # ln2: x1 = LN(x + drop(ao))
+        dao, dx_res = K.layernorm_bwd(dx1_res, dx1_ffn, ao, x, g2.detach(), mean2, rstd2, dg2, dbe2, p, seed1, 3, want_dx=True, want_dres=p > 0)
+        if p == 0:
+            dx_res = dao
+        # output projection
+        dbo = colsum(dao)
+        dwo = wgrad(dao, o, d, d, M)
+        do = K.gemm(L.NN, dao, wo_c, M, d, d)
+        # attention core
+        _, _, _, dqkv = K.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, do, lse, B, T, H, 3 * d, 1.0 / math.sqrt(d // H),
+                                   keymask, p, seed_a)
+        dbqkv = colsum(dqkv)
+        dwqkv = wgrad(dqkv, x, 3 * d, d, M)
+        dx_qkv = K.gemm(L.NN, dqkv, wqkv_c, M, d, 3 * d)
+        dx = K.add(dx_res, dx_qkv)
+        return (dx, None, None, None, None, None, None,
+                dwqkv[:d], dbqkv[:d], dwqkv[d:2 * d], dbqkv[d:2 * d], dwqkv[2 * d:], dbqkv[2 * d:],
+                dwo, dbo, dw1, db1, dw2, db2, dg1, dbe1, dg2, dbe2)
+
+
+# ------------------------------------------------------------------ Gumbel vector quantiser
+class VQFn(torch.autograd.Function):
+    """GumbelVectorQuantizer.forward (audio8/wav2vec2.py:547-576): returns (q [N, G*D], prob_ppl [1]).
+    The 512->G*V projection runs in exact f32 (2944 rows: negligible) so code selection tracks the
+    f32 reference as closely as possible; `gumbel` injects the noise (None: drawn with torch's recipe)."""
+
+    @staticmethod
+    def forward(ctx, y, wp, bp, vars_, G, V, tau, training, gumbel):
+        N, Cin = y.shape
+        D = vars_.shape[-1]
+        yf = y if y.dtype == torch.float32 else K.cast(y.contiguous(), torch.float32)
+        logits = K.gemm(L.NT, yf, wp.detach().contiguous(), N, G * V, Cin, bias=bp.detach()).view(N * G, V)
+        if training and gumbel is None:
+            gumbel = -torch.empty_like(logits).exponential_().log()
+        vars2d = vars_.detach().reshape(G * V, D)
+        codes, avg = K.vq_select(logits, gumbel if training else None, tau)
+        q = K.vq_gather(vars2d, codes, N, G, V, D, y.dtype)
+        ppl, dppl = K.vq_ppl(avg)
+        ctx.save_for_backward(yf, wp, logits, gumbel if training else None, codes, vars2d, dppl)
+        ctx.cfg = (G, V, D, tau, training, y.dtype, vars_.shape)
+        ctx.mark_non_differentiable(codes)
+        return q, ppl, codes
+
+    @staticmethod
+    def backward(ctx, dq, dppl_out, _dcodes):
+        yf, wp, logits, gumbel, codes, vars2d, dppl = ctx.saved_tensors
+        G, V, D, tau, training, ydt, vshape = ctx.cfg
+        N, Cin = yf.shape
+        dev = yf.device
+        dqf = dq.contiguous()
+        if dqf.dtype != torch.float32:
+            dqf = K.cast(dqf, torch.float32)
+        eproj = None
+        if training:
+            eproj = torch.empty((N, G * V), device=dev, dtype=torch.float32)
+            for g in range(G):
+                K.gemm(L.NT, dqf[:, g * D:], vars2d[g * V:], N, V, D, lda=G * D, out=eproj[:, g * V:], ldc=G * V)
+        dvars = torch.zeros_like(vars2d)
+        gppl = dppl_out.contiguous().float() if dppl_out is not None else torch.zeros(1, device=dev)
+        dlogits = K.vq_bwd(logits, gumbel, tau, codes, vars2d, dqf, eproj, dppl, gppl, dvars, N, G, V, D, training).view(N, G * V)
+        dwp = wgrad(dlogits, yf, G * V, Cin, N)
+        dbp = colsum(dlogits)
+        dy = K.gemm(L.NN, dlogits, wp.detach().contiguous(), N, Cin, G * V)
+        if ydt != torch.float32:
+            dy = K.cast(dy, ydt)
+        return dy, dwp, dbp, dvars.view(vshape), None, None, None, None, None
+
+
+# ------------------------------------------------------------------ contrastive loss
+class ContrastiveXEFn(torch.autograd.Function):
+    """mean over masked frames of CE([cos(c, q+), cos(c, q-_1..N)], 0)  (audio8/wav2vec2.py:384-390)."""
+
+    @staticmethod
+    def forward(ctx, ctx_rows, lat_rows, neg_idx):
+        logits, loss_sum = K.contrastive_fwd(ctx_rows.contiguous(), lat_rows.contiguous(), neg_idx)
+        ctx.save_for_backward(ctx_rows, lat_rows, neg_idx, logits)
+        rows = ctx_rows.shape[0]
+        ctx.mark_non_differentiable(logits)
+        return loss_sum[0] / rows, logits
+
+    @staticmethod
+    def backward(ctx, dloss, _dlogits):
+        c, q, neg_idx, logits = ctx.saved_tensors
+        rows = c.shape[0]
+        gscale = (dloss.float() / rows).reshape(1).contiguous()
+        dctx, dlat = K.contrastive_bwd(c.contiguous(), q.contiguous(), neg_idx, logits, gscale)
+        if c.dtype != torch.float32:
+            dctx, dlat = K.cast(dctx, c.dtype), K.cast(dlat, q.dtype)
+        return dctx, dlat, None
+
+
+# ------------------------------------------------------------------ log-softmax head + CTC
+class LogSoftmaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        shp = x.shape
+        y = K.log_softmax_fwd(x.reshape(-1, shp[-1]).contiguous())
+        ctx.save_for_backward(y)
+        ctx.dt = x.dtype
+        return y.view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return K.log_softmax_bwd(y, dy.reshape(y.shape).contiguous().float(), ctx.dt).view(dy.shape)
+
+
+class CTCFn(torch.autograd.Function):
+    """Per-utterance CTC negative log-likelihoods (zero_infinity applied) from log-probs [T,B,V]."""
+
+    @staticmethod
+    def forward(ctx, lp, flat_i32, off_i32, in_len_i32, Smax, blank, zero_infinity):
+        nll, grad = K.ctc_fwd_bwd(lp.contiguous().float(), flat_i32, off_i32, in_len_i32, Smax, blank, zero_infinity)
+        ctx.save_for_backward(grad)
+        return nll
+
+    @staticmethod
+    def backward(ctx, dnll):
+        (grad,) = ctx.saved_tensors
+        return grad * dnll.view(1, -1, 1), None, None, None, None, None, None
+
+
+def host_i32(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device, non_blocking=True)

@@ -100,14 +100,15 @@ int a8_add(int dtype, const void* a, const void* b, void* y, int64_t n, void* st
 
 /* ---- positional conv (eight_mile Conv1DSame(d,d,k=128,groups=16)+GELU, audio8/wav2vec2.py:600-609,634-638)
  * x dtype [B,T,d]; w dtype [G][d/G out][k][d/G in] (weight-normed, re-laid-out by the host); bias f32[d].
- * y = x + gelu(conv(x) + bias) when add_residual, z (pre-GELU, dtype) saved for backward.
+ * add_residual = 1: y = x + gelu(conv(x) + bias); 0: y = gelu(conv(x) + bias); -1: y = conv(x) (data-gradient mode).
+ * z (pre-GELU, dtype, may be NULL) is saved for backward.
  * The same kernel computes the data gradient when given the flipped/transposed weights and pads swapped. */
 int a8_posconv_fwd(int dtype, const void* x, const void* w, const float* bias, void* y, void* z,
                    int B, int T, int d, int groups, int k, int pad_left, int add_residual, void* stream);
 /* dw f32 [G][dg_out][k][dg_in] += sum_{b,t} dz[b,t,co] x[b,t+kk-pad_left,ci] */
 int a8_posconv_wgrad(int dtype, const void* x, const void* dz, float* dw, int B, int T, int d, int groups, int k,
                      int pad_left, void* stream);
-/* dz = dy * gelu'(z); dbias[d] += sum rows dz */
+/* dz = dy * gelu'(z) (z NULL: dz = dy); dbias[cols] += column sums of dz.  dz and dbias may each be NULL. */
 int a8_gelu_bwd_bias(int dtype, const void* dy, const void* z, void* dz, float* dbias, int rows, int cols, void* stream);
 
 /* ---- multi-head self-attention core (eight_mile SeqScaledDotProductAttention) ----
@@ -133,21 +134,22 @@ int a8_vq_ppl(const float* avg_probs, float* ppl, float* dppl_davg, int V, void*
  *   straight-through soft path: d/dlogits of sum_v ysoft_v * <dq_g, vars_v>  (ysoft = softmax((logits+gumbel)/tau))
  * + diversity path: gppl * dppl/dlogits through avg_probs = mean softmax(logits). */
 int a8_vq_bwd(int dtype, const float* logits, const float* gumbel, float tau, const int32_t* codes, const float* vars,
-              const void* dq, const float* dppl_davg, const float* gppl, float* dlogits, float* dvars,
+              const void* dq, const float* eproj /* f32 [R,V]: <dq_g, vars[g,v,:]>, from a8_gemm */, const float* dppl_davg, const float* gppl, float* dlogits, float* dvars,
               int N, int G, int V, int D, int training, void* stream);
 
 /* ---- negatives gather + cosine + cross-entropy (Sampler.negatives + Wav2Vec2Loss, audio8/wav2vec2.py:371-392,955-976)
  * ctx dtype [B*Tm, C] (context at masked frames), lat dtype [B*Tm, C] (quantised latents), neg_idx i32 [B*Tm, N]
  * (row indices into lat).  logits f32 [B*Tm, N+1] (column 0 = positive), loss_sum f32[1] += sum_rows CE(row, 0). */
 int a8_contrastive_fwd(int dtype, const void* ctx, const void* lat, const int32_t* neg_idx, float* logits,
-                       float* loss_sum, int rows, int N, int C, void* stream);
+                       float* loss_sum, float* inv_norms /* scratch f32 [2*rows] */, int rows, int N, int C, void* stream);
 /* dctx, dlat f32 [rows, C] (dlat accumulated with atomics: zero it first); gscale multiplies d(loss_sum). */
 int a8_contrastive_bwd(int dtype, const void* ctx, const void* lat, const int32_t* neg_idx, const float* logits,
-                       const float* gscale, float* dctx, float* dlat, int rows, int N, int C, void* stream);
+                       const float* gscale, float* dctx, float* dlat, float* inv_norms /* scratch f32 [2*rows] */, int rows, int N, int C,
+                       void* stream);
 
 /* ---- CTC (F.ctc_loss native path, audio8/ctc.py:186-206) + log_softmax head (audio8/wav2vec2.py:770) ----
  * lp f32 [T,B,V] log-probs; targets i32 flat (PAD/EOS already stripped), tgt_off i32 [B+1]; nll f32 [B];
- * alpha is scratch f32 [B, T, 2*Smax+1]; grad f32 [T,B,V] = d nll_b / d lp (zero_infinity applied). */
+ * alpha is scratch f32 [B, T, 2*Smax+2]; grad f32 [T,B,V] = d nll_b / d lp (zero_infinity applied). */
 int a8_ctc_fwd_bwd(const float* lp, const int32_t* targets, const int32_t* tgt_off, const int32_t* in_len,
                    float* nll, float* grad, float* alpha, int T, int B, int V, int Smax, int blank, int zero_infinity,
                    void* stream);

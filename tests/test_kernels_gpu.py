@@ -1,0 +1,420 @@
+"""GPU parity of every HIP kernel (through the C ABI) against the CPU oracle / golden vectors."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2}
+
+
+def rnd(shape, seed, scale=1.0):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def close(got, ref, tol, what=""):
+    got = got.detach().float().cpu().numpy()
+    ref = ref.detach().float().cpu().numpy()
+    scale = max(1.0, float(np.abs(ref).max()))
+    np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * scale, err_msg=what)
+
+
+# ------------------------------------------------------------------ conv layer 0
+@pytest.mark.parametrize("dtype", DT)
+def test_conv0_gn_gelu(dtype):
+    from audio8_amd import kernels as K
+    B, L, C = 2, 4000, 512
+    x = rnd((B, L), 1, 0.1).clamp_(-1, 1)
+    w = rnd((C, 1, 10), 2, math.sqrt(2 / 10)).requires_grad_(True)
+    gw = (1 + 0.1 * rnd((C,), 3)).requires_grad_(True)
+    gb = (0.1 * rnd((C,), 4)).requires_grad_(True)
+    ref = F.gelu(F.group_norm(F.conv1d(x.unsqueeze(1), w, stride=5), C, gw, gb, 1e-5)).transpose(1, 2)   # [B,L0,C]
+    dout = rnd(tuple(ref.shape), 5)
+    ref.backward(dout)
+    d = "cuda"
+    out, stats = K.conv0_gn_gelu_fwd(x.to(d), w.detach().to(d), gw.detach().to(d), gb.detach().to(d), dtype)
+    close(out, ref, TOL[dtype], "conv0 fwd")
+    dw = torch.zeros((C, 1, 10), device=d)
+    dgw = torch.zeros((C,), device=d)
+    dgb = torch.zeros((C,), device=d)
+    K.conv0_gn_gelu_bwd(x.to(d), w.detach().to(d), gw.detach().to(d), gb.detach().to(d), stats, dout.to(dtype).to(d), dw, dgw, dgb)
+    tol = 2e-4 if dtype == torch.float32 else 3e-2
+    close(dw, w.grad, tol, "conv0 dw")
+    close(dgw, gw.grad, tol, "conv0 dgn_w")
+    close(dgb, gb.grad, tol, "conv0 dgn_b")
+
+
+def test_conv0_golden_g3(golden_dir):
+    """Layer 0 of the golden conv stack (reference's own ConvFeatureExtractionModel) in f32."""
+    from audio8_amd import kernels as K
+    from tools.gen_golden import conv_fixture_weights
+    from oracle import ref_cpu as R
+    g = np.load(os.path.join(golden_dir, "g3_conv.npz"))
+    ws, gn_w, gn_b = conv_fixture_weights(int(g["b_seed"]))
+    x = torch.from_numpy(g["b_x"])
+    sd = {f"feature_extractor.conv_layers.{i}.0.weight": torch.from_numpy(w) for i, w in enumerate(ws)}
+    sd["feature_extractor.conv_layers.0.2.weight"] = torch.from_numpy(gn_w)
+    sd["feature_extractor.conv_layers.0.2.bias"] = torch.from_numpy(gn_b)
+    ref0 = R.conv_feature_extractor(x, sd, return_all=True)[0].transpose(1, 2)
+    out, _ = K.conv0_gn_gelu_fwd(x.cuda(), torch.from_numpy(ws[0]).cuda(), torch.from_numpy(gn_w).cuda(), torch.from_numpy(gn_b).cuda(), torch.float32)
+    close(out, ref0, 2e-5)
+    st = g["b_layer_stats"][0]
+    np.testing.assert_allclose(out.double().mean().item(), st[0], rtol=1e-3, atol=1e-6)
+    np.testing.assert_allclose(out.double().abs().mean().item(), st[1], rtol=1e-4)
+
+
+# ------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cols", [512, 768, 1024])
+def test_layernorm_fwd_bwd(dtype, cols):
+    from audio8_amd import kernels as K
+    rows = 203
+    x = rnd((rows, cols), 1).to(dtype)
+    res = rnd((rows, cols), 2).to(dtype)
+    gm = (1 + 0.1 * rnd((cols,), 3)).requires_grad_(True)
+    bt = (0.1 * rnd((cols,), 4)).requires_grad_(True)
+    xs = x.float().requires_grad_(True)
+    rs = res.float().requires_grad_(True)
+    ref = F.layer_norm(xs + rs, (cols,), gm, bt, 1e-6)
+    dy, dy2 = rnd((rows, cols), 5).to(dtype), rnd((rows, cols), 6).to(dtype)
+    ref.backward(dy.float() + dy2.float())
+    d = "cuda"
+    y, mean, rstd = K.layernorm_fwd(x.to(d), res.to(d), gm.detach().to(d), bt.detach().to(d), 1e-6)
+    close(y, ref, TOL[dtype], "ln fwd")
+    dg, db = torch.zeros((cols,), device=d), torch.zeros((cols,), device=d)
+    dx, dres = K.layernorm_bwd(dy.to(d), dy2.to(d), x.to(d), res.to(d), gm.detach().to(d), mean, rstd, dg, db)
+    tol = 1e-4 if dtype == torch.float32 else 3e-2
+    close(dx, xs.grad, tol, "ln dx")
+    close(dres, rs.grad, tol, "ln dres")
+    close(dg, gm.grad, tol, "ln dgamma")
+    close(db, bt.grad, tol, "ln dbeta")
+
+
+def test_layernorm_fused_dropout_consistency():
+    from audio8_amd import kernels as K
+    rows, cols, p = 64, 768, 0.3
+    d = "cuda"
+    x, res = rnd((rows, cols), 1).to(d), rnd((rows, cols), 2).to(d)
+    gm, bt = torch.ones(cols, device=d), torch.zeros(cols, device=d)
+    xd = K.dropout(x, p, 77, 5)
+    keep = (xd != 0).float()
+    assert abs(keep.mean().item() - (1 - p)) < 0.02
+    close(xd, x * keep / (1 - p), 1e-6)
+    y1, m1, r1 = K.layernorm_fwd(x, res, gm, bt, 1e-5, p=p, seed=77, rng_stream=5)
+    y2, m2, r2 = K.layernorm_fwd(xd, res, gm, bt, 1e-5)
+    close(y1, y2, 1e-6)
+    dy = rnd((rows, cols), 3).to(d)
+    dg, db = torch.zeros(cols, device=d), torch.zeros(cols, device=d)
+    dx1, dres1 = K.layernorm_bwd(dy, None, x, res, gm, m1, r1, dg, db, p=p, seed=77, rng_stream=5)
+    dx2, dres2 = K.layernorm_bwd(dy, None, xd, res, gm, m2, r2, dg, db)
+    close(dres1, dres2, 1e-5)
+    close(dx1, dx2 * keep / (1 - p), 1e-5)
+
+
+# ------------------------------------------------------------------ element-wise
+@pytest.mark.parametrize("dtype", DT)
+def test_elementwise(dtype):
+    from audio8_amd import kernels as K
+    d = "cuda"
+    rows, cols = 98, 768
+    x = rnd((rows, cols), 1).to(dtype)
+    mask = torch.zeros(rows, dtype=torch.uint8)
+    mask[torch.randperm(rows, generator=torch.Generator().manual_seed(0))[:40]] = 1
+    emb = rnd((cols,), 2)
+    ref = torch.where(mask.bool().unsqueeze(1), emb.to(dtype).unsqueeze(0), x)
+    got = K.mask_fill_rows_(x.clone().to(d), mask.to(d), emb.to(d))
+    assert torch.equal(got.cpu(), ref)
+    dy = rnd((rows, cols), 3).to(dtype)
+    demb = torch.zeros(cols, device=d)
+    dyo = K.mask_fill_rows_bwd_(dy.clone().to(d), mask.to(d), demb)
+    close(demb, dy.float()[mask.bool()].sum(0), 1e-5 if dtype == torch.float32 else 1e-2)
+    assert torch.equal(dyo.cpu(), torch.where(mask.bool().unsqueeze(1), torch.zeros_like(dy), dy))
+    idx = torch.nonzero(mask).flatten().int()
+    gat = K.gather_rows(x.to(d), idx.to(d))
+    assert torch.equal(gat.cpu(), x[idx.long()])
+    dst = torch.zeros((rows, cols), dtype=dtype, device=d)
+    K.scatter_add_rows_(dst, idx.to(d), gat)
+    assert torch.equal(dst.cpu(), torch.where(mask.bool().unsqueeze(1), x, torch.zeros_like(x)))
+    close(K.add(x.to(d), dy.to(d)), (x.float() + dy.float()).to(dtype), 1e-6)
+    close(K.cast(x.to(d), torch.float32), x.float(), 0)
+    z = rnd((rows, cols), 4).to(dtype)
+    zz = z.float().requires_grad_(True)
+    F.gelu(zz).backward(dy.float())
+    db = torch.zeros(cols, device=d)
+    dz = K.gelu_bwd_bias(dy.to(d), z.to(d), db)
+    close(dz, zz.grad, TOL[dtype])
+    close(db, zz.grad.sum(0), 1e-4 if dtype == torch.float32 else 3e-2)
+    keep = (torch.arange(rows) % 3 != 0).to(torch.uint8)
+    zr = K.zero_rows_(x.clone().to(d), keep.to(d))
+    assert torch.equal(zr.cpu(), x * keep.bool().unsqueeze(1))
+    cm = (torch.arange(2 * cols).reshape(2, cols) % 5 == 0).to(torch.uint8)
+    x3 = x[:96].reshape(2, 48, cols)
+    zc = K.mask_zero_cols_(x3.clone().to(d), cm.to(d))
+    assert torch.equal(zc.cpu(), x3.masked_fill(cm.bool().unsqueeze(1), 0))
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("k", [3, 2])
+def test_col2im_gelu_grad(dtype, k):
+    from audio8_amd import kernels as K
+    B, Lin, C, s = 2, 38, 64, 2
+    Lout = (Lin - k) // s + 1
+    dcol = rnd((B * Lout, k * C), 1).to(dtype)
+    z = rnd((B, Lin, C), 2).to(dtype)
+    ref = torch.zeros(B, Lin, C)
+    dc = dcol.float().view(B, Lout, k, C)
+    for t in range(Lout):
+        for kk in range(k):
+            ref[:, t * s + kk] += dc[:, t, kk]
+    zz = z.float().requires_grad_(True)
+    F.gelu(zz).sum().backward()
+    got = K.col2im_gelu_grad(dcol.cuda(), z.cuda(), B, Lin, Lout, C, k, s)
+    close(got, ref * zz.grad, TOL[dtype])
+
+
+# ------------------------------------------------------------------ positional conv
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("dm,T", [(768, 100), (1024, 300)])
+def test_posconv(dtype, dm, T):
+    from audio8_amd import kernels as K
+    from oracle import ref_cpu as R
+    B, G, k = 2, 16, 128
+    dg = dm // G
+    x = rnd((B, T, dm), 1).to(dtype)
+    v = rnd((dm, dg, k), 2, 0.02)
+    gnorm = v.norm(2, dim=(0, 1), keepdim=True) * (1 + 0.1 * rnd((1, 1, k), 3))
+    bias = 0.1 * rnd((dm,), 4)
+    w = R.weight_norm_dim2(gnorm, v).to(dtype).float().requires_grad_(True)     # [dm, dg, k]
+    xs = x.float().requires_grad_(True)
+    zref = F.conv1d(F.pad(xs.transpose(1, 2), (63, 64)), w, bias, groups=G).transpose(1, 2)
+    yref = xs + F.gelu(zref)
+    dy = rnd((B, T, dm), 5).to(dtype)
+    d = "cuda"
+    # kernel weight layout [G][co][kk][ci]
+    wk = w.detach().view(G, dg, dg, k).permute(0, 1, 3, 2).contiguous().to(dtype).to(d)
+    y, z = K.posconv_fwd(x.to(d), wk, bias.to(d), G, k, 63, 1, want_z=True)
+    tol = 1e-4 if dtype == torch.float32 else 3e-2
+    close(z, zref, tol, "posconv z")
+    close(y, yref, tol, "posconv y")
+    # backward through the conv only: dz -> dx (dgrad mode) and dw
+    dz = rnd((B, T, dm), 6).to(dtype)
+    zref.backward(dz.float())
+    wt = w.detach().view(G, dg, dg, k).flip(3).permute(0, 2, 3, 1).contiguous().to(dtype).to(d)   # [G][ci][kk'][co]
+    dx, _ = K.posconv_fwd(dz.to(d), wt, None, G, k, k - 1 - 63, -1)
+    close(dx, xs.grad, tol, "posconv dgrad")
+    dw = torch.zeros((G, dg, k, dg), device=d)
+    K.posconv_wgrad(x.to(d), dz.to(d), dw, G, k, 63)
+    dw_ref = w.grad.view(G, dg, dg, k).permute(0, 1, 3, 2)
+    close(dw, dw_ref, 2e-4 if dtype == torch.float32 else 3e-2, "posconv wgrad")
+
+
+# ------------------------------------------------------------------ attention
+def _attn_ref(q, k, v, keymask, scale, drop_keep=None, p=0.0):
+    s = torch.matmul(q, k.transpose(-2, -1)) * scale
+    if keymask is not None:
+        s = s.masked_fill(keymask[:, None, None, :] == 0, -1e9)
+    a = s.softmax(-1)
+    if drop_keep is not None:
+        a = a * drop_keep / (1 - p)
+    return torch.matmul(a, v)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("T,use_mask", [(64, False), (100, True), (333, False)])
+def test_attention_fwd_bwd(dtype, T, use_mask):
+    from audio8_amd import kernels as K
+    B, H = 2, 3
+    d = H * 64
+    qkv = rnd((B * T, 3 * d), 1).to(dtype)
+    dout = rnd((B * T, d), 2).to(dtype)
+    keymask = None
+    if use_mask:
+        keymask = torch.ones(B, T, dtype=torch.uint8)
+        keymask[0, 70:] = 0
+        keymask[1, 90:] = 0
+    f = qkv.float().view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)        # [3,B,H,T,64]
+    q, k, v = (f[i].clone().requires_grad_(True) for i in range(3))
+    scale = 1 / 8.0
+    oref = _attn_ref(q, k, v, keymask, scale)                           # [B,H,T,64]
+    oref.backward(dout.float().view(B, T, H, 64).permute(0, 2, 1, 3))
+    dev = "cuda"
+    g = qkv.to(dev)
+    km = keymask.to(dev) if use_mask else None
+    o, lse = K.attn_fwd(g[:, :d], g[:, d:2 * d], g[:, 2 * d:], B, T, H, 3 * d, scale, km)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    close(o.view(B, T, H, 64), oref.permute(0, 2, 1, 3), tol, "attn o")
+    dq, dk, dv, _ = K.attn_bwd(g[:, :d], g[:, d:2 * d], g[:, 2 * d:], o, dout.to(dev), lse, B, T, H, 3 * d, scale, km)
+    tolb = 1e-4 if dtype == torch.float32 else 3e-2
+    close(dq.reshape(B, T, H, 64), q.grad.permute(0, 2, 1, 3), tolb, "attn dq")
+    close(dk.reshape(B, T, H, 64), k.grad.permute(0, 2, 1, 3), tolb, "attn dk")
+    close(dv.reshape(B, T, H, 64), v.grad.permute(0, 2, 1, 3), tolb, "attn dv")
+
+
+def test_attention_dropout_mask_consistency():
+    """Extract the kernel's keep-mask (q = k = 0 -> uniform P; V = I), then check fwd/bwd against a
+    reference that applies exactly that mask."""
+    from audio8_amd import kernels as K
+    B, H, T, p, seed = 1, 2, 64, 0.25, 1234
+    d = H * 64
+    dev = "cuda"
+    z = torch.zeros((B * T, d), device=dev)
+    eye = torch.eye(64, device=dev).repeat(1, H)                         # V[key][h*64 + c] = (key == c)
+    o, _ = K.attn_fwd(z, z, eye, B, T, H, d, 0.125, None, p=p, seed=seed)
+    keep = (o.view(T, H, 64).permute(1, 0, 2) > 0).float().cpu()        # [H, q, key]
+    assert abs(keep.mean().item() - (1 - p)) < 0.03
+    np.testing.assert_allclose(o.view(T, H, 64)[o.view(T, H, 64) > 0].cpu().numpy(), 1 / 64 / (1 - p), rtol=1e-5)
+    qkv = rnd((B * T, 3 * d), 3)
+    dout = rnd((B * T, d), 4)
+    f = qkv.view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    q, k, v = (f[i].clone().requires_grad_(True) for i in range(3))
+    oref = _attn_ref(q, k, v, None, 0.125, keep.unsqueeze(0), p)
+    oref.backward(dout.view(B, T, H, 64).permute(0, 2, 1, 3))
+    g = qkv.to(dev)
+    o, lse = K.attn_fwd(g[:, :d], g[:, d:2 * d], g[:, 2 * d:], B, T, H, 3 * d, 0.125, None, p=p, seed=seed)
+    close(o.view(B, T, H, 64), oref.permute(0, 2, 1, 3), 2e-5)
+    dq, dk, dv, _ = K.attn_bwd(g[:, :d], g[:, d:2 * d], g[:, 2 * d:], o, dout.to(dev), lse, B, T, H, 3 * d, 0.125, None, p=p, seed=seed)
+    close(dq.reshape(B, T, H, 64), q.grad.permute(0, 2, 1, 3), 1e-4)
+    close(dk.reshape(B, T, H, 64), k.grad.permute(0, 2, 1, 3), 1e-4)
+    close(dv.reshape(B, T, H, 64), v.grad.permute(0, 2, 1, 3), 1e-4)
+
+
+# ------------------------------------------------------------------ VQ (golden G4)
+def test_vq_against_golden(golden_dir):
+    from audio8_amd import kernels as K, _lib as L
+    g = np.load(os.path.join(golden_dir, "g4_vq.npz"))
+    d = "cuda"
+    B, Tm, Cin = g["y"].shape
+    G, V, D = 2, 320, 128
+    N = B * Tm
+    y = torch.from_numpy(g["y"]).view(N, Cin).to(d)
+    wp, bp = torch.from_numpy(g["wp"]).to(d), torch.from_numpy(g["bp"]).to(d)
+    vars2d = torch.from_numpy(g["vars"]).view(G * V, D).to(d)
+    logits = K.gemm(L.NT, y, wp, N, G * V, Cin, bias=bp, out_dtype=torch.float32).view(N * G, V)
+    # eval: argmax
+    codes, avg = K.vq_select(logits, None, 0.5)
+    q = K.vq_gather(vars2d, codes, N, G, V, D, torch.float32)
+    ppl, dppl = K.vq_ppl(avg)
+    close(q.view(B, Tm, G * D), torch.from_numpy(g["eval_q"]), 1e-6)
+    np.testing.assert_allclose(ppl.item(), g["eval_ppl"], rtol=1e-5)
+    # train: injected gumbel noise
+    gum = torch.from_numpy(g["gumbel"]).to(d)
+    codes, avg = K.vq_select(logits, gum, 0.5)
+    q = K.vq_gather(vars2d, codes, N, G, V, D, torch.float32)
+    ppl, dppl = K.vq_ppl(avg)
+    close(q.view(B, Tm, G * D), torch.from_numpy(g["train_q"]), 1e-6)
+    np.testing.assert_allclose(ppl.item(), g["train_ppl"], rtol=1e-5)
+    # backward of sum(q * gq): no diversity term
+    gq = torch.from_numpy(g["train_gq"]).view(N, G * D).to(d)
+    eproj = torch.empty((N * G, V), device=d)
+    for gi in range(G):
+        K.gemm(L.NT, gq[:, gi * D:], vars2d[gi * V:], N, V, D, lda=G * D, out=eproj.view(N, G * V)[:, gi * V:], ldc=G * V)
+    dvars = torch.zeros_like(vars2d)
+    zero = torch.zeros(1, device=d)
+    dlogits = K.vq_bwd(logits, gum, 0.5, codes, vars2d, gq, eproj, dppl, zero, dvars, N, G, V, D, True)
+    close(dvars.view(1, G * V, D), torch.from_numpy(g["train_gvars"]), 1e-5)
+    dl = dlogits.view(N, G * V)
+    gwp = K.gemm(L.TN, dl, y, G * V, Cin, N, out_dtype=torch.float32)
+    gy = K.gemm(L.NN, dl, wp, N, Cin, G * V)
+    close(gwp, torch.from_numpy(g["train_gwp"]), 1e-4)
+    close(dl.sum(0), torch.from_numpy(g["train_gbp"]), 1e-4)
+    close(gy.view(B, Tm, Cin), torch.from_numpy(g["train_gy"]), 1e-4)
+    # gradient of prob_ppl alone (diversity path)
+    one = torch.ones(1, device=d)
+    dvars2 = torch.zeros_like(vars2d)
+    dl2 = K.vq_bwd(logits, gum, 0.5, codes, vars2d, torch.zeros_like(gq), torch.zeros_like(eproj), dppl, one, dvars2, N, G, V, D, True)
+    gy2 = K.gemm(L.NN, dl2.view(N, G * V), wp, N, Cin, G * V)
+    close(gy2.view(B, Tm, Cin), torch.from_numpy(g["ppl_gy"]), 1e-4)
+
+
+# ------------------------------------------------------------------ contrastive (golden G5)
+@pytest.mark.parametrize("dtype", DT)
+def test_contrastive_against_golden(golden_dir, dtype):
+    from audio8_amd import kernels as K
+    g = np.load(os.path.join(golden_dir, "g5_loss.npz"))
+    d = "cuda"
+    mask = torch.from_numpy(g["mask"])
+    outputs = torch.from_numpy(g["outputs"])
+    B, T, C = outputs.shape
+    ctx = outputs[mask.unsqueeze(-1).expand_as(outputs)].view(-1, C)          # [B*Tm, C], b-major
+    lat = torch.from_numpy(g["latents"]).view(-1, C)
+    Tm = lat.shape[0] // B
+    idx = torch.from_numpy(g["idx"]).view(B, Tm, -1).reshape(B * Tm, -1).int()   # [B, N*Tm] is (t, n) row-major per b
+    N = idx.shape[1]
+    logits, loss_sum = K.contrastive_fwd(ctx.to(dtype).to(d), lat.to(dtype).to(d), idx.to(d))
+    ref_logits = torch.from_numpy(g["logits"]).view(Tm, B, N + 1).transpose(0, 1).reshape(B * Tm, N + 1)   # reference rows are t*B + b
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    close(logits, ref_logits, tol, "cosine logits")
+    xe = loss_sum.item() / (B * Tm)
+    loss = 0.1 * xe + 10 * (640 - float(g["gs"])) / 640
+    np.testing.assert_allclose(loss, float(g["loss"]), rtol=1e-5 if dtype == torch.float32 else 5e-3)
+    gscale = torch.full((1,), 0.1 / (B * Tm), device=d)
+    dctx, dlat = K.contrastive_bwd(ctx.to(dtype).to(d), lat.to(dtype).to(d), idx.to(d), logits, gscale)
+    g_out = torch.from_numpy(g["g_outputs"])
+    ref_dctx = g_out[mask.unsqueeze(-1).expand_as(g_out)].view(-1, C)
+    tolb = 1e-4 if dtype == torch.float32 else 3e-2
+    close(dctx, ref_dctx, tolb, "dctx")
+    close(dlat, torch.from_numpy(g["g_latents"]).view(-1, C), tolb, "dlat")
+
+
+# ------------------------------------------------------------------ CTC (golden G6 + f64 oracle)
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_ctc_against_golden_and_oracle(golden_dir, tag):
+    from audio8_amd import kernels as K
+    from oracle import ref_cpu as R
+    g = np.load(os.path.join(golden_dir, "g6_ctc.npz"))
+    lp = torch.from_numpy(g[f"{tag}_lp"])
+    il, tl, targets = g[f"{tag}_il"], g[f"{tag}_tl"], g[f"{tag}_targets"]
+    flat = R.ctc_strip_targets(targets).astype(np.int32)
+    off = np.concatenate([[0], np.cumsum(tl)]).astype(np.int32)
+    d = "cuda"
+    nll, grad = K.ctc_fwd_bwd(lp.to(d), torch.from_numpy(flat).to(d), torch.from_numpy(off).to(d), torch.from_numpy(il.astype(np.int32)).to(d),
+                              int(tl.max()))
+    want_nll, want_grad = R.ctc_loss_np(g[f"{tag}_lp"], il, targets, tl, reduction="none")
+    np.testing.assert_allclose(nll.cpu().numpy(), want_nll, rtol=2e-5)
+    np.testing.assert_allclose(grad.cpu().numpy(), want_grad, rtol=1e-3, atol=2e-5)     # vs the f64 oracle
+    np.testing.assert_allclose(nll.sum().item(), g[f"{tag}_sum_loss"], rtol=2e-5)        # vs the reference (ATen f32)
+    atol = 1e-5 if tag == "a" else 2.5e-3   # the golden's own f32 log-space noise at T=624, see test_oracle_golden
+    np.testing.assert_allclose(grad.cpu().numpy(), g[f"{tag}_sum_grad"], rtol=1e-3, atol=atol)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_log_softmax(dtype):
+    from audio8_amd import kernels as K
+    x = rnd((300, 32), 1, 3.0).to(dtype)
+    xs = x.float().requires_grad_(True)
+    ref = F.log_softmax(xs, -1)
+    dy = rnd((300, 32), 2)
+    ref.backward(dy)
+    y = K.log_softmax_fwd(x.cuda())
+    close(y, ref, 1e-5)
+    dx = K.log_softmax_bwd(y, dy.cuda(), dtype)
+    close(dx, xs.grad, TOL[dtype])
+
+
+# ------------------------------------------------------------------ optimizer
+def test_sumsq_adamw_matches_torch():
+    from audio8_amd import kernels as K
+    n = 100003
+    p0 = rnd((n + 1,), 1)[:n]
+    p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([p], lr=2e-4, weight_decay=1e-2)
+    d = "cuda"
+    flat = torch.zeros(n + 5, device=d)[:n]
+    flat.copy_(p0)
+    m, v = torch.zeros(n, device=d), torch.zeros(n, device=d)
+    for step in range(1, 4):
+        gr = rnd((n,), 10 + step, 0.05)
+        p.grad = gr.clone()
+        torch.nn.utils.clip_grad_norm_([p], 1.0)
+        opt.step()
+        gsq = torch.zeros(1, device=d)
+        gd = gr.to(d)
+        K.sumsq_(gd, gsq)
+        np.testing.assert_allclose(gsq.item(), (gr.double() ** 2).sum().item(), rtol=1e-5)
+        K.adamw_(flat, gd, m, v, 2e-4, 0.9, 0.999, 1e-8, 1e-2, step, gsq, 1.0)
+        close(flat, p.data, 2e-6)
