@@ -1,0 +1,90 @@
+"""MI355X-native mirror of audio8/ctc.py: CTCLoss (audio8/ctc.py:186-206) on the wave-per-utterance
+HIP kernel, and the greedy-decode metrics (audio8/ctc.py:139-183, 63-72) with an own Levenshtein
+(the reference imports the third-party `editdistance`).  The prefix-beam/LM decoder
+(audio8/ctc.py:11-60) wraps the third-party `ctcdecode` and is out of scope."""
+import numpy as np
+import torch
+import torch.nn
+
+from . import ops
+
+
+class Offsets:
+    """eight_mile.utils.Offsets as audio8/train.py:20-27 configures it."""
+    GO, PAD, EOS, UNK = 0, 1, 2, 3
+    VALUES = ['<s>', '<pad>', '</s>', '<unk>']
+
+
+def postproc_letters(sentence):
+    return ''.join(sentence).replace(" ", "").replace("|", " ").strip()
+
+
+def postproc_bpe(sentence):
+    return ' '.join(sentence).replace("@@ ", "").strip()
+
+
+def edit_distance(a, b) -> int:
+    """Levenshtein distance between two sequences (== editdistance.eval)."""
+    a, b = list(a), list(b)
+    if len(a) < len(b):
+        a, b = b, a
+    prev = list(range(len(b) + 1))
+    for i, ca in enumerate(a, 1):
+        cur = [i] + [0] * len(b)
+        for j, cb in enumerate(b, 1):
+            cur[j] = min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb))
+        prev = cur
+    return prev[-1]
+
+
+def ctc_metrics(lprobs_t, target, input_lengths, index2vocab, postproc_fn=postproc_letters):
+    """Greedy CTC decode + CER/WER counts.  Keeps the reference's quirk of slicing frames by the
+    *sample* length (audio8/ctc.py:156 with audio8/train.py:47)."""
+    BLANK_IDX = Offsets.GO
+    c_err = c_len = w_errs = w_len = wv_errs = 0
+    with torch.no_grad():
+        for lp, t, inp_l in zip(lprobs_t, target, input_lengths):
+            lp = lp[:inp_l].unsqueeze(0)
+            p = (t != Offsets.PAD) & (t != Offsets.EOS)
+            targ = t[p]
+            targ_units_arr = targ.tolist()
+            toks = lp.argmax(dim=-1).unique_consecutive()
+            pred_units_arr = toks[toks != BLANK_IDX].tolist()
+            c_err += edit_distance(pred_units_arr, targ_units_arr)
+            c_len += len(targ_units_arr)
+            targ_words = postproc_fn([index2vocab[x] for x in targ_units_arr]).split()
+            pred_words_raw = postproc_fn([index2vocab[x] for x in pred_units_arr]).split()
+            dist = edit_distance(pred_words_raw, targ_words)
+            w_errs += dist
+            wv_errs += dist
+            w_len += len(targ_words)
+    return {"wv_errors": wv_errs, "w_errors": w_errs, "w_total": w_len, "c_errors": c_err, "c_total": c_len}
+
+
+class CTCLoss(torch.nn.Module):
+    """forward(log_prob [T,B,V], input_lengths [B], targets int [B,S] padded with PAD/EOS, target_lengths [B])."""
+
+    def __init__(self, zero_infinity=True, reduction_type="sum"):
+        super().__init__()
+        if reduction_type not in ("sum", "mean", "none"):
+            raise ValueError(f"unknown reduction {reduction_type}")
+        self.zero_infinity = zero_infinity
+        self.reduction_type = reduction_type
+
+    def forward(self, log_prob, input_lengths, targets, target_lengths):
+        dev = log_prob.device
+        t = targets.detach().cpu().numpy()
+        flat = t[(t != Offsets.PAD) & (t != Offsets.EOS)]                      # audio8/ctc.py:193-194
+        tl = np.asarray(target_lengths.detach().cpu().numpy() if torch.is_tensor(target_lengths) else target_lengths).astype(np.int64)
+        if int(tl.sum()) != flat.size:
+            raise RuntimeError("CTCLoss: sum(target_lengths) does not match the number of non-PAD/EOS targets")
+        off = np.concatenate([[0], np.cumsum(tl)])
+        in_len = input_lengths.to(device=dev, dtype=torch.int32) if torch.is_tensor(input_lengths) else ops.host_i32(input_lengths, dev)
+        nll = ops.CTCFn.apply(log_prob, ops.host_i32(flat, dev), ops.host_i32(off, dev), in_len.contiguous(),
+                              int(max(1, tl.max() if tl.size else 1)), Offsets.GO, self.zero_infinity)
+        if self.reduction_type == "sum":
+            return nll.sum()
+        if self.reduction_type == "mean":                                     # ATen: mean over batch of nll / clamp(target_len, 1)
+            denom = torch.from_numpy(np.maximum(tl, 1)).to(device=dev, dtype=nll.dtype)
+            return (nll / denom).mean()
+        return nll

@@ -172,7 +172,7 @@ def audio_transformer_encoder(x, sd, num_layers, num_heads, pad_mask=None, prefi
         # eight_mile TransformerEncoderStack draws np.random.random() per layer per forward
         # for layer-drop (recalled; advances the numpy RNG that a8 later consumes).
         pdraw = np.random.random() if layerdrop_rng_draws else 1.0
-        if training and layer_drop > 0 and pdraw <= layer_drop:
+        if training and pdraw < layer_drop:
             continue
         x = encoder_layer(x, sd, f"{prefix}transformer.encoders.{i}.", num_heads, mask, ln_eps, pdrop, training)
     return x

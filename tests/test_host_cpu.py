@@ -1,0 +1,113 @@
+"""CPU-side checks: the C-ABI library loads and exports every declared symbol, the host model
+exposes the reference's state_dict keys, host samplers are bit-exact against the golden vectors,
+and the product path refuses to run without a GPU (no silent fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from audio8_amd import _lib as L
+    lib = L.lib()
+    hdr = open(os.path.join(ROOT, "include", "a8hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(a8_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared, "no declarations found"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/a8hip.h but not exported"
+    assert sorted(L.EXPORTS) == declared
+    assert lib.a8_version() == 100
+
+
+def test_state_dict_keys_match_reference_names():
+    from audio8_amd import wav2vec2 as W
+    from oracle import ref_cpu as R
+    m = W.create_model(num_layers=2)
+    want = R.init_state_dict(num_layers=2)
+    got = m.state_dict()
+    assert set(got.keys()) == set(want.keys())
+    for k in want:
+        assert tuple(got[k].shape) == tuple(want[k].shape), k
+    assert sum(p.numel() for p in m.feature_extractor.parameters()) == 4200448
+    a = W.create_acoustic_model(32, num_layers=1)
+    wantc = R.init_state_dict(num_layers=1, ctc_labels=32)
+    assert set(a.state_dict().keys()) == set(wantc.keys())
+    assert a.freeze is True and hasattr(a, "proj") and hasattr(a, "encoder")
+    full = W.create_model()
+    assert sum(p.numel() for p in full.parameters()) == 95044608      # wav2vec2-base, SURVEY 2.2 C1 ("~95.0 M")
+
+
+def test_fairseq_key_maps_cover_model():
+    from audio8_amd import wav2vec2 as W
+    m = W.create_model(num_layers=2)
+    sd = m.state_dict()
+    fake = {}
+    for i in range(2):
+        for k, v in W.W2V_NESTED_MAP.items():
+            fake[k.format(i)] = sd[v.format(i)].clone()
+    for k, v in W.W2V2_FLAT_MAP.items():
+        fake[k] = sd[v].clone()
+    mapped = W.convert_keys(2, dict(fake), W.W2V_MAP.nested, W.W2V_MAP.flat)
+    assert set(mapped.keys()) <= set(sd.keys())
+    res = m.load_state_dict(mapped, strict=False)
+    assert not res.unexpected_keys
+    a = W.create_acoustic_model(32, num_layers=1)
+    sda = a.state_dict()
+    for k, v in list(W.W2V_CTC_MAP[16].nested.items()):
+        assert v.format(0) in sda, v
+    for k, v in W.W2V_CTC_MAP[16].flat.items():
+        assert v in sda, v
+    assert len(W.W2V2_CTC_FLAT_MAP_8) == len(W.W2V2_CTC_FLAT_MAP_16) - 1
+
+
+def test_host_samplers_match_golden(golden_dir):
+    from audio8_amd import wav2vec2 as W
+    g = np.load(os.path.join(golden_dir, "g1_masks.npz"))
+    for key in g["keys"]:
+        key = str(key)
+        seed = int(key.split("_")[0][1:])
+        B, T = (int(v) for v in g[key + "_shape"])
+        p = int(key.split("_p")[1].split("_")[0]) / 100.0
+        ml = int(key.split("_l")[1])
+        np.random.seed(seed)
+        m = W.create_mask((B, T), p, ml)
+        assert np.array_equal(m, np.unpackbits(g[key])[: B * T].reshape(B, T).astype(bool)), key
+        assert np.random.rand() == float(g[key + "_tail"])
+    g2 = np.load(os.path.join(golden_dir, "g2_negatives.npz"))
+    for key in g2["keys"]:
+        key = str(key)
+        seed = int(key.split("_")[0][1:])
+        B = int(key.split("_b")[1].split("_")[0]); Tm = int(key.split("_t")[1].split("_")[0]); N = int(key.split("_n")[1])
+        np.random.seed(seed)
+        assert np.array_equal(W.Sampler(N).indices(B, Tm), g2[key].astype(np.int64)), key
+
+
+def test_quantizer_temperature_quirk():
+    from audio8_amd import wav2vec2 as W
+    m = W.create_model(num_layers=1)
+    assert m.quantizer.curr_temperature == 0.5
+    m.set_num_updates(1000)
+    assert m.quantizer.curr_temperature == 2
+
+
+def test_product_path_has_no_cpu_fallback():
+    from audio8_amd import wav2vec2 as W
+    m = W.create_model(num_layers=1)
+    with pytest.raises(RuntimeError, match="GPU|cuda|CUDA"):
+        m(torch.zeros(1, 4000))
+
+
+def test_ctc_metrics_and_edit_distance():
+    from audio8_amd import ctc as Cc
+    vocab = {0: '<s>', 1: '<pad>', 2: '</s>', 3: '<unk>', 4: '|', 5: 'a', 6: 'b', 7: 'c'}
+    seq = [5, 5, 0, 5, 4, 6, 6, 7]
+    lp = torch.full((1, len(seq), 8), -10.0)
+    for t, s in enumerate(seq):
+        lp[0, t, s] = 0.0
+    tgt = torch.tensor([[5, 5, 4, 6, 6, 2, 1, 1]])
+    assert Cc.ctc_metrics(lp, tgt, [10 ** 6], vocab) == dict(wv_errors=1, w_errors=1, w_total=2, c_errors=1, c_total=5)
+    assert Cc.edit_distance("kitten", "sitting") == 3 and Cc.edit_distance([], [1, 2]) == 2

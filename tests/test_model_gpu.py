@@ -1,0 +1,203 @@
+"""End-to-end GPU parity of the host model (audio8_amd.wav2vec2 / audio8_amd.ctc over the C ABI) against
+the CPU oracle on the same seeded inputs: loss, logits, sampled indices and every parameter gradient."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def synth(B, L, seed=1234):
+    g = torch.Generator().manual_seed(seed)
+    return (0.1 * torch.randn(B, L, generator=g)).clamp_(-1, 1)
+
+
+def rel_err(a, b):
+    """||a-b|| / ||b||, with an absolute floor of 1e-7 per element: gradients that are identically zero in
+    exact arithmetic (e.g. the key-projection bias: softmax is invariant to a constant key offset) are pure
+    rounding noise on both sides."""
+    a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)
+    return float((a - b).norm() / (b.norm() + 1e-7 * (b.numel() ** 0.5)))
+
+
+def cosine(a, b):
+    a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)
+    return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+
+@pytest.fixture
+def restore_dtype():
+    from audio8_amd import ops
+    old = ops.compute_dtype()
+    yield
+    ops.set_compute_dtype(old)
+
+
+def _pretrain_pair(dtype, num_layers=2, B=2, L=16000, seed=0):
+    from audio8_amd import ops, wav2vec2 as W
+    from oracle import ref_cpu as R
+    ops.set_compute_dtype(dtype)
+    sd = R.init_state_dict(seed=seed, num_layers=num_layers)
+    x = synth(B, L)
+    T = R.conv_out_lengths(L)[-1]
+    np.random.seed(seed)
+    Tm = int(R.create_mask((B, T), 0.65, 10)[0].sum())
+    gum = -torch.empty(B * Tm * 2, 320).exponential_(generator=torch.Generator().manual_seed(5)).log()
+    # oracle
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    np.random.seed(seed)
+    loss_ref, aux = R.pretrain_loss(x, sdg, num_layers=num_layers, training=True, gumbel=gum)
+    loss_ref.backward()
+    # product
+    model = W.create_model(num_layers=num_layers, dropout=0.0, dropout_input=0.0, dropout_features=0.0)
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().train()
+    model.quantizer.gumbel_override = gum.cuda()
+    loss_fn = W.create_loss(640, 100)
+    np.random.seed(seed)
+    loss = loss_fn(model, x.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    return model, loss, loss_fn, sdg, loss_ref, aux
+
+
+def test_pretrain_step_parity_f32(restore_dtype):
+    """north_star tolerance: bit-exact mask/negative indices for a fixed seed; f32 logits/loss within 1e-4 rtol."""
+    from oracle import ref_cpu as R
+    model, loss, loss_fn, sdg, loss_ref, aux = _pretrain_pair(torch.float32)
+    np.testing.assert_allclose(loss.item(), loss_ref.item(), rtol=1e-4)
+    # logits: product rows are (b, t), oracle rows are (t, b)
+    B, Tm = aux["q"].shape[:2]
+    om = aux["ctx"][torch.from_numpy(aux["time_mask"]).unsqueeze(-1).expand_as(aux["ctx"])].view(B, Tm, -1)
+    ref_logits = R.contrastive_logits(om, aux["q"], torch.from_numpy(aux["neg_idx"])).view(Tm, B, -1).transpose(0, 1).reshape(B * Tm, -1)
+    np.testing.assert_allclose(loss_fn.last_logits.cpu().numpy(), ref_logits.detach().numpy(), rtol=1e-4, atol=1e-5)
+    got = dict(model.named_parameters())
+    worst = 0.0
+    for k, ref in sdg.items():
+        assert got[k].grad is not None, k
+        e = rel_err(got[k].grad, ref.grad)
+        worst = max(worst, e)
+        assert e < 2e-3, f"{k}: rel grad err {e}"
+    print("worst relative gradient error (f32):", worst)
+
+
+def test_pretrain_step_parity_bf16(restore_dtype):
+    """Throughput mode (bf16 activations, f32 accumulate/statistics): stated, looser tolerance."""
+    model, loss, loss_fn, sdg, loss_ref, aux = _pretrain_pair(torch.bfloat16)
+    np.testing.assert_allclose(loss.item(), loss_ref.item(), rtol=3e-2)
+    got = dict(model.named_parameters())
+    for k in ("encoder.transformer.encoders.0.ffn.0.layer.weight", "encoder.transformer.encoders.1.self_attn.w_Q.layer.weight",
+              "feature_extractor.conv_layers.3.0.weight", "proj_to_input.layer.weight", "final_proj.layer.weight"):
+        c = cosine(got[k].grad, sdg[k].grad)
+        assert c > 0.97, f"{k}: gradient cosine {c}"
+
+
+def test_eval_mode_forward_f32(restore_dtype):
+    """eval(): masking still happens (no training guard, audio8/wav2vec2.py:937), quantizer takes the argmax path."""
+    from audio8_amd import ops, wav2vec2 as W
+    from oracle import ref_cpu as R
+    ops.set_compute_dtype(torch.float32)
+    sd = R.init_state_dict(seed=3, num_layers=1)
+    x = synth(2, 16000, 7)
+    np.random.seed(11)
+    loss_ref, aux = R.pretrain_loss(x, sd, num_layers=1, training=False)
+    model = W.create_model(num_layers=1)
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    np.random.seed(11)
+    with torch.no_grad():
+        loss = W.create_loss(640, 100)(model, x.cuda())
+    np.testing.assert_allclose(loss.item(), loss_ref.item(), rtol=1e-4)
+
+
+def test_training_step_with_dropout_runs_and_is_deterministic(restore_dtype):
+    from audio8_amd import ops, wav2vec2 as W
+    ops.set_compute_dtype(torch.bfloat16)
+    torch.manual_seed(0)
+    model = W.create_model(num_layers=2).cuda().train()
+    loss_fn = W.create_loss(640, 100)
+    x = synth(2, 16000).cuda()
+    vals = []
+    for _ in range(2):
+        torch.manual_seed(1)
+        ops.reset_seed_stream()
+        np.random.seed(2)
+        model.zero_grad()
+        loss = loss_fn(model, x)
+        loss.backward()
+        vals.append((loss.item(), model.final_proj.layer.weight.grad.float().norm().item()))
+    assert np.isfinite(vals[0][0]) and vals[0][1] > 0
+    np.testing.assert_allclose(vals[0][0], vals[1][0], rtol=1e-4)
+
+
+def test_ctc_finetune_parity_f32(restore_dtype):
+    from audio8_amd import ops, wav2vec2 as W, ctc as Cc
+    from oracle import ref_cpu as R
+    ops.set_compute_dtype(torch.float32)
+    B, L, V = 3, 16000, 32
+    sd = R.init_state_dict(seed=1, num_layers=1, ctc_labels=V)
+    x = synth(B, L, 99)
+    lengths = torch.tensor([16000, 12000, 9000])
+    pad_mask = R.sequence_mask(lengths, L)
+    T = R.conv_out_lengths(L)[-1]
+    tl = torch.tensor([12, 7, 5])
+    targets = torch.full((B, 15), 1, dtype=torch.long)
+    g = torch.Generator().manual_seed(3)
+    for b in range(B):
+        targets[b, : tl[b]] = torch.randint(4, V, (int(tl[b]),), generator=g)
+        targets[b, tl[b]] = 2
+    # oracle (training masks sampled in the product's order: time mask, channel mask)
+    np.random.seed(4)
+    tm = R.create_mask((B, T), 0.5, 10)
+    cm = R.create_mask((B, 768), 0.1, 64)
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    lp_ref, pm_ref = R.acoustic_model_forward(x, pad_mask, sdg, num_layers=1, time_mask=tm, channel_mask=cm)
+    out_len = pm_ref.sum(-1)
+    flat = torch.from_numpy(R.ctc_strip_targets(targets.numpy()))
+    loss_ref = F.ctc_loss(lp_ref.transpose(1, 0), flat, out_len, tl, blank=0, reduction="sum", zero_infinity=True)
+    loss_ref.backward()
+    # product
+    model = W.create_acoustic_model(V, num_layers=1, dropout=0.0, freeze_fx=False)
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().train()
+    model.freeze = False
+    np.random.seed(4)
+    lp, pm = model(x.cuda(), pad_mask.cuda())
+    assert torch.equal(pm.cpu(), pm_ref)
+    np.testing.assert_allclose(lp.detach().cpu().numpy(), lp_ref.detach().numpy(), rtol=1e-4, atol=2e-5)
+    loss = Cc.CTCLoss(reduction_type="sum")(lp.transpose(1, 0), pm.sum(-1), targets.cuda(), tl)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), loss_ref.item(), rtol=1e-4)
+    got = dict(model.named_parameters())
+    for k, ref in sdg.items():
+        if k.endswith("w_K.layer.bias"):      # exactly zero in exact arithmetic (softmax shift invariance): noise on both sides
+            qn = got[k.replace("w_K", "w_Q")].grad.norm().item()
+            assert got[k].grad.norm().item() < 1e-3 * qn and ref.grad.norm().item() < 1e-3 * qn
+            continue
+        e = rel_err(got[k].grad, ref.grad)
+        assert e < 2e-3, f"{k}: rel grad err {e}"
+    # eval-mode metrics plumbing
+    model.eval()
+    with torch.no_grad():
+        lp_e, _ = model(x.cuda(), pad_mask.cuda())
+    vocab = {i: c for i, c in enumerate(['<s>', '<pad>', '</s>', '<unk>', '|'] + [chr(97 + i) for i in range(27)])}
+    m = Cc.ctc_metrics(lp_e.cpu(), targets, lengths, vocab)
+    want = R.ctc_metrics(lp_e.cpu(), targets, lengths, vocab)
+    assert m == want and m["c_total"] == int(tl.sum())
+
+
+def test_frozen_encoder_gives_no_encoder_grads(restore_dtype):
+    """train.py starts with model.freeze = True (audio8/wav2vec2.py:763,767): only `proj` trains."""
+    from audio8_amd import ops, wav2vec2 as W, ctc as Cc
+    ops.set_compute_dtype(torch.bfloat16)
+    model = W.create_acoustic_model(32, num_layers=1).cuda().train()
+    x = synth(2, 16000).cuda()
+    pm = torch.ones(2, 16000, dtype=torch.bool, device="cuda")
+    np.random.seed(0)
+    lp, pmo = model(x, pm)
+    targets = torch.tensor([[5, 6, 7, 2, 1], [8, 9, 2, 1, 1]], device="cuda")
+    loss = Cc.CTCLoss()(lp.transpose(1, 0), pmo.sum(-1), targets, torch.tensor([3, 2]))
+    loss.backward()
+    assert model.proj.weight.grad is not None and model.proj.weight.grad.abs().sum() > 0
+    assert all(p.grad is None for p in model.encoder.parameters())
