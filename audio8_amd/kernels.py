@@ -10,6 +10,11 @@ import torch
 from . import _lib as L
 
 
+# When set to a list, every a8_gemm launch is bracketed by HIP events on the launch stream and
+# (start, end, algorithmic_flops, layout) is appended -- bench.py's live roofline measurement.
+GEMM_PROFILE = None
+
+
 def _c(t):
     if t is not None and not t.is_contiguous():
         raise RuntimeError("a8hip: expected a contiguous tensor")
@@ -51,7 +56,14 @@ def gemm(layout, A, B, M, N, K, *, out=None, out_dtype=None, lda=None, ldb=None,
     d.accumulate = 1 if accumulate else 0
     d.splitk = splitk
     d.alpha = alpha
-    L.check(L.lib().a8_gemm(C.byref(d), L.stream()), "a8_gemm")
+    if GEMM_PROFILE is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        L.check(L.lib().a8_gemm(C.byref(d), L.stream()), "a8_gemm")
+        ev1.record()
+        GEMM_PROFILE.append((ev0, ev1, 2.0 * M * N * K, layout))
+    else:
+        L.check(L.lib().a8_gemm(C.byref(d), L.stream()), "a8_gemm")
     return out
 
 

@@ -1,0 +1,160 @@
+"""Step-level runtime either side of the hot path:
+
+  * FlatState     -- all parameters / gradients / Adam moments live in four contiguous f32 buffers
+                     (288 GB of HBM: nothing is sharded or offloaded); module parameters are views.
+  * GradReducer   -- data-parallel gradient exchange: the flat gradient buffer is cut into buckets in
+                     reverse-parameter order; when the last gradient of a bucket has been accumulated
+                     (post-accumulate hook) the bucket's all-reduce is issued on a side HIP stream behind
+                     an event, so RCCL traffic over xGMI overlaps the rest of backward.  Replaces DDP's
+                     reducer for audio8/pretrain.py:152-159 (the model stays wrappable by DDP as well).
+  * Stepper       -- zero_grad / clip_grad_norm_ / AdamW of audio8/pretrain.py:171-186 as two kernel
+                     launches (global sum of squares, fused clip+AdamW), no host sync.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+from . import kernels as K
+
+
+class FlatState:
+    def __init__(self, model: torch.nn.Module):
+        params = [p for p in model.parameters() if p.requires_grad]
+        dev = params[0].device
+        self.params = params
+        self.offsets, off = [], 0
+        for p in params:
+            self.offsets.append(off)
+            off += (p.numel() + 3) // 4 * 4             # keep every view 16-byte aligned
+        self.total = off
+        self.flat_p = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.flat_g = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.flat_m = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.flat_v = torch.zeros(off, device=dev, dtype=torch.float32)
+        for p, o in zip(params, self.offsets):
+            view = self.flat_p[o:o + p.numel()].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = self.flat_g[o:o + p.numel()].view_as(p)
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+        for p, o in zip(self.params, self.offsets):      # keep .grad bound to the flat views
+            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
+                p.grad = self.flat_g[o:o + p.numel()].view_as(p)
+
+
+class GradReducer:
+    """Bucketed all-reduce of the flat gradient buffer, overlapped with backward."""
+
+    def __init__(self, state: FlatState, bucket_mb: float = 32.0, process_group=None):
+        self.state = state
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.enabled = self.world > 1
+        self.on_gpu = state.flat_g.is_cuda
+        self.side = torch.cuda.Stream() if (self.enabled and self.on_gpu) else None
+        cap = int(bucket_mb * 1024 * 1024 / 4)
+        # buckets over contiguous flat ranges; built from the LAST parameter backwards (gradients of late
+        # layers are ready first), each bucket = [lo, hi) in elements plus the parameter indices it holds
+        self.buckets = []
+        hi, members = state.total, []
+        for i in range(len(state.params) - 1, -1, -1):
+            members.append(i)
+            lo = state.offsets[i]
+            if hi - lo >= cap or i == 0:
+                self.buckets.append({"lo": lo, "hi": hi, "members": members, "pending": len(members)})
+                hi, members = lo, []
+        self.bucket_of = {}
+        for b, bk in enumerate(self.buckets):
+            for i in bk["members"]:
+                self.bucket_of[i] = b
+        self.handles = []
+        if self.enabled:
+            for i, p in enumerate(state.params):
+                p.register_post_accumulate_grad_hook(self._make_hook(i))
+
+    def _make_hook(self, i):
+        def hook(_p):
+            bk = self.buckets[self.bucket_of[i]]
+            bk["pending"] -= 1
+            if bk["pending"] == 0:
+                self._launch(bk)
+        return hook
+
+    def _launch(self, bk):
+        view = self.state.flat_g[bk["lo"]:bk["hi"]]
+        if self.on_gpu:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.side.wait_event(ev)
+            with torch.cuda.stream(self.side):
+                h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        else:                                            # gloo on CPU (tests): same bucket schedule, no streams
+            h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        self.handles.append(h)
+        bk["launched"] = True
+
+    def begin_step(self):
+        for bk in self.buckets:
+            bk["pending"] = len(bk["members"])
+            bk["launched"] = False
+        self.handles = []
+
+    def finish(self):
+        """Issue any bucket whose parameters produced no gradient this step (frozen encoder, audio8/train.py:266-268),
+        then make the compute stream wait for the exchange.  Gradients hold the SUM over ranks afterwards."""
+        if not self.enabled:
+            return
+        for bk in self.buckets:
+            if not bk.get("launched"):
+                self._launch(bk)
+        for h in self.handles:
+            h.wait()
+        if self.on_gpu:
+            torch.cuda.current_stream().wait_stream(self.side)
+
+
+class Stepper:
+    """clip_grad_norm_(max_norm) + AdamW on the flat buffers; gradients are averaged over ranks inside the update."""
+
+    def __init__(self, model, lr=2.0e-4, weight_decay=1.0e-2, betas=(0.9, 0.999), eps=1e-8, clip=1.0, bucket_mb=32.0, lr_function=None):
+        self.state = FlatState(model)
+        self.reducer = GradReducer(self.state, bucket_mb)
+        self.lr, self.wd, self.betas, self.eps, self.clip = lr, weight_decay, betas, eps, clip
+        self.lr_function = lr_function
+        self.global_step = 0
+        self.gnorm_sq = torch.zeros(1, device=self.state.flat_p.device, dtype=torch.float32)
+        if self.reducer.enabled:                         # C1 of SURVEY 2.2: rank 0's parameters everywhere
+            dist.broadcast(self.state.flat_p, src=0)
+
+    @property
+    def current_lr(self):
+        return self.lr_function(self.global_step) if self.lr_function else self.lr
+
+    def zero_grad(self):
+        self.state.zero_grad()
+        self.reducer.begin_step()
+
+    def step(self):
+        self.reducer.finish()
+        self.global_step += 1
+        scale = 1.0 / self.reducer.world
+        self.gnorm_sq.zero_()
+        K.sumsq_(self.state.flat_g, self.gnorm_sq)
+        K.adamw_(self.state.flat_p, self.state.flat_g, self.state.flat_m, self.state.flat_v, self.current_lr, self.betas[0], self.betas[1],
+                 self.eps, self.wd, self.global_step, self.gnorm_sq, self.clip, scale)
+
+
+def init_distributed_from_env():
+    """One process per GPU; rendezvous from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
+    if world > 1 and not dist.is_initialized():
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world)
+    return rank, local, world
