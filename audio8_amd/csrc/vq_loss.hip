@@ -148,15 +148,13 @@ __global__ __launch_bounds__(256) void vq_bwd_kernel(const float* __restrict__ l
 }
 
 // ------------------------------------------------------------------ contrastive: cosine logits + CE
-// one wave per masked frame; the 4 quarter-waves take targets n = quarter, quarter+4, ...; C <= 16*EPL*... (C = 256 -> 16 per lane)
-constexpr int CPL = 16;     // channels per lane within a quarter wave (C = 256)
-template <typename T> A8_DEV void load16f(const T* p, float (&v)[CPL]) {
+// one wave per masked frame, C = 256: lane l owns channels {l, l+64, l+128, l+192}, so every load, and every
+// f32 atomic of the backward scatter, is one 256-byte contiguous wave-instruction (the shape the memory-side
+// atomic units run at full rate for; a 64-byte lane stride is ~17x slower).
+constexpr int CPL = 4;      // channels per lane (C = 256)
+template <typename T> A8_DEV void load_row(const T* p, int lane, float (&v)[CPL]) {
 #pragma unroll
-    for (int i = 0; i < CPL; ++i) v[i] = to_f(p[i]);
-}
-A8_DEV float quarter_sum(float v) {
-    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-    return v;
+    for (int i = 0; i < CPL; ++i) v[i] = to_f(p[lane + 64 * i]);
 }
 
 template <typename T>
@@ -174,34 +172,32 @@ template <typename T>
 __global__ __launch_bounds__(256) void contrastive_fwd_kernel(const T* __restrict__ ctx, const T* __restrict__ lat, const int32_t* __restrict__ idx,
                                                               const float* __restrict__ inv_ctx, const float* __restrict__ inv_lat,
                                                               float* __restrict__ logits, float* __restrict__ loss_sum, int rows, int N) {
-    __shared__ float s_log[4][128];
     __shared__ float red[4];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, qt = lane >> 4, ql = lane & 15;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float lsum = 0.f;
     for (int row = blockIdx.x * 4 + wv; row < rows; row += gridDim.x * 4) {
         float c[CPL];
-        load16f(ctx + (long long)row * (16 * CPL) + ql * CPL, c);
+        load_row(ctx + (long long)row * 256, lane, c);
         const float ic = inv_ctx[row];
-        for (int n = qt; n <= N; n += 4) {
+        float mine0 = -INFINITY, mine1 = -INFINITY;        // logits n = lane and n = lane + 64
+        for (int n = 0; n <= N; ++n) {
             const int tr = n == 0 ? row : idx[(long long)row * N + n - 1];
             float tv[CPL];
-            load16f(lat + (long long)tr * (16 * CPL) + ql * CPL, tv);
+            load_row(lat + (long long)tr * 256, lane, tv);
             float d = 0.f;
 #pragma unroll
             for (int i = 0; i < CPL; ++i) d = fmaf(c[i], tv[i], d);
-            d = quarter_sum(d) * ic * inv_lat[tr];
-            if (ql == 0) { s_log[wv][n] = d; logits[(long long)row * (N + 1) + n] = d; }
+            d = wave_sum(d) * ic * inv_lat[tr];
+            if (n == lane) mine0 = d;
+            if (n == lane + 64) mine1 = d;
         }
-        __builtin_amdgcn_s_waitcnt(0);   // this wave's LDS writes are complete before its reads below
-        __builtin_amdgcn_wave_barrier();
-        float mx = -INFINITY;
-        for (int n = lane; n <= N; n += 64) mx = fmaxf(mx, s_log[wv][n]);
-        mx = wave_max(mx);
-        float s = 0.f;
-        for (int n = lane; n <= N; n += 64) s += __expf(s_log[wv][n] - mx);
+        if (lane <= N) logits[(long long)row * (N + 1) + lane] = mine0;
+        if (lane + 64 <= N) logits[(long long)row * (N + 1) + lane + 64] = mine1;
+        const float mx = wave_max(fmaxf(mine0, mine1));
+        float s = (lane <= N ? __expf(mine0 - mx) : 0.f) + (lane + 64 <= N ? __expf(mine1 - mx) : 0.f);
         s = wave_sum(s);
-        if (lane == 0) lsum += mx + __logf(s) - s_log[wv][0];
-        __builtin_amdgcn_wave_barrier();
+        const float pos = __shfl(mine0, 0, 64);
+        if (lane == 0) lsum += mx + __logf(s) - pos;
     }
     lsum = block_sum<4>(lsum, red);
     if (threadIdx.x == 0) atomicAdd(loss_sum, lsum);
@@ -212,46 +208,39 @@ __global__ __launch_bounds__(256) void contrastive_bwd_kernel(const T* __restric
                                                               const float* __restrict__ inv_ctx, const float* __restrict__ inv_lat,
                                                               const float* __restrict__ logits, const float* __restrict__ gscale,
                                                               float* __restrict__ dctx, float* __restrict__ dlat, int rows, int N) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, qt = lane >> 4, ql = lane & 15;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const float gs = gscale[0];
     for (int row = blockIdx.x * 4 + wv; row < rows; row += gridDim.x * 4) {
-        // softmax over the N+1 logits of this row
-        float mx = -INFINITY;
-        for (int n = lane; n <= N; n += 64) mx = fmaxf(mx, logits[(long long)row * (N + 1) + n]);
-        mx = wave_max(mx);
-        float s = 0.f;
-        for (int n = lane; n <= N; n += 64) s += __expf(logits[(long long)row * (N + 1) + n] - mx);
-        s = wave_sum(s);
-        const float inv_s = 1.0f / s;
+        const float l0 = lane <= N ? logits[(long long)row * (N + 1) + lane] : -INFINITY;
+        const float l1 = lane + 64 <= N ? logits[(long long)row * (N + 1) + lane + 64] : -INFINITY;
+        const float mx = wave_max(fmaxf(l0, l1));
+        const float e0 = lane <= N ? __expf(l0 - mx) : 0.f, e1 = lane + 64 <= N ? __expf(l1 - mx) : 0.f;
+        const float inv_s = 1.0f / wave_sum(e0 + e1);
         float c[CPL], dc[CPL];
-        load16f(ctx + (long long)row * (16 * CPL) + ql * CPL, c);
+        load_row(ctx + (long long)row * 256, lane, c);
 #pragma unroll
         for (int i = 0; i < CPL; ++i) dc[i] = 0.f;
         const float ic = inv_ctx[row];
-        for (int n = qt; n <= N; n += 4) {
+        for (int n = 0; n <= N; ++n) {
             const int tr = n == 0 ? row : idx[(long long)row * N + n - 1];
-            const float lg = logits[(long long)row * (N + 1) + n];
-            const float dl = gs * (__expf(lg - mx) * inv_s - (n == 0 ? 1.f : 0.f));
+            const float lg = n < 64 ? __shfl(l0, n, 64) : __shfl(l1, n - 64, 64);
+            const float en = n < 64 ? __shfl(e0, n, 64) : __shfl(e1, n - 64, 64);
+            const float dl = gs * (en * inv_s - (n == 0 ? 1.f : 0.f));
             const float it = inv_lat[tr];
             float tv[CPL];
-            load16f(lat + (long long)tr * (16 * CPL) + ql * CPL, tv);
+            load_row(lat + (long long)tr * 256, lane, tv);
             // d cos/dc = t*ic*it - cos*c*ic^2 ; d cos/dt = c*ic*it - cos*t*it^2
             const float a = dl * ic * it, bc = dl * lg * ic * ic, bt = dl * lg * it * it;
-            float* dlp = dlat + (long long)tr * (16 * CPL) + ql * CPL;
+            float* dlp = dlat + (long long)tr * 256;
 #pragma unroll
             for (int i = 0; i < CPL; ++i) {
                 dc[i] += a * tv[i] - bc * c[i];
-                atomicAdd(dlp + i, a * c[i] - bt * tv[i]);
+                atomicAdd(dlp + lane + 64 * i, a * c[i] - bt * tv[i]);
             }
         }
-        // combine the four quarter-waves' partial dctx
+        float* dp = dctx + (long long)row * 256;
 #pragma unroll
-        for (int i = 0; i < CPL; ++i) { dc[i] += __shfl_xor(dc[i], 16, 64); dc[i] += __shfl_xor(dc[i], 32, 64); }
-        if (qt == 0) {
-            float* dp = dctx + (long long)row * (16 * CPL) + ql * CPL;
-#pragma unroll
-            for (int i = 0; i < CPL; i += 4) *reinterpret_cast<f32x4*>(dp + i) = (f32x4){dc[i], dc[i + 1], dc[i + 2], dc[i + 3]};
-        }
+        for (int i = 0; i < CPL; ++i) dp[lane + 64 * i] = dc[i];
     }
 }
 
@@ -298,7 +287,7 @@ extern "C" int a8_vq_bwd(int dtype, const float* logits, const float* gumbel, fl
 
 extern "C" int a8_contrastive_fwd(int dtype, const void* ctx, const void* lat, const int32_t* neg_idx, float* logits,
                                   float* loss_sum, float* inv_norms, int rows, int N, int Cn, void* stream) {
-    A8_REQUIRE(Cn == 16 * CPL, "a8_contrastive_fwd: C must be %d (got %d)", 16 * CPL, Cn);
+    A8_REQUIRE(Cn == 64 * CPL, "a8_contrastive_fwd: C must be %d (got %d)", 64 * CPL, Cn);
     A8_REQUIRE(N >= 1 && N + 1 <= 128, "a8_contrastive_fwd: N=%d must be in [1,127]", N);
     if (rows == 0) return A8_OK;
     float* ic = inv_norms; float* il = inv_norms + rows;
@@ -317,7 +306,7 @@ extern "C" int a8_contrastive_fwd(int dtype, const void* ctx, const void* lat, c
 
 extern "C" int a8_contrastive_bwd(int dtype, const void* ctx, const void* lat, const int32_t* neg_idx, const float* logits,
                                   const float* gscale, float* dctx, float* dlat, float* inv_norms, int rows, int N, int Cn, void* stream) {
-    A8_REQUIRE(Cn == 16 * CPL, "a8_contrastive_bwd: C must be %d (got %d)", 16 * CPL, Cn);
+    A8_REQUIRE(Cn == 64 * CPL, "a8_contrastive_bwd: C must be %d (got %d)", 64 * CPL, Cn);
     A8_REQUIRE(N >= 1 && N + 1 <= 128, "a8_contrastive_bwd: N=%d must be in [1,127]", N);
     if (rows == 0) return A8_OK;
     float* ic = inv_norms; float* il = inv_norms + rows;

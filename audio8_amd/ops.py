@@ -69,12 +69,72 @@ def wgrad(dy, x, n_out, n_in, m, lda=None, ldb=None, b_rpb=0, b_bs=0):
     return out
 
 
-def colsum(x2d, cols=None):
-    """f32 column sums of a [rows, cols] activation (bias gradients)."""
-    out = torch.zeros((x2d.shape[-1],), device=x2d.device, dtype=torch.float32)
+def colsum(x2d, out=None):
+    """f32 column sums of a [rows, cols] activation (bias gradients); accumulates into `out` when given."""
+    if out is None:
+        out = torch.zeros((x2d.shape[-1],), device=x2d.device, dtype=torch.float32)
     rows = x2d.numel() // x2d.shape[-1]
     L.check(L.lib().a8_gelu_bwd_bias(L.dt(x2d), L.ptr(x2d), None, None, L.ptr(out), rows, x2d.shape[-1], L.stream()), "a8_gelu_bwd_bias")
     return out
+
+
+# ------------------------------------------------------------------ direct gradient accumulation
+# When enabled (audio8_amd.trainer.Stepper does), a backward kernel adds its weight gradient straight into
+# the parameter's existing f32 .grad buffer (a view of the flat gradient buffer) and hands autograd `None`:
+# no temporary, no AccumulateGrad "+=" pass.  GRAD_READY_HOOK(param) then tells the DP reducer that the
+# parameter's gradient has been enqueued on the stream.
+DIRECT_GRADS = False
+GRAD_READY_HOOK = None
+
+
+def _target(p):
+    if DIRECT_GRADS and p is not None and p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous():
+        return p.grad
+    return None
+
+
+def _ready(*ps):
+    if GRAD_READY_HOOK is not None:
+        for p in ps:
+            if p is not None:
+                GRAD_READY_HOOK(p)
+
+
+def acc_wgrad(p, dy, x, n_out, n_in, m, **kw):
+    """Weight gradient of parameter p: in place into p.grad (returns None) or as a fresh tensor."""
+    tgt = _target(p)
+    if tgt is None:
+        return wgrad(dy, x, n_out, n_in, m, **kw)
+    K.gemm(L.TN, dy, x, n_out, n_in, m, out=tgt, accumulate=True, splitk=_splitk(_tiles(n_out, n_in), m), **kw)
+    _ready(p)
+    return None
+
+
+def acc_colsum(p, x2d):
+    tgt = _target(p)
+    if tgt is None:
+        return colsum(x2d)
+    colsum(x2d, tgt)
+    _ready(p)
+    return None
+
+
+def _adjacent(a, b, c):
+    """True when tensors a, b, c are back-to-back views of ONE storage (FlatState lays q/k/v weights out that way).
+    Separate allocations that merely happen to be neighbours do not count: a view may not span storages."""
+    if a is None or b is None or c is None or not (a.is_contiguous() and b.is_contiguous() and c.is_contiguous()):
+        return False
+    sa = a.untyped_storage()
+    if sa.data_ptr() != b.untyped_storage().data_ptr() or sa.data_ptr() != c.untyped_storage().data_ptr():
+        return False
+    es = a.element_size()
+    return (a.storage_offset() + a.numel() == b.storage_offset() and b.storage_offset() + b.numel() == c.storage_offset()
+            and (c.storage_offset() + c.numel()) * es <= sa.nbytes())
+
+
+def _span3(a, shape):
+    """View of 3x the extent of `a` starting at a (requires _adjacent)."""
+    return torch.empty(0, device=a.device, dtype=a.dtype).set_(a.untyped_storage(), a.storage_offset(), shape)
 
 
 # ------------------------------------------------------------------ Linear
@@ -90,19 +150,21 @@ class LinearFn(torch.autograd.Function):
                    out_dtype=torch.float32 if out_f32 else x.dtype)
         ctx.save_for_backward(x, wc)
         ctx.has_bias = bias is not None
+        ctx.params = (weight, bias)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, wc = ctx.saved_tensors
+        weight, bias = ctx.params
         M, Kd = x.shape
         N = wc.shape[0]
         dy = dy.contiguous()
         if dy.dtype != x.dtype:
             dy = K.cast(dy, x.dtype)
         dx = K.gemm(L.NN, dy, wc, M, Kd, N) if ctx.needs_input_grad[0] else None
-        dw = wgrad(dy, x, N, Kd, M) if ctx.needs_input_grad[1] else None
-        db = colsum(dy) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        dw = acc_wgrad(weight, dy, x, N, Kd, M) if ctx.needs_input_grad[1] else None
+        db = acc_colsum(bias, dy) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db, None
 
 
@@ -122,17 +184,24 @@ class LayerNormFn(torch.autograd.Function):
         y, mean, rstd = K.layernorm_fwd(x, res, gamma.detach(), beta.detach(), eps, p, seed, 1)
         ctx.save_for_backward(x, res, gamma, mean, rstd)
         ctx.p, ctx.seed = p, seed
+        ctx.params = (gamma, beta)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, res, gamma, mean, rstd = ctx.saved_tensors
-        dg = torch.zeros_like(gamma, dtype=torch.float32)
-        db = torch.zeros_like(gamma, dtype=torch.float32)
+        pg, pb = ctx.params
+        tg, tb = _target(pg), _target(pb)
+        direct = tg is not None and tb is not None
+        dg = tg if direct else torch.zeros_like(gamma, dtype=torch.float32)
+        db = tb if direct else torch.zeros_like(gamma, dtype=torch.float32)
         dx, dres = K.layernorm_bwd(dy.contiguous(), None, x, res, gamma.detach(), mean, rstd, dg, db, ctx.p, ctx.seed, 1,
                                    want_dx=True, want_dres=res is not None and ctx.p > 0)
         if res is not None and ctx.p == 0:
             dres = dx
+        if direct:
+            _ready(pg, pb)
+            dg = db = None
         return dx, (dres if res is not None else None), dg, db, None, None
 
 
@@ -164,13 +233,19 @@ class MaskFillRowsFn(torch.autograd.Function):
     def forward(ctx, x, mask_u8, emb):
         y = K.mask_fill_rows_(x.clone(), mask_u8, emb.detach())
         ctx.save_for_backward(mask_u8)
+        ctx.params = (emb,)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         (mask_u8,) = ctx.saved_tensors
-        demb = torch.zeros((dy.shape[-1],), device=dy.device, dtype=torch.float32)
+        (emb,) = ctx.params
+        tgt = _target(emb)
+        demb = tgt if tgt is not None else torch.zeros((dy.shape[-1],), device=dy.device, dtype=torch.float32)
         dx = K.mask_fill_rows_bwd_(dy.clone(), mask_u8, demb)
+        if tgt is not None:
+            _ready(emb)
+            demb = None
         return dx, None, demb
 
 
@@ -241,6 +316,7 @@ class ConvStackFn(torch.autograd.Function):
             wcs.append(wc)
             lens.append(Lout)
         ctx.feats, ctx.lens, ctx.B = feats, lens, B
+        ctx.params = (ws[0], gn_w, gn_b)
         ctx.save_for_backward(x, gn_w, gn_b, stats, ws[0], *acts[:-1], *zs[1:], *wcs[1:])
         ctx.nl = len(ws)
         return acts[-1]
@@ -270,10 +346,16 @@ class ConvStackFn(torch.autograd.Function):
             dcol = K.gemm(L.NN, dz, wcs[i], M, k * cin, co)
             dz = K.col2im_gelu_grad(dcol, zs[i - 1] if i - 1 >= 1 else None, B, Lin, Lout, cin, k, s).view(-1, cin)
             del dcol
-        dw0 = torch.zeros_like(w0, dtype=torch.float32)
-        dgw = torch.zeros_like(gn_w, dtype=torch.float32)
-        dgb = torch.zeros_like(gn_b, dtype=torch.float32)
+        pw0, pgw, pgb = ctx.params
+        t0, t1, t2 = _target(pw0), _target(pgw), _target(pgb)
+        direct = t0 is not None and t1 is not None and t2 is not None
+        dw0 = t0 if direct else torch.zeros_like(w0, dtype=torch.float32)
+        dgw = t1 if direct else torch.zeros_like(gn_w, dtype=torch.float32)
+        dgb = t2 if direct else torch.zeros_like(gn_b, dtype=torch.float32)
         K.conv0_gn_gelu_bwd(x, w0.detach().contiguous(), gn_w.detach(), gn_b.detach(), stats, dz.view(B, lens[0], -1), dw0, dgw, dgb)
+        if direct:
+            _ready(pw0, pgw, pgb)
+            dw0 = dgw = dgb = None
         grads[0] = dw0
         return (None, dgw, dgb, None, *grads)
 
@@ -295,6 +377,7 @@ class PosConvFn(torch.autograd.Function):
         y, z = K.posconv_fwd(x.contiguous(), wf, bias.detach(), groups, k, pad_left, 1, want_z=True)
         ctx.save_for_backward(x, z, wt)
         ctx.groups, ctx.pad_left, ctx.k, ctx.dg = groups, pad_left, k, dg
+        ctx.params = (bias,)
         return y
 
     @staticmethod
@@ -303,8 +386,13 @@ class PosConvFn(torch.autograd.Function):
         B, T, d = x.shape
         G, k, dg = ctx.groups, ctx.k, ctx.dg
         dy = dy.contiguous()
-        dbias = torch.zeros((d,), device=x.device, dtype=torch.float32)
+        (pbias,) = ctx.params
+        tb = _target(pbias)
+        dbias = tb if tb is not None else torch.zeros((d,), device=x.device, dtype=torch.float32)
         dz = K.gelu_bwd_bias(dy, z, dbias)
+        if tb is not None:
+            _ready(pbias)
+            dbias = None
         dxc, _ = K.posconv_fwd(dz, wt, None, G, k, k - 1 - ctx.pad_left, -1)
         dx = K.add(dy, dxc)
         dwg = torch.zeros((G, dg, k, dg), device=x.device, dtype=torch.float32)
@@ -324,8 +412,11 @@ class EncoderLayerFn(torch.autograd.Function):
         M, d = x.shape
         dt = x.dtype
         dff = w1.shape[0]
-        wqkv = torch.cat([wq.detach(), wk.detach(), wv.detach()], 0)
-        bqkv = torch.cat([bq.detach(), bk.detach(), bv.detach()], 0)
+        if _adjacent(wq, wk, wv) and _adjacent(bq, bk, bv):          # FlatState layout: no concatenation needed
+            wqkv, bqkv = _span3(wq.detach(), (3 * d, d)), _span3(bq.detach(), (3 * d,))
+        else:
+            wqkv = torch.cat([wq.detach(), wk.detach(), wv.detach()], 0)
+            bqkv = torch.cat([bq.detach(), bk.detach(), bv.detach()], 0)
         wqkv_c, wo_c, w1_c, w2_c = _wcast(wqkv, dt), _wcast(wo, dt), _wcast(w1, dt), _wcast(w2, dt)
         qkv = K.gemm(L.NT, x, wqkv_c, M, 3 * d, d, bias=bqkv)
         seed_a = next_seed() if p > 0 else 0
@@ -341,6 +432,7 @@ class EncoderLayerFn(torch.autograd.Function):
         ctx.save_for_backward(x, keymask, qkv, o, lse, ao, x1, mean2, rstd2, z1, h, f, mean1, rstd1,
                               wqkv_c, wo_c, w1_c, w2_c, g1, g2)
         ctx.cfg = (B, T, H, p, seed_a, seed1, seed2)
+        ctx.params = (wq, bq, wk, bk, wv, bv, wo, bo, w1, b1, w2, b2, g1, be1, g2, be2)
         return x2
 
     @staticmethod
@@ -352,37 +444,57 @@ class EncoderLayerFn(torch.autograd.Function):
         dev = x.device
         f32 = torch.float32
         dx2 = dx2.contiguous()
-        dg1, dbe1 = torch.zeros(d, device=dev, dtype=f32), torch.zeros(d, device=dev, dtype=f32)
-        dg2, dbe2 = torch.zeros(d, device=dev, dtype=f32), torch.zeros(d, device=dev, dtype=f32)
+        wq, bq, wk, bk, wv, bv, wo, bo, w1, b1, w2, b2, pg1, pbe1, pg2, pbe2 = ctx.params
+
+        def ln_targets(pg, pb):
+            tg, tb = _target(pg), _target(pb)
+            if tg is not None and tb is not None:
+                return tg, tb, True
+            return torch.zeros(d, device=dev, dtype=f32), torch.zeros(d, device=dev, dtype=f32), False
+
+        dg1, dbe1, dir1 = ln_targets(pg1, pbe1)
+        dg2, dbe2, dir2 = ln_targets(pg2, pbe2)
         # ln1: x2 = LN(x1 + drop(f))
         df, dx1_res = K.layernorm_bwd(dx2, None, f, x1, g1.detach(), mean1, rstd1, dg1, dbe1, p, seed2, 4, want_dx=True, want_dres=p > 0)
         if p == 0:
             dx1_res = df
+        if dir1:
+            _ready(pg1, pbe1)
+            dg1 = dbe1 = None
         # FFN
-        db2 = colsum(df)
-        dw2 = wgrad(df, h, d, dff, M)
+        db2 = acc_colsum(b2, df)
+        dw2 = acc_wgrad(w2, df, h, d, dff, M)
         dz1 = K.gemm(L.NN, df, w2_c, M, dff, d, act=L.ACT_MUL_GELU_GRAD, zin=z1, ldz=dff)
-        db1 = colsum(dz1)
-        dw1 = wgrad(dz1, x1, dff, d, M)
+        db1 = acc_colsum(b1, dz1)
+        dw1 = acc_wgrad(w1, dz1, x1, dff, d, M)
         dx1_ffn = K.gemm(L.NN, dz1, w1_c, M, d, dff)
         # ln2: x1 = LN(x + drop(ao))
         dao, dx_res = K.layernorm_bwd(dx1_res, dx1_ffn, ao, x, g2.detach(), mean2, rstd2, dg2, dbe2, p, seed1, 3, want_dx=True, want_dres=p > 0)
         if p == 0:
             dx_res = dao
+        if dir2:
+            _ready(pg2, pbe2)
+            dg2 = dbe2 = None
         # output projection
-        dbo = colsum(dao)
-        dwo = wgrad(dao, o, d, d, M)
+        dbo = acc_colsum(bo, dao)
+        dwo = acc_wgrad(wo, dao, o, d, d, M)
         do = K.gemm(L.NN, dao, wo_c, M, d, d)
         # attention core
         _, _, _, dqkv = K.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, do, lse, B, T, H, 3 * d, 1.0 / math.sqrt(d // H),
                                    keymask, p, seed_a)
-        dbqkv = colsum(dqkv)
-        dwqkv = wgrad(dqkv, x, 3 * d, d, M)
+        tw, tb = [_target(w) for w in (wq, wk, wv)], [_target(b) for b in (bq, bk, bv)]
+        if all(t is not None for t in tw + tb) and _adjacent(*tw) and _adjacent(*tb):
+            colsum(dqkv, _span3(tb[0], (3 * d,)))
+            K.gemm(L.TN, dqkv, x, 3 * d, d, M, out=_span3(tw[0], (3 * d, d)), accumulate=True, splitk=_splitk(_tiles(3 * d, d), M))
+            _ready(wq, bq, wk, bk, wv, bv)
+            gq = (None,) * 6
+        else:
+            dbqkv = colsum(dqkv)
+            dwqkv = wgrad(dqkv, x, 3 * d, d, M)
+            gq = (dwqkv[:d], dbqkv[:d], dwqkv[d:2 * d], dbqkv[d:2 * d], dwqkv[2 * d:], dbqkv[2 * d:])
         dx_qkv = K.gemm(L.NN, dqkv, wqkv_c, M, d, 3 * d)
         dx = K.add(dx_res, dx_qkv)
-        return (dx, None, None, None, None, None, None,
-                dwqkv[:d], dbqkv[:d], dwqkv[d:2 * d], dbqkv[d:2 * d], dwqkv[2 * d:], dbqkv[2 * d:],
-                dwo, dbo, dw1, db1, dw2, db2, dg1, dbe1, dg2, dbe2)
+        return (dx, None, None, None, None, None, None, *gq, dwo, dbo, dw1, db1, dw2, db2, dg1, dbe1, dg2, dbe2)
 
 
 # ------------------------------------------------------------------ Gumbel vector quantiser
@@ -405,6 +517,7 @@ class VQFn(torch.autograd.Function):
         ppl, dppl = K.vq_ppl(avg)
         ctx.save_for_backward(yf, wp, logits, gumbel if training else None, codes, vars2d, dppl)
         ctx.cfg = (G, V, D, tau, training, y.dtype, vars_.shape)
+        ctx.params = (wp, bp, vars_)
         ctx.mark_non_differentiable(codes)
         return q, ppl, codes
 
@@ -422,15 +535,19 @@ class VQFn(torch.autograd.Function):
             eproj = torch.empty((N, G * V), device=dev, dtype=torch.float32)
             for g in range(G):
                 K.gemm(L.NT, dqf[:, g * D:], vars2d[g * V:], N, V, D, lda=G * D, out=eproj[:, g * V:], ldc=G * V)
-        dvars = torch.zeros_like(vars2d)
+        pwp, pbp, pvars = ctx.params
+        tv = _target(pvars)
+        dvars = tv.view(G * V, D) if tv is not None else torch.zeros_like(vars2d)
         gppl = dppl_out.contiguous().float() if dppl_out is not None else torch.zeros(1, device=dev)
         dlogits = K.vq_bwd(logits, gumbel, tau, codes, vars2d, dqf, eproj, dppl, gppl, dvars, N, G, V, D, training).view(N, G * V)
-        dwp = wgrad(dlogits, yf, G * V, Cin, N)
-        dbp = colsum(dlogits)
+        if tv is not None:
+            _ready(pvars)
+        dwp = acc_wgrad(pwp, dlogits, yf, G * V, Cin, N)
+        dbp = acc_colsum(pbp, dlogits)
         dy = K.gemm(L.NN, dlogits, wp.detach().contiguous(), N, Cin, G * V)
         if ydt != torch.float32:
             dy = K.cast(dy, ydt)
-        return dy, dwp, dbp, dvars.view(vshape), None, None, None, None, None
+        return dy, dwp, dbp, (None if tv is not None else dvars.view(vshape)), None, None, None, None, None
 
 
 # ------------------------------------------------------------------ contrastive loss

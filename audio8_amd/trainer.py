@@ -16,11 +16,12 @@ import torch
 import torch.distributed as dist
 
 from . import kernels as K
+from . import ops
 
 
 class FlatState:
     def __init__(self, model: torch.nn.Module):
-        params = [p for p in model.parameters() if p.requires_grad]
+        params = self._ordered(model)
         dev = params[0].device
         self.params = params
         self.offsets, off = [], 0
@@ -37,6 +38,28 @@ class FlatState:
             view.copy_(p.data)
             p.data = view
             p.grad = self.flat_g[o:o + p.numel()].view_as(p)
+
+    @staticmethod
+    def _ordered(model):
+        """Parameters in module order, except that each attention block's w_Q/w_K/w_V weights (and biases) are
+        made adjacent so the fused N = 3d QKV GEMM and its weight gradient address them as one [3d, d] matrix."""
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        by_name = dict(named)
+        out, done = [], set()
+        for n, p in named:
+            if id(p) in done:
+                continue
+            if n.endswith("self_attn.w_Q.layer.weight"):
+                stem = n[: -len("w_Q.layer.weight")]
+                group = [stem + f"w_{c}.layer.{leaf}" for leaf in ("weight", "bias") for c in "QKV"]
+                if all(g in by_name for g in group):
+                    for g in group:
+                        out.append(by_name[g])
+                        done.add(id(by_name[g]))
+                    continue
+            out.append(p)
+            done.add(id(p))
+        return out
 
     def zero_grad(self):
         self.flat_g.zero_()
@@ -71,17 +94,28 @@ class GradReducer:
             for i in bk["members"]:
                 self.bucket_of[i] = b
         self.handles = []
+        self.index_of = {id(p): i for i, p in enumerate(state.params)}
         if self.enabled:
             for i, p in enumerate(state.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(i))
 
+    def _mark(self, i):
+        bk = self.buckets[self.bucket_of[i]]
+        bk["pending"] -= 1
+        if bk["pending"] == 0 and not bk.get("launched"):
+            self._launch(bk)
+
     def _make_hook(self, i):
         def hook(_p):
-            bk = self.buckets[self.bucket_of[i]]
-            bk["pending"] -= 1
-            if bk["pending"] == 0:
-                self._launch(bk)
+            self._mark(i)
         return hook
+
+    def param_ready(self, p):
+        """ops.GRAD_READY_HOOK: a backward kernel has enqueued p's gradient directly into the flat buffer."""
+        if self.enabled:
+            i = self.index_of.get(id(p))
+            if i is not None:
+                self._mark(i)
 
     def _launch(self, bk):
         view = self.state.flat_g[bk["lo"]:bk["hi"]]
@@ -126,6 +160,8 @@ class Stepper:
         self.lr_function = lr_function
         self.global_step = 0
         self.gnorm_sq = torch.zeros(1, device=self.state.flat_p.device, dtype=torch.float32)
+        ops.DIRECT_GRADS = True
+        ops.GRAD_READY_HOOK = self.reducer.param_ready
         if self.reducer.enabled:                         # C1 of SURVEY 2.2: rank 0's parameters everywhere
             dist.broadcast(self.state.flat_p, src=0)
 

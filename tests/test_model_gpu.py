@@ -201,3 +201,48 @@ def test_frozen_encoder_gives_no_encoder_grads(restore_dtype):
     loss.backward()
     assert model.proj.weight.grad is not None and model.proj.weight.grad.abs().sum() > 0
     assert all(p.grad is None for p in model.encoder.parameters())
+
+
+def test_direct_grad_accumulation_and_stepper_match_autograd(restore_dtype):
+    """Stepper mode (gradients written by the kernels straight into the flat f32 buffer, fused clip+AdamW)
+    must equal plain autograd + torch clip_grad_norm_ + AdamW."""
+    from audio8_amd import ops, wav2vec2 as W
+    from audio8_amd.trainer import Stepper
+    from oracle import ref_cpu as R
+    ops.set_compute_dtype(torch.float32)
+    sd = R.init_state_dict(seed=2, num_layers=2)
+    x = synth(2, 16000, 5).cuda()
+    gum = (-torch.empty(2 * 21 * 2, 320).exponential_(generator=torch.Generator().manual_seed(6)).log()).cuda()
+
+    def make():
+        m = W.create_model(num_layers=2, dropout=0.0, dropout_input=0.0, dropout_features=0.0)
+        m.load_state_dict(sd)
+        m = m.cuda().train()
+        m.quantizer.gumbel_override = gum
+        return m
+
+    try:
+        ref = make()
+        opt = torch.optim.AdamW(ref.parameters(), lr=2e-4, weight_decay=1e-2)
+        np.random.seed(0)
+        W.create_loss(640, 100)(ref, x).backward()
+        ref_grads = {k: p.grad.clone() for k, p in ref.named_parameters()}
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 1.0)
+        opt.step()
+
+        mdl = make()
+        st = Stepper(mdl, lr=2e-4, weight_decay=1e-2, clip=1.0)
+        assert ops.DIRECT_GRADS
+        st.zero_grad()
+        np.random.seed(0)
+        W.create_loss(640, 100)(mdl, x).backward()
+        for k, p in mdl.named_parameters():
+            assert p.grad.data_ptr() >= st.state.flat_g.data_ptr(), k
+            assert rel_err(p.grad, ref_grads[k]) < 1e-4, k
+        st.step()
+        torch.cuda.synchronize()
+        for (k, p), (_, q) in zip(mdl.named_parameters(), ref.named_parameters()):
+            np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=2e-5, atol=2e-5, err_msg=k)  # atol = 10% of one lr-sized Adam step (gradients ~ eps are sign-unstable)
+    finally:
+        ops.DIRECT_GRADS = False
+        ops.GRAD_READY_HOOK = None
