@@ -7,8 +7,9 @@
 // An operand that is K-strided in memory ("KS") is staged [k][row] in LDS and read with
 // ds_read_b64_tr_b16 (bf16) so no operand is ever transposed through HBM.
 //
-// Block = 256 threads = 4 waves (2x2), tile 128x128, BK = 64 (bf16) / 16 (f32), register-staged
-// double-buffered LDS (global loads for tile t+1 are in flight while tile t is multiplied).
+// Block = 256 threads = 4 waves (2x2), tile 128x128, k-tile = 64 bytes of K per row (32 bf16 / 16 f32), staged
+// by LDS-DMA (global_load_lds) into a 4-deep LDS ring: three k-tiles are in flight per block behind a counted
+// s_waitcnt vmcnt and one raw s_barrier per k-tile (the K = 768 projections are latency-bound otherwise).
 // "Row remap": an operand's outer index o maps to (o / rpb) * bs + (o % rpb) * ld, which lets the
 // strided conv layers run as plain GEMMs over overlapping rows of a channels-last activation
 // (row t of utterance b starts at b*Lin*C + t*stride*C and is k*C long).
@@ -32,23 +33,77 @@ A8_DEV long long outer_off(const Op& o, long long idx) {
     return o.rpb ? (idx / o.rpb) * o.bs + (idx % o.rpb) * o.ld : idx * o.ld;
 }
 
-template <typename T, bool KS> struct Stage {
-    static constexpr int EPC = 16 / (int)sizeof(T);                  // elements per 16-byte chunk
-    static constexpr int CPR = KS ? 128 / EPC : Tile<T>::BK / EPC;   // chunks per LDS row
-    static constexpr int NCH = KS ? Tile<T>::BK * CPR / 256 : 128 * CPR / 256;
-    static constexpr int RSTEP = 256 / CPR;                          // LDS rows between a thread's chunks
+// 16 zero bytes: the LDS-DMA source of every out-of-range lane (M/N/K tails are zero-filled this way)
+__device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
+
+A8_DEV void glds16(const char* src, char* lds_dst_wave_uniform) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_dst_wave_uniform, 16, 0, 0);
+}
+
+// ---- stage tile geometry.  An operand stage is 128 rows x KROW bytes of K (KROW = 64 or 128), filled by LDS-DMA
+// pieces of 1 KB (one wave-instruction each, lane l lands at piece + 16 l).  The XOR swizzles live on the per-lane
+// SOURCE address; the LDS image is linear.
+//   KC (reduction contiguous): [128 rows][KROW]; lane -> row RPP*p + l/SPR, slot l%SPR holds chunk slot ^ swz(row)
+//   KS bf16: [BK k][256 B]; piece = 4 k-rows; lane -> k 4p + l/16, 16-B piece l%16; 32-B chunk c stored at c ^ key(k)
+//   KS f32 : [BK k][512 B]; piece = 2 k-rows; lane -> k 2p + l/32, 16-B piece l%32 (no swizzle)
+template <int KB> struct KcGeom {
+    static constexpr int KROW = 64 * KB, SPR = KROW / 16, RPP = 1024 / KROW, OPBYTES = 128 * KROW, NPIECE = OPBYTES / 1024;
+    static A8_DEV int swz(int row) { return KB == 1 ? ((row >> 1) & 3) : (row & 7); }
+};
+template <typename T, int KB> struct StageTile;
+template <int KB> struct StageTile<bf16, KB> {
+    typedef KcGeom<KB> G;
+    static constexpr int BK = 32 * KB, KSTEPS = KB;
+    static A8_DEV int ks_key(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+    static A8_DEV bf16x8 kc_frag(const char* t, int rb, int ks, int lane) {
+        const int row = rb + (lane & 15);
+        return *reinterpret_cast<const bf16x8*>(t + row * G::KROW + (((ks * 4 + (lane >> 4)) ^ G::swz(row)) << 4));
+    }
+    static A8_DEV bf16x8 ks_frag(const char* t, int rb, int ks, int lane) {
+        const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3, nb = rb >> 4;
+        const int k0 = ks * 32 + 8 * g + q, k1 = k0 + 4;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, t + k0 * 256 + ((nb ^ ks_key(k0)) << 5) + 8 * p));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, t + k1 * 256 + ((nb ^ ks_key(k1)) << 5) + 8 * p));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    }
+    static A8_DEV void ks_src(int p, int lane, int& k, int& col) {
+        k = 4 * p + (lane >> 4);
+        const int pc = lane & 15;
+        col = (((pc >> 1) ^ ks_key(k)) << 4) + ((pc & 1) << 3);
+    }
+};
+template <int KB> struct StageTile<float, KB> {
+    typedef KcGeom<KB> G;
+    static constexpr int BK = 16 * KB, KSTEPS = 4 * KB;
+    static A8_DEV float kc_frag(const char* t, int rb, int ks, int lane) {
+        const int row = rb + (lane & 15);
+        return *reinterpret_cast<const float*>(t + row * G::KROW + ((ks ^ G::swz(row)) << 4) + ((lane >> 4) << 2));
+    }
+    static A8_DEV float ks_frag(const char* t, int rb, int ks, int lane) {
+        return *reinterpret_cast<const float*>(t + (ks * 4 + (lane >> 4)) * 512 + (rb + (lane & 15)) * 4);
+    }
+    static A8_DEV void ks_src(int p, int lane, int& k, int& col) {
+        k = 2 * p + (lane >> 5);
+        col = (lane & 31) << 2;
+    }
 };
 
-template <typename T, bool AKS, bool BKS>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
-    constexpr int BK = Tile<T>::BK;
-    constexpr int TILE_BYTES = sizeof(T) == 2 ? 16384 : 10240;
+// Main loop: NST-deep ring of LDS stages filled by LDS-DMA (global_load_lds, 16 B per lane), NST-1 k-tiles in
+// flight per block; one raw s_barrier and one counted s_waitcnt vmcnt per k-tile; no register staging.
+template <typename T, bool AKS, bool BKS, int KB, int NST>
+__global__ __launch_bounds__(256, (NST * 2 * 8192 * KB <= 65536) ? 2 : 1) void gemm_kernel(const GemmArgs g) {
+    typedef StageTile<T, KB> ST;
+    typedef KcGeom<KB> G;
     typedef Mma<T> MM;
-    typedef Stage<T, AKS> SA;
-    typedef Stage<T, BKS> SB;
-    __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES];
+    constexpr int BK = ST::BK, TILE = G::OPBYTES, EPC = 16 / (int)sizeof(T), SZ = (int)sizeof(T);
+    constexpr int PPW = G::NPIECE / 4;            // LDS-DMA pieces per wave per operand per stage
+    __shared__ __attribute__((aligned(1024))) char lds[NST * 2 * TILE];
 
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = w >> 1, wn = w & 1;
     const int nblk = g.tiles_m * g.tiles_n * g.nsplit;
     const int bid = xcd_remap(blockIdx.x, nblk);
@@ -58,64 +113,80 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     const int kbeg = split * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
     const int nkb = (kend - kbeg + BK - 1) / BK;
+    const char* zero = reinterpret_cast<const char*>(g_zero16);
 
-    // ---- per-thread staging coordinates
-    const int a_c = t % SA::CPR, a_r = t / SA::CPR;      // chunk within LDS row, first LDS row
-    const int b_c = t % SB::CPR, b_r = t / SB::CPR;
-    long long a_base[SA::NCH], b_base[SB::NCH];          // KC: element offset of the row start (-1 = out of range)
-    if constexpr (!AKS) {
+    // ---- per-lane LDS-DMA sources for this wave's pieces of each operand
+    const char* a_ptr[PPW]; int a_k[PPW]; bool a_ok[PPW];
+    const char* b_ptr[PPW]; int b_k[PPW]; bool b_ok[PPW];
 #pragma unroll
-        for (int j = 0; j < SA::NCH; ++j) {
-            const int row = m0 + a_r + j * SA::RSTEP;
-            a_base[j] = row < g.M ? outer_off(g.A, row) : -1;
+    for (int j = 0; j < PPW; ++j) {
+        const int p = w + 4 * j;
+        if constexpr (!AKS) {
+            const int rl = G::RPP * p + lane / G::SPR, row = m0 + rl;
+            a_k[j] = (((lane % G::SPR) ^ G::swz(rl)) & (G::SPR - 1)) * EPC;
+            a_ok[j] = row < g.M;
+            a_ptr[j] = g.A.p + (a_ok[j] ? outer_off(g.A, row) : 0) * SZ;
+        } else {
+            int kl, col;
+            ST::ks_src(p, lane, kl, col);
+            a_k[j] = kl;
+            a_ok[j] = m0 + col + EPC <= g.M;
+            a_ptr[j] = g.A.p + (long long)(m0 + col) * SZ;
+        }
+        if constexpr (!BKS) {
+            const int rl = G::RPP * p + lane / G::SPR, row = n0 + rl;
+            b_k[j] = (((lane % G::SPR) ^ G::swz(rl)) & (G::SPR - 1)) * EPC;
+            b_ok[j] = row < g.N;
+            b_ptr[j] = g.B.p + (b_ok[j] ? outer_off(g.B, row) : 0) * SZ;
+        } else {
+            int kl, col;
+            ST::ks_src(p, lane, kl, col);
+            b_k[j] = kl;
+            b_ok[j] = n0 + col + EPC <= g.N;
+            b_ptr[j] = g.B.p + (long long)(n0 + col) * SZ;
         }
     }
-    if constexpr (!BKS) {
-#pragma unroll
-        for (int j = 0; j < SB::NCH; ++j) {
-            const int row = n0 + b_r + j * SB::RSTEP;
-            b_base[j] = row < g.N ? outer_off(g.B, row) : -1;
-        }
-    }
-    u32x4 ra[SA::NCH], rb[SB::NCH];
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
-    auto gload = [&](int kb) {
+    // K-strided operands walk their outer index by BK per k-tile: keep (batch, row-in-batch) incrementally
+    // instead of a 64-bit division per DMA (the conv weight gradient has rows_per_batch != 0).
+    long long a_q[PPW], a_r[PPW], b_q[PPW], b_r[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        if constexpr (AKS) { const long long k = kbeg + a_k[j]; a_q[j] = g.A.rpb ? k / g.A.rpb : 0; a_r[j] = g.A.rpb ? k % g.A.rpb : k; }
+        if constexpr (BKS) { const long long k = kbeg + b_k[j]; b_q[j] = g.B.rpb ? k / g.B.rpb : 0; b_r[j] = g.B.rpb ? k % g.B.rpb : k; }
+    }
+    int kb_issued = 0;                      // issue() is always called with kb = 0, 1, 2, ... in order
+    auto issue = [&](int kb) {
+        char* ta = lds + (kb % NST) * 2 * TILE;
+        char* tb = ta + TILE;
         const int k0 = kbeg + kb * BK;
 #pragma unroll
-        for (int j = 0; j < SA::NCH; ++j) {
+        for (int j = 0; j < PPW; ++j) {
+            const int p = w + 4 * j;
+            const char* sa;
             if constexpr (!AKS) {
-                const int k = k0 + a_c * SA::EPC;
-                ra[j] = (a_base[j] >= 0 && k + SA::EPC <= kend) ? ld16(g.A.p + (a_base[j] + k) * (long long)sizeof(T)) : zero4;
+                const int k = k0 + a_k[j];
+                sa = (a_ok[j] && k + EPC <= kend) ? a_ptr[j] + (long long)k * SZ : zero;
             } else {
-                const int k = k0 + a_r + j * SA::RSTEP, m = m0 + a_c * SA::EPC;
-                ra[j] = (k < kend && m + SA::EPC <= g.M) ? ld16(g.A.p + (outer_off(g.A, k) + m) * (long long)sizeof(T)) : zero4;
+                const int k = k0 + a_k[j];
+                sa = (a_ok[j] && k < kend) ? a_ptr[j] + (a_q[j] * g.A.bs + a_r[j] * g.A.ld) * SZ : zero;
+                a_r[j] += BK;
+                if (g.A.rpb) while (a_r[j] >= g.A.rpb) { a_r[j] -= g.A.rpb; ++a_q[j]; }
             }
-        }
-#pragma unroll
-        for (int j = 0; j < SB::NCH; ++j) {
+            glds16(sa, ta + p * 1024);
+            const char* sb;
             if constexpr (!BKS) {
-                const int k = k0 + b_c * SB::EPC;
-                rb[j] = (b_base[j] >= 0 && k + SB::EPC <= kend) ? ld16(g.B.p + (b_base[j] + k) * (long long)sizeof(T)) : zero4;
+                const int k = k0 + b_k[j];
+                sb = (b_ok[j] && k + EPC <= kend) ? b_ptr[j] + (long long)k * SZ : zero;
             } else {
-                const int k = k0 + b_r + j * SB::RSTEP, n = n0 + b_c * SB::EPC;
-                rb[j] = (k < kend && n + SB::EPC <= g.N) ? ld16(g.B.p + (outer_off(g.B, k) + n) * (long long)sizeof(T)) : zero4;
+                const int k = k0 + b_k[j];
+                sb = (b_ok[j] && k < kend) ? b_ptr[j] + (b_q[j] * g.B.bs + b_r[j] * g.B.ld) * SZ : zero;
+                b_r[j] += BK;
+                if (g.B.rpb) while (b_r[j] >= g.B.rpb) { b_r[j] -= g.B.rpb; ++b_q[j]; }
             }
+            glds16(sb, tb + p * 1024);
         }
-    };
-    auto lstore = [&](int buf) {
-        char* ta = lds + buf * 2 * TILE_BYTES;
-        char* tb = ta + TILE_BYTES;
-#pragma unroll
-        for (int j = 0; j < SA::NCH; ++j) {
-            const int r = a_r + j * SA::RSTEP;
-            st16(ta + (AKS ? Tile<T>::ks_off(r, a_c) : Tile<T>::kc_off(r, a_c)), ra[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < SB::NCH; ++j) {
-            const int r = b_r + j * SB::RSTEP;
-            st16(tb + (BKS ? Tile<T>::ks_off(r, b_c) : Tile<T>::kc_off(r, b_c)), rb[j]);
-        }
+        (void)kb_issued;
     };
 
     f32x4 acc[4][4];
@@ -124,23 +195,22 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    if (nkb > 0) {
-        gload(0);
-        lstore(0);
-    }
-    __syncthreads();
-    for (int kb = 0; kb < nkb; ++kb) {
-        const int buf = kb & 1;
-        if (kb + 1 < nkb) gload(kb + 1);
-        const char* ta = lds + buf * 2 * TILE_BYTES;
-        const char* tb = ta + TILE_BYTES;
 #pragma unroll
-        for (int ks = 0; ks < BK / MM::KI; ++ks) {
+    for (int s = 0; s < NST - 1; ++s) issue(s);
+    for (int kb = 0; kb < nkb; ++kb) {
+        // stage kb has landed once all but the (NST-2) youngest stages' DMAs of this wave are done (2*PPW per stage per lane)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NST - 2) * 2 * PPW) : "memory");
+        __builtin_amdgcn_s_barrier();
+        issue(kb + NST - 1);                  // refills the buffer every wave finished reading last iteration
+        const char* ta = lds + (kb % NST) * 2 * TILE;
+        const char* tb = ta + TILE;
+#pragma unroll
+        for (int ks = 0; ks < ST::KSTEPS; ++ks) {
             typename MM::Frag fa[4], fb[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                fa[i] = AKS ? Tile<T>::ks_frag(ta, wm * 64 + 16 * i, ks, lane) : Tile<T>::kc_frag(ta, wm * 64 + 16 * i, ks, lane);
-                fb[i] = BKS ? Tile<T>::ks_frag(tb, wn * 64 + 16 * i, ks, lane) : Tile<T>::kc_frag(tb, wn * 64 + 16 * i, ks, lane);
+                fa[i] = AKS ? ST::ks_frag(ta, wm * 64 + 16 * i, ks, lane) : ST::kc_frag(ta, wm * 64 + 16 * i, ks, lane);
+                fb[i] = BKS ? ST::ks_frag(tb, wn * 64 + 16 * i, ks, lane) : ST::kc_frag(tb, wn * 64 + 16 * i, ks, lane);
             }
             // swapped operands: accumulator reg r <-> 4 consecutive n, lane&15 <-> m  (vector C stores)
 #pragma unroll
@@ -148,80 +218,122 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = MM::mma(fb[j], fa[i], acc[i][j]);
         }
-        if (kb + 1 < nkb) lstore(buf ^ 1);
-        __syncthreads();
     }
+    // no DMA may still be in flight, and every wave must be done reading the ring, before LDS is reused
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 
-    // ---- epilogue
-    const int g4 = (lane >> 4) * 4, li = lane & 15;
+    // ---- epilogue through LDS: each wave parks its 64x64 f32 sub-tile in its own 16 KB of the (now free) ring, then
+    // walks it row by row so that every global store / f32 atomic wave-instruction is ONE contiguous row segment
+    // (256 B of f32, 128 B of bf16) instead of 16 rows x 16 B -- the shape the memory-side atomic units need.
+    static_assert(NST * 2 * TILE >= 65536, "epilogue staging needs 64 KB of LDS");
+    float* cw = reinterpret_cast<float*>(lds) + w * 4096;
+    {
+        const int g4 = lane >> 4, li = lane & 15;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + 16 * i + li;
-        if (m >= g.M) continue;
-        const long long crow = g.c_rpb ? (m / g.c_rpb) * g.c_bs + (m % g.c_rpb) * g.ldc : (long long)m * g.ldc;
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + 16 * j + g4;
-            if (n >= g.N) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * g.alpha;
-            if (g.bias) {
-                if (g.bias_rows) {
-                    const float bm = g.bias[m];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += bm;
-                } else {
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(g.bias + n);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += bv[r];
-                }
+            for (int j = 0; j < 4; ++j) {
+                f32x4 v = acc[i][j];
+                v *= g.alpha;
+                *reinterpret_cast<f32x4*>(cw + (16 * i + li) * 64 + (((4 * j + g4) ^ li) << 2)) = v;
             }
-            if (g.zout) {
-                T* zp = reinterpret_cast<T*>(g.zout) + (long long)m * g.ldz + n;
+    }
+    __builtin_amdgcn_wave_barrier();      // the tile is wave-private: program order of this wave's LDS ops suffices
+    const int mw = m0 + wm * 64, nw = n0 + wn * 64;
+    const bool f32_rows = g.out_f32 || sizeof(T) == 4;
+    if (f32_rows) {
+        const int n = nw + lane;
+        const bool n_ok = n < g.N;
+        const float bn = (g.bias && !g.bias_rows && n_ok) ? g.bias[n] : 0.f;
+        for (int rr = 0; rr < 64; ++rr) {
+            const int m = mw + rr;
+            if (m >= g.M) break;
+            float v = cw[rr * 64 + ((((lane >> 2) ^ (rr & 15))) << 2) + (lane & 3)] + bn;
+            if (g.bias && g.bias_rows) v += g.bias[m];
+            if (!n_ok) continue;
+            if (g.zout) reinterpret_cast<T*>(g.zout)[(long long)m * g.ldz + n] = from_f<T>(v);
+            if (g.act == A8_ACT_GELU) v = gelu_f(v);
+            else if (g.act == A8_ACT_MUL_GELU_GRAD) v *= gelu_grad_f(to_f(reinterpret_cast<const T*>(g.zin)[(long long)m * g.ldz + n]));
+            const long long crow = g.c_rpb ? (m / g.c_rpb) * g.c_bs + (m % g.c_rpb) * g.ldc : (long long)m * g.ldc;
+            float* cp = reinterpret_cast<float*>(g.C) + crow + n;
+            if (g.atomic) atomicAdd(cp, v);
+            else *cp = v;
+        }
+    } else {
+        // 16-bit output: lane owns 8 consecutive columns (16 B), a wave-instruction covers 8 rows x 128 B
+        const int c8 = (lane & 7) << 3;                 // first column within the wave's 64
+        const int n = nw + c8;
+        const bool n_ok = n < g.N;
+        float bn[8];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) zp[r] = from_f<T>(v[r]);
+        for (int e = 0; e < 8; ++e) bn[e] = (g.bias && !g.bias_rows && n_ok) ? g.bias[n + e] : 0.f;
+        typedef T T8 __attribute__((ext_vector_type(8)));
+        for (int it = 0; it < 8; ++it) {
+            if (mw + 8 * it >= g.M) break;
+            const int rr = 8 * it + (lane >> 3);
+            const int m = mw + rr;
+            const int ch = c8 >> 2;                      // even 16-byte chunk index; its partner is ch + 1
+            const f32x4 p0 = *reinterpret_cast<const f32x4*>(cw + rr * 64 + ((ch ^ (rr & 15)) << 2));
+            const f32x4 p1 = *reinterpret_cast<const f32x4*>(cw + rr * 64 + (((ch + 1) ^ (rr & 15)) << 2));
+            if (m >= g.M || !n_ok) continue;
+            float v[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+            const float bm = (g.bias && g.bias_rows) ? g.bias[m] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bn[e] + bm;
+            if (g.zout) {
+                T8 zv;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) zv[e] = from_f<T>(v[e]);
+                *reinterpret_cast<T8*>(reinterpret_cast<T*>(g.zout) + (long long)m * g.ldz + n) = zv;
             }
             if (g.act == A8_ACT_GELU) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+                for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
             } else if (g.act == A8_ACT_MUL_GELU_GRAD) {
-                const T* zp = reinterpret_cast<const T*>(g.zin) + (long long)m * g.ldz + n;
+                const T8 zz = *reinterpret_cast<const T8*>(reinterpret_cast<const T*>(g.zin) + (long long)m * g.ldz + n);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_f(to_f(zp[r]));
+                for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(to_f(zz[e]));
             }
-            if (g.out_f32) {
-                float* cp = reinterpret_cast<float*>(g.C) + crow + n;
-                if (g.atomic) {
+            const long long crow = g.c_rpb ? (m / g.c_rpb) * g.c_bs + (m % g.c_rpb) * g.ldc : (long long)m * g.ldc;
+            T8 ov;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) atomicAdd(cp + r, v[r]);
-                } else {
-                    *reinterpret_cast<f32x4*>(cp) = (f32x4){v[0], v[1], v[2], v[3]};
-                }
-            } else {
-                T* cp = reinterpret_cast<T*>(g.C) + crow + n;
-                if constexpr (sizeof(T) == 2) {
-                    bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                    *reinterpret_cast<bf16x4*>(cp) = o;
-                } else {
-                    *reinterpret_cast<f32x4*>(cp) = (f32x4){v[0], v[1], v[2], v[3]};
-                }
-            }
+            for (int e = 0; e < 8; ++e) ov[e] = from_f<T>(v[e]);
+            *reinterpret_cast<T8*>(reinterpret_cast<T*>(g.C) + crow + n) = ov;
         }
     }
 }
 
-template <typename T> int launch(const a8_gemm_desc* d, const GemmArgs& g, int grid, hipStream_t s) {
+int g_variant = 2;      // tuning knob (a8_set_tuning): 0 = 128 B of K per row x 3 stages, 1 = 64 B x 4, 2 = 128 B x 2 (default: measured best), 3 = 64 B x 5
+
+template <typename T, int KB, int NST> int launch2(const a8_gemm_desc* d, const GemmArgs& g, int grid, hipStream_t s) {
     switch (d->layout) {
-        case A8_GEMM_NT: hipLaunchKernelGGL((gemm_kernel<T, false, false>), dim3(grid), dim3(256), 0, s, g); break;
-        case A8_GEMM_NN: hipLaunchKernelGGL((gemm_kernel<T, false, true>), dim3(grid), dim3(256), 0, s, g); break;
-        case A8_GEMM_TN: hipLaunchKernelGGL((gemm_kernel<T, true, true>), dim3(grid), dim3(256), 0, s, g); break;
+        case A8_GEMM_NT: hipLaunchKernelGGL((gemm_kernel<T, false, false, KB, NST>), dim3(grid), dim3(256), 0, s, g); break;
+        case A8_GEMM_NN: hipLaunchKernelGGL((gemm_kernel<T, false, true, KB, NST>), dim3(grid), dim3(256), 0, s, g); break;
+        case A8_GEMM_TN: hipLaunchKernelGGL((gemm_kernel<T, true, true, KB, NST>), dim3(grid), dim3(256), 0, s, g); break;
         default: return a8_set_error(A8_ERR_ARG, "a8_gemm: bad layout %d", d->layout);
     }
     return a8_check_launch("a8_gemm");
 }
+template <typename T> int launch(const a8_gemm_desc* d, const GemmArgs& g, int grid, hipStream_t s) {
+    if constexpr (sizeof(T) == 2) {
+        switch (g_variant) {
+            case 1: return launch2<T, 1, 4>(d, g, grid, s);
+            case 2: return launch2<T, 2, 2>(d, g, grid, s);
+            case 3: return launch2<T, 1, 5>(d, g, grid, s);
+            default: return launch2<T, 2, 3>(d, g, grid, s);
+        }
+    } else {
+        return launch2<T, 1, 4>(d, g, grid, s);
+    }
+}
 
 }  // namespace
+
+extern "C" int a8_set_tuning(int key, int value) {
+    if (key == 0) { g_variant = value; return A8_OK; }
+    return a8_set_error(A8_ERR_ARG, "a8_set_tuning: unknown key %d", key);
+}
 
 extern "C" int a8_gemm(const a8_gemm_desc* d, void* stream) {
     A8_REQUIRE(d != nullptr, "a8_gemm: null descriptor");
@@ -230,14 +342,15 @@ extern "C" int a8_gemm(const a8_gemm_desc* d, void* stream) {
     if (d->M == 0) return A8_OK;
     const int esz = d->dtype == A8_BF16 ? 2 : 4, epc = 16 / esz;
     const bool aks = d->layout == A8_GEMM_TN, bks = d->layout != A8_GEMM_NT;
-    A8_REQUIRE(d->N % 4 == 0, "a8_gemm: N=%d must be a multiple of 4", d->N);
+    A8_REQUIRE(d->N % 8 == 0 || (d->N % 4 == 0 && (d->out_f32 || d->dtype == A8_F32)), "a8_gemm: N=%d must be a multiple of 8 (4 for f32 output)", d->N);
+    A8_REQUIRE(d->out_f32 || d->dtype == A8_F32 || (d->ldc % 8 == 0 && (!d->zout && !d->zin || d->ldz % 8 == 0)), "a8_gemm: ldc/ldz must be multiples of 8 for 16-bit output");
     if (!aks || !bks) A8_REQUIRE(d->K % epc == 0, "a8_gemm: K=%d must be a multiple of %d for a K-contiguous operand", d->K, epc);
     if (aks) A8_REQUIRE(d->M % epc == 0, "a8_gemm: M=%d must be a multiple of %d (TN)", d->M, epc);
     if (bks) A8_REQUIRE(d->N % epc == 0, "a8_gemm: N=%d must be a multiple of %d (NN/TN)", d->N, epc);
     A8_REQUIRE(d->lda % epc == 0 && d->ldb % epc == 0 && d->ldc % 4 == 0, "a8_gemm: leading dimensions must keep 16-byte alignment");
     A8_REQUIRE(((uintptr_t)d->A % 16) == 0 && ((uintptr_t)d->B % 16) == 0 && ((uintptr_t)d->C % 16) == 0, "a8_gemm: pointers must be 16-byte aligned");
     A8_REQUIRE(d->a_bs % epc == 0 && d->b_bs % epc == 0, "a8_gemm: batch strides must keep 16-byte alignment");
-    const int bk = d->dtype == A8_BF16 ? 64 : 16;
+    const int bk = d->dtype == A8_BF16 ? ((g_variant == 1 || g_variant == 3) ? 32 : 64) : 16;
     GemmArgs g;
     g.A = Op{(const char*)d->A, d->lda, d->a_rpb, d->a_bs};
     g.B = Op{(const char*)d->B, d->ldb, d->b_rpb, d->b_bs};

@@ -49,6 +49,8 @@ typedef struct a8_gemm_desc {
     float alpha;
 } a8_gemm_desc;
 int a8_gemm(const a8_gemm_desc* d, void* stream);
+/* developer tuning knob (key 0: GEMM stage geometry variant); never needed for correctness */
+int a8_set_tuning(int key, int value);
 
 /* ---- conv layer 0 + GroupNorm + GELU (audio8/wav2vec2.py:417-423, Cin=1, k=10, s=5) --------------
  * x f32 [B,L]; w f32 [C,10]; out dtype [B,L0,C] channels-last; stats f32 [B,C,2] = (mean, rstd).
