@@ -467,7 +467,7 @@ extern "C" int a8_layernorm_bwd(int dtype, const void* dy, const void* dy2, cons
     A8_REQUIRE(cols % 8 == 0 && cols <= MAXC * 512, "a8_layernorm_bwd: cols=%d must be a multiple of 8 and <= %d", cols, MAXC * 512);
     if (rows == 0) return A8_OK;
     const Drop dr = make_drop(p, seed, rng_stream);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(ln_bwd_kernel<T>, dim3(grid_for(rows, 8)), dim3(256), 0, (hipStream_t)stream,
+    DISPATCH_T(dtype, hipLaunchKernelGGL(ln_bwd_kernel<T>, dim3(grid_for(rows, 16)), dim3(256), 0, (hipStream_t)stream,
                                          (const T*)dy, (const T*)dy2, (const T*)x, (const T*)res, gamma, mean, rstd, (T*)dx, (T*)dres,
                                          dgamma, dbeta, rows, cols, dr));
     return a8_check_launch("a8_layernorm_bwd");

@@ -87,6 +87,27 @@ def colsum(x2d, out=None):
 # parameter's gradient has been enqueued on the stream.
 DIRECT_GRADS = False
 GRAD_READY_HOOK = None
+# Weight-gradient GEMMs do not feed the backward critical path.  With direct accumulation on, they are issued on
+# a side HIP stream (behind an event on their inputs) so their small grids co-run with the data-gradient chain.
+# The owner of DIRECT_GRADS (trainer.Stepper) joins the side stream before it reads the gradients.
+WGRAD_SIDE_STREAM = None
+
+
+def _on_side(fn, *inputs):
+    """Run fn() on the wgrad side stream after everything enqueued so far on the current stream."""
+    side = WGRAD_SIDE_STREAM
+    if side is None:
+        fn()
+        return
+    cur = torch.cuda.current_stream()
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    side.wait_event(ev)
+    with torch.cuda.stream(side):
+        fn()
+    for t in inputs:
+        if t is not None:
+            t.record_stream(side)
 
 
 def _target(p):
@@ -107,8 +128,11 @@ def acc_wgrad(p, dy, x, n_out, n_in, m, **kw):
     tgt = _target(p)
     if tgt is None:
         return wgrad(dy, x, n_out, n_in, m, **kw)
-    K.gemm(L.TN, dy, x, n_out, n_in, m, out=tgt, accumulate=True, splitk=_splitk(_tiles(n_out, n_in), m), **kw)
-    _ready(p)
+
+    def run():
+        K.gemm(L.TN, dy, x, n_out, n_in, m, out=tgt, accumulate=True, splitk=_splitk(_tiles(n_out, n_in), m), **kw)
+        _ready(p)
+    _on_side(run, dy, x)
     return None
 
 
@@ -487,8 +511,13 @@ class EncoderLayerFn(torch.autograd.Function):
         tw, tb = [_target(w) for w in (wq, wk, wv)], [_target(b) for b in (bq, bk, bv)]
         if all(t is not None for t in tw + tb) and _adjacent(*tw) and _adjacent(*tb):
             colsum(dqkv, _span3(tb[0], (3 * d,)))
-            K.gemm(L.TN, dqkv, x, 3 * d, d, M, out=_span3(tw[0], (3 * d, d)), accumulate=True, splitk=_splitk(_tiles(3 * d, d), M))
-            _ready(wq, bq, wk, bk, wv, bv)
+            _ready(bq, bk, bv)
+            wspan = _span3(tw[0], (3 * d, d))
+
+            def run_qkv():
+                K.gemm(L.TN, dqkv, x, 3 * d, d, M, out=wspan, accumulate=True, splitk=_splitk(_tiles(3 * d, d), M))
+                _ready(wq, wk, wv)
+            _on_side(run_qkv, dqkv, x)
             gq = (None,) * 6
         else:
             dbqkv = colsum(dqkv)

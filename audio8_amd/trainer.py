@@ -94,6 +94,7 @@ class GradReducer:
             for i in bk["members"]:
                 self.bucket_of[i] = b
         self.handles = []
+        self.extra_streams = []
         self.index_of = {id(p): i for i, p in enumerate(state.params)}
         if self.enabled:
             for i, p in enumerate(state.params):
@@ -123,6 +124,9 @@ class GradReducer:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self.side.wait_event(ev)
+            for s2 in self.extra_streams:              # gradients may have been produced on the wgrad side stream too
+                if s2 is not None:
+                    self.side.wait_stream(s2)
             with torch.cuda.stream(self.side):
                 h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         else:                                            # gloo on CPU (tests): same bucket schedule, no streams
@@ -153,7 +157,7 @@ class GradReducer:
 class Stepper:
     """clip_grad_norm_(max_norm) + AdamW on the flat buffers; gradients are averaged over ranks inside the update."""
 
-    def __init__(self, model, lr=2.0e-4, weight_decay=1.0e-2, betas=(0.9, 0.999), eps=1e-8, clip=1.0, bucket_mb=32.0, lr_function=None):
+    def __init__(self, model, lr=2.0e-4, weight_decay=1.0e-2, betas=(0.9, 0.999), eps=1e-8, clip=1.0, bucket_mb=32.0, lr_function=None, wgrad_side_stream=True):
         self.state = FlatState(model)
         self.reducer = GradReducer(self.state, bucket_mb)
         self.lr, self.wd, self.betas, self.eps, self.clip = lr, weight_decay, betas, eps, clip
@@ -162,6 +166,9 @@ class Stepper:
         self.gnorm_sq = torch.zeros(1, device=self.state.flat_p.device, dtype=torch.float32)
         ops.DIRECT_GRADS = True
         ops.GRAD_READY_HOOK = self.reducer.param_ready
+        self.wgrad_stream = torch.cuda.Stream() if (wgrad_side_stream and self.state.flat_p.is_cuda) else None
+        ops.WGRAD_SIDE_STREAM = self.wgrad_stream
+        self.reducer.extra_streams = [self.wgrad_stream, torch.cuda.current_stream() if self.state.flat_p.is_cuda else None]
         if self.reducer.enabled:                         # C1 of SURVEY 2.2: rank 0's parameters everywhere
             dist.broadcast(self.state.flat_p, src=0)
 
@@ -174,6 +181,8 @@ class Stepper:
         self.reducer.begin_step()
 
     def step(self):
+        if self.wgrad_stream is not None:                # join the weight-gradient stream before gradients are read
+            torch.cuda.current_stream().wait_stream(self.wgrad_stream)
         self.reducer.finish()
         self.global_step += 1
         scale = 1.0 / self.reducer.world

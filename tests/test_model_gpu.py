@@ -246,3 +246,4 @@ def test_direct_grad_accumulation_and_stepper_match_autograd(restore_dtype):
     finally:
         ops.DIRECT_GRADS = False
         ops.GRAD_READY_HOOK = None
+        ops.WGRAD_SIDE_STREAM = None
