@@ -33,6 +33,10 @@ class GemmDesc(C.Structure):
     ]
 
 
+class WPrepDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("dstT", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("kw", C.c_int)]
+
+
 def lib():
     """Load (once) and return the HIP library; raise if it is not built."""
     global _lib
@@ -76,7 +80,7 @@ def require_cuda(*ts):
 
 
 EXPORTS = [
-    "a8_version", "a8_last_error", "a8_gemm", "a8_set_tuning",
+    "a8_version", "a8_last_error", "a8_gemm", "a8_set_tuning", "a8_prepare_weights",
     "a8_conv0_gn_gelu_fwd", "a8_conv0_gn_gelu_bwd", "a8_col2im_gelu_grad",
     "a8_layernorm_fwd", "a8_layernorm_bwd",
     "a8_cast", "a8_dropout", "a8_mask_fill_rows", "a8_mask_fill_rows_bwd", "a8_mask_zero_cols", "a8_zero_rows",

@@ -98,25 +98,20 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     }
 }
 
-// Column sums held per wave in registers -> LDS -> one atomic per column per block.
-// acc[c][i] belongs to column (lane + 64c)*8 + i.  lds: float[cols].
+// Column sums held per wave in registers -> LDS [4][cols] (one slab per wave, no serial phases) -> one atomic
+// per column per block.  acc[c][i] belongs to column (lane + 64c)*8 + i.  lds: float[4 * cols].
 A8_DEV void flush_colsum(float (&acc)[MAXC][8], float* lds, float* __restrict__ out, int cols) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nch = cols >> 3;
-    for (int i = threadIdx.x; i < cols; i += 256) lds[i] = 0.f;
     __syncthreads();
-    for (int ww = 0; ww < 4; ++ww) {
-        if (w == ww) {
 #pragma unroll
-            for (int c = 0; c < MAXC; ++c)
-                if (lane + 64 * c < nch) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) lds[(lane + 64 * c) * 8 + i] += acc[c][i];
-                }
+    for (int c = 0; c < MAXC; ++c)
+        if (lane + 64 * c < nch) {
+            float* p = lds + w * cols + (lane + 64 * c) * 8;
+            *reinterpret_cast<f32x4*>(p) = (f32x4){acc[c][0], acc[c][1], acc[c][2], acc[c][3]};
+            *reinterpret_cast<f32x4*>(p + 4) = (f32x4){acc[c][4], acc[c][5], acc[c][6], acc[c][7]};
         }
-        __syncthreads();
-    }
-    for (int i = threadIdx.x; i < cols; i += 256) atomicAdd(out + i, lds[i]);
     __syncthreads();
+    for (int i = threadIdx.x; i < cols; i += 256) atomicAdd(out + i, lds[i] + lds[cols + i] + lds[2 * cols + i] + lds[3 * cols + i]);
 }
 
 // ------------------------------------------------------------------ LayerNorm backward
@@ -127,7 +122,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      const float* __restrict__ rstd, T* __restrict__ dx, T* __restrict__ dres,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                      int rows, int cols, Drop dr) {
-    __shared__ float lds[MAXC * 512];
+    __shared__ __attribute__((aligned(16))) float lds[4 * MAXC * 512];
     const int lane = threadIdx.x & 63, nch = cols >> 3;
     const float inv = 1.0f / (float)cols;
     float ag[MAXC][8], ab[MAXC][8];
@@ -250,7 +245,7 @@ __global__ void mask_fill_rows_kernel(T* __restrict__ x, const uint8_t* __restri
 }
 template <typename T>
 __global__ __launch_bounds__(256) void mask_fill_rows_bwd_kernel(T* __restrict__ dy, const uint8_t* __restrict__ mask, float* __restrict__ demb, int rows, int cols) {
-    __shared__ float lds[MAXC * 512];
+    __shared__ __attribute__((aligned(16))) float lds[4 * MAXC * 512];
     const int lane = threadIdx.x & 63, nch = cols >> 3;
     float ab[MAXC][8];
 #pragma unroll
@@ -467,7 +462,7 @@ extern "C" int a8_layernorm_bwd(int dtype, const void* dy, const void* dy2, cons
     A8_REQUIRE(cols % 8 == 0 && cols <= MAXC * 512, "a8_layernorm_bwd: cols=%d must be a multiple of 8 and <= %d", cols, MAXC * 512);
     if (rows == 0) return A8_OK;
     const Drop dr = make_drop(p, seed, rng_stream);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(ln_bwd_kernel<T>, dim3(grid_for(rows, 16)), dim3(256), 0, (hipStream_t)stream,
+    DISPATCH_T(dtype, hipLaunchKernelGGL(ln_bwd_kernel<T>, dim3(grid_for(rows, 12)), dim3(256), 0, (hipStream_t)stream,
                                          (const T*)dy, (const T*)dy2, (const T*)x, (const T*)res, gamma, mean, rstd, (T*)dx, (T*)dres,
                                          dgamma, dbeta, rows, cols, dr));
     return a8_check_launch("a8_layernorm_bwd");

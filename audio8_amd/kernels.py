@@ -321,3 +321,8 @@ def sumsq_(x, out):
 def adamw_(p, g, m, v, lr, beta1, beta2, eps, wd, step, gnorm_sq=None, max_norm=0.0, grad_scale=1.0):
     L.check(L.lib().a8_adamw(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), C.c_int64(p.numel()), _f(lr), _f(beta1), _f(beta2), _f(eps), _f(wd),
                              int(step), L.ptr(gnorm_sq), _f(max_norm), _f(grad_scale), L.stream()), "a8_adamw")
+
+
+# ----------------------------------------------------------------------------- weight preparation
+def prepare_weights(dtype_code, desc_array, n):
+    L.check(L.lib().a8_prepare_weights(dtype_code, desc_array, n, L.stream()), "a8_prepare_weights")

@@ -46,6 +46,25 @@ def reset_seed_stream():
     _SEED_STATE["ctr"] = 0
 
 
+# Prepared working copies of the weights, refreshed once per optimizer step by trainer.Stepper with ONE C call:
+# id(param) -> (W2 [rows, cols] compute dtype, W2^T [cols, rows]); the fused QKV matrix is keyed by the w_Q weight.
+WEIGHT_CACHE = None
+WEIGHT_CACHE_DTYPE = None
+
+
+def cached_weights(p, dtype):
+    if WEIGHT_CACHE is not None and dtype == WEIGHT_CACHE_DTYPE:
+        return WEIGHT_CACHE.get(id(p))
+    return None
+
+
+def _dgrad(dy, wc, wcT, M, n_in, k_out, **kw):
+    """dx[M, n_in] = dy[M, k_out] . W[k_out, n_in]: K-contiguous NT GEMM on the prepared transpose when there is one."""
+    if wcT is not None:
+        return K.gemm(L.NT, dy, wcT, M, n_in, k_out, **kw)
+    return K.gemm(L.NN, dy, wc, M, n_in, k_out, **kw)
+
+
 def _wcast(w, dtype):
     """Working copy of an f32 master weight in the compute dtype."""
     return w.detach() if dtype == torch.float32 else K.cast(w.detach().contiguous(), dtype)
@@ -171,10 +190,12 @@ class LinearFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, out_f32):
         M, Kd = x.shape
         N = weight.shape[0]
-        wc = _wcast(weight, x.dtype)
+        e = cached_weights(weight, x.dtype)
+        wc, wcT = e if e is not None else (_wcast(weight, x.dtype), None)
         y = K.gemm(L.NT, x, wc, M, N, Kd, bias=bias.detach() if bias is not None else None,
                    out_dtype=torch.float32 if out_f32 else x.dtype)
         ctx.save_for_backward(x, wc)
+        ctx.wcT = wcT
         ctx.has_bias = bias is not None
         ctx.params = (weight, bias)
         return y
@@ -188,7 +209,7 @@ class LinearFn(torch.autograd.Function):
         dy = dy.contiguous()
         if dy.dtype != x.dtype:
             dy = K.cast(dy, x.dtype)
-        dx = K.gemm(L.NN, dy, wc, M, Kd, N) if ctx.needs_input_grad[0] else None
+        dx = _dgrad(dy, wc, ctx.wcT, M, Kd, N) if ctx.needs_input_grad[0] else None
         dw = acc_wgrad(weight, dy, x, N, Kd, M) if ctx.needs_input_grad[1] else None
         db = acc_colsum(bias, dy) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db, None
@@ -327,12 +348,17 @@ class ConvStackFn(torch.autograd.Function):
         B, Ls = x.shape
         x = x.contiguous().float()
         a, stats = K.conv0_gn_gelu_fwd(x, ws[0].detach().contiguous(), gn_w.detach(), gn_b.detach(), dtype)
-        acts, zs, wcs, lens = [a], [None], [None], [a.shape[1]]
+        acts, zs, wcs, lens, wcTs = [a], [None], [None], [a.shape[1]], [None]
         for i in range(1, len(ws)):
             co, k, s = feats[i]
             cin = ws[i].shape[1]
-            w2 = ws[i].detach().permute(0, 2, 1).reshape(co, k * cin)            # [co][kk*cin + ci]
-            wc = w2.contiguous() if dtype == torch.float32 else K.cast(w2.contiguous(), dtype)
+            e = cached_weights(ws[i], dtype)
+            if e is not None:
+                wc, wcT = e
+            else:
+                w2 = ws[i].detach().permute(0, 2, 1).reshape(co, k * cin)        # [co][kk*cin + ci]
+                wc, wcT = (w2.contiguous() if dtype == torch.float32 else K.cast(w2.contiguous(), dtype)), None
+            wcTs.append(wcT)
             Lin = lens[-1]
             Lout = (Lin - k) // s + 1
             z = torch.empty((B * Lout, co), device=x.device, dtype=dtype)
@@ -342,6 +368,7 @@ class ConvStackFn(torch.autograd.Function):
             wcs.append(wc)
             lens.append(Lout)
         ctx.feats, ctx.lens, ctx.B = feats, lens, B
+        ctx.wcTs = wcTs
         ctx.params = (ws[0], gn_w, gn_b)
         ctx.save_for_backward(x, gn_w, gn_b, stats, ws[0], *acts[:-1], *zs[1:], *wcs[1:])
         ctx.nl = len(ws)
@@ -369,7 +396,7 @@ class ConvStackFn(torch.autograd.Function):
             M = B * Lout
             dw2 = wgrad(dz, acts[i - 1], co, k * cin, M, ldb=s * cin, b_rpb=Lout, b_bs=Lin * cin)
             grads[i] = dw2.view(co, k, cin).permute(0, 2, 1).contiguous()
-            dcol = K.gemm(L.NN, dz, wcs[i], M, k * cin, co)
+            dcol = _dgrad(dz, wcs[i], ctx.wcTs[i], M, k * cin, co)
             dz = K.col2im_gelu_grad(dcol, zs[i - 1] if i - 1 >= 1 else None, B, Lin, Lout, cin, k, s).view(-1, cin)
             del dcol
         pw0, pgw, pgb = ctx.params
@@ -438,12 +465,18 @@ class EncoderLayerFn(torch.autograd.Function):
         M, d = x.shape
         dt = x.dtype
         dff = w1.shape[0]
-        if _adjacent(wq, wk, wv) and _adjacent(bq, bk, bv):          # FlatState layout: no concatenation needed
-            wqkv, bqkv = _span3(wq.detach(), (3 * d, d)), _span3(bq.detach(), (3 * d,))
+        fused = _adjacent(wq, wk, wv) and _adjacent(bq, bk, bv)      # FlatState layout: no concatenation needed
+        bqkv = _span3(bq.detach(), (3 * d,)) if fused else torch.cat([bq.detach(), bk.detach(), bv.detach()], 0)
+        eq = cached_weights(wq, dt) if fused else None
+        if eq is not None:
+            wqkv_c, wqkv_t = eq
         else:
-            wqkv = torch.cat([wq.detach(), wk.detach(), wv.detach()], 0)
-            bqkv = torch.cat([bq.detach(), bk.detach(), bv.detach()], 0)
-        wqkv_c, wo_c, w1_c, w2_c = _wcast(wqkv, dt), _wcast(wo, dt), _wcast(w1, dt), _wcast(w2, dt)
+            wqkv = _span3(wq.detach(), (3 * d, d)) if fused else torch.cat([wq.detach(), wk.detach(), wv.detach()], 0)
+            wqkv_c, wqkv_t = _wcast(wqkv, dt), None
+        eo, e1, e2 = cached_weights(wo, dt), cached_weights(w1, dt), cached_weights(w2, dt)
+        wo_c, wo_t = eo if eo is not None else (_wcast(wo, dt), None)
+        w1_c, w1_t = e1 if e1 is not None else (_wcast(w1, dt), None)
+        w2_c, w2_t = e2 if e2 is not None else (_wcast(w2, dt), None)
         qkv = K.gemm(L.NT, x, wqkv_c, M, 3 * d, d, bias=bqkv)
         seed_a = next_seed() if p > 0 else 0
         o, lse = K.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, T, H, 3 * d, 1.0 / math.sqrt(d // H), keymask, p, seed_a)
@@ -458,6 +491,7 @@ class EncoderLayerFn(torch.autograd.Function):
         ctx.save_for_backward(x, keymask, qkv, o, lse, ao, x1, mean2, rstd2, z1, h, f, mean1, rstd1,
                               wqkv_c, wo_c, w1_c, w2_c, g1, g2)
         ctx.cfg = (B, T, H, p, seed_a, seed1, seed2)
+        ctx.wts = (wqkv_t, wo_t, w1_t, w2_t)
         ctx.params = (wq, bq, wk, bk, wv, bv, wo, bo, w1, b1, w2, b2, g1, be1, g2, be2)
         return x2
 
@@ -490,10 +524,11 @@ class EncoderLayerFn(torch.autograd.Function):
         # FFN
         db2 = acc_colsum(b2, df)
         dw2 = acc_wgrad(w2, df, h, d, dff, M)
-        dz1 = K.gemm(L.NN, df, w2_c, M, dff, d, act=L.ACT_MUL_GELU_GRAD, zin=z1, ldz=dff)
+        wqkv_t, wo_t, w1_t, w2_t = ctx.wts
+        dz1 = _dgrad(df, w2_c, w2_t, M, dff, d, act=L.ACT_MUL_GELU_GRAD, zin=z1, ldz=dff)
         db1 = acc_colsum(b1, dz1)
         dw1 = acc_wgrad(w1, dz1, x1, dff, d, M)
-        dx1_ffn = K.gemm(L.NN, dz1, w1_c, M, d, dff)
+        dx1_ffn = _dgrad(dz1, w1_c, w1_t, M, d, dff)
         # ln2: x1 = LN(x + drop(ao))
         dao, dx_res = K.layernorm_bwd(dx1_res, dx1_ffn, ao, x, g2.detach(), mean2, rstd2, dg2, dbe2, p, seed1, 3, want_dx=True, want_dres=p > 0)
         if p == 0:
@@ -504,7 +539,7 @@ class EncoderLayerFn(torch.autograd.Function):
         # output projection
         dbo = acc_colsum(bo, dao)
         dwo = acc_wgrad(wo, dao, o, d, d, M)
-        do = K.gemm(L.NN, dao, wo_c, M, d, d)
+        do = _dgrad(dao, wo_c, wo_t, M, d, d)
         # attention core
         _, _, _, dqkv = K.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, do, lse, B, T, H, 3 * d, 1.0 / math.sqrt(d // H),
                                    keymask, p, seed_a)
@@ -523,7 +558,7 @@ class EncoderLayerFn(torch.autograd.Function):
             dbqkv = colsum(dqkv)
             dwqkv = wgrad(dqkv, x, 3 * d, d, M)
             gq = (dwqkv[:d], dbqkv[:d], dwqkv[d:2 * d], dbqkv[d:2 * d], dwqkv[2 * d:], dbqkv[2 * d:])
-        dx_qkv = K.gemm(L.NN, dqkv, wqkv_c, M, d, 3 * d)
+        dx_qkv = _dgrad(dqkv, wqkv_c, wqkv_t, M, d, 3 * d)
         dx = K.add(dx_res, dx_qkv)
         return (dx, None, None, None, None, None, None, *gq, dwo, dbo, dw1, db1, dw2, db2, dg1, dbe1, dg2, dbe2)
 

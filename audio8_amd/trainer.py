@@ -15,6 +15,7 @@ import os
 import torch
 import torch.distributed as dist
 
+from . import _lib as L
 from . import kernels as K
 from . import ops
 
@@ -66,6 +67,53 @@ class FlatState:
         for p, o in zip(self.params, self.offsets):      # keep .grad bound to the flat views
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
                 p.grad = self.flat_g[o:o + p.numel()].view_as(p)
+
+
+class WeightCache:
+    """bf16 working copies (and transposes) of every GEMM weight, rebuilt from the f32 masters by ONE C call per
+    optimizer step (a8_prepare_weights).  Registered in ops.WEIGHT_CACHE; see ops.cached_weights."""
+
+    def __init__(self, model: torch.nn.Module, dtype=torch.bfloat16):
+        from .layers import MultiHeadedAttention
+        self.dtype = dtype
+        entries = []            # (key_param, src_tensor, rows, cols, kw)
+        fused = set()
+        for m in model.modules():
+            if isinstance(m, MultiHeadedAttention):
+                wq, wk, wv = m.w_Q.layer.weight, m.w_K.layer.weight, m.w_V.layer.weight
+                if ops._adjacent(wq, wk, wv):
+                    d = wq.shape[1]
+                    entries.append((wq, wq, 3 * wq.shape[0], d, 1))
+                    fused.update((id(wq), id(wk), id(wv)))
+        for n, p in model.named_parameters():
+            if id(p) in fused or not p.requires_grad:
+                continue
+            if p.dim() == 2 and "quantizer" not in n:
+                entries.append((p, p, p.shape[0], p.shape[1], 1))
+            elif p.dim() == 3 and p.shape[1] > 1 and "pos_conv" not in n and "quantizer" not in n:
+                entries.append((p, p, p.shape[0], p.shape[1] * p.shape[2], p.shape[2]))
+        dev = next(model.parameters()).device
+        total = sum(r * c for _, _, r, c, _ in entries)
+        self.arena = torch.empty(total + 8, device=dev, dtype=dtype)
+        self.arena_t = torch.empty(total + 8, device=dev, dtype=dtype)
+        self.n = len(entries)
+        self.descs = (L.WPrepDesc * self.n)()
+        self.cache = {}
+        self.params = [e[0] for e in entries]
+        off = 0
+        for i, (key, src, r, c, kw) in enumerate(entries):
+            dst = self.arena[off:off + r * c].view(r, c)
+            dst_t = self.arena_t[off:off + r * c].view(c, r)
+            off += (r * c + 7) // 8 * 8
+            self.descs[i] = L.WPrepDesc(src.data_ptr(), dst.data_ptr(), dst_t.data_ptr(), r, c, kw)
+            self.cache[id(key)] = (dst, dst_t)
+        self._src_ptrs = [e[1].data_ptr() for e in entries]
+
+    def refresh(self):
+        for i, p in enumerate(self.params):               # parameters may have been re-pointed (e.g. .to(), load)
+            if p.data_ptr() != self._src_ptrs[i]:
+                raise RuntimeError("WeightCache: a parameter's storage moved; rebuild the Stepper")
+        K.prepare_weights(L.dt(self.arena), self.descs, self.n)
 
 
 class GradReducer:
@@ -169,6 +217,12 @@ class Stepper:
         self.wgrad_stream = torch.cuda.Stream() if (wgrad_side_stream and self.state.flat_p.is_cuda) else None
         ops.WGRAD_SIDE_STREAM = self.wgrad_stream
         self.reducer.extra_streams = [self.wgrad_stream, torch.cuda.current_stream() if self.state.flat_p.is_cuda else None]
+        self.wcache = None
+        if self.state.flat_p.is_cuda and ops.compute_dtype() == torch.bfloat16:
+            self.wcache = WeightCache(model, torch.bfloat16)
+            self.wcache.refresh()
+            ops.WEIGHT_CACHE, ops.WEIGHT_CACHE_DTYPE = self.wcache.cache, torch.bfloat16
+        self._versions = [p._version for p in self.state.params]
         if self.reducer.enabled:                         # C1 of SURVEY 2.2: rank 0's parameters everywhere
             dist.broadcast(self.state.flat_p, src=0)
 
@@ -176,9 +230,25 @@ class Stepper:
     def current_lr(self):
         return self.lr_function(self.global_step) if self.lr_function else self.lr
 
+    def refresh_weights(self):
+        """Rebuild the bf16 working copies (call after changing parameters outside step(), e.g. load_state_dict)."""
+        if self.wcache is not None:
+            self.wcache.refresh()
+        self._versions = [p._version for p in self.state.params]
+
     def zero_grad(self):
+        if self.wcache is not None and any(p._version != v for p, v in zip(self.state.params, self._versions)):
+            self.refresh_weights()                        # someone wrote to a parameter through torch since the last step
         self.state.zero_grad()
         self.reducer.begin_step()
+
+    def close(self):
+        """Detach the global hooks this Stepper installed in audio8_amd.ops."""
+        ops.DIRECT_GRADS = False
+        ops.GRAD_READY_HOOK = None
+        ops.WGRAD_SIDE_STREAM = None
+        ops.WEIGHT_CACHE = None
+        ops.WEIGHT_CACHE_DTYPE = None
 
     def step(self):
         if self.wgrad_stream is not None:                # join the weight-gradient stream before gradients are read
@@ -190,6 +260,8 @@ class Stepper:
         K.sumsq_(self.state.flat_g, self.gnorm_sq)
         K.adamw_(self.state.flat_p, self.state.flat_g, self.state.flat_m, self.state.flat_v, self.current_lr, self.betas[0], self.betas[1],
                  self.eps, self.wd, self.global_step, self.gnorm_sq, self.clip, scale)
+        if self.wcache is not None:
+            self.wcache.refresh()
 
 
 def init_distributed_from_env():

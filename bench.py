@@ -36,6 +36,7 @@ def cpu_baseline(args):
     sequence on this host's cores, on a bounded sample of the workload."""
     from oracle import ref_cpu as R
     B, L = args.cpu_batch, args.samples
+    torch.set_num_threads(min(args.cpu_threads, os.cpu_count() or 1))       # the GPU box's CPU share for one GPU is 16
     torch.manual_seed(0)
     np.random.seed(0)
     sd = {k: v.clone().requires_grad_(True) for k, v in R.init_state_dict(seed=0).items()}
@@ -70,6 +71,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=1)
     ap.add_argument("--cpu-steps", type=int, default=1)
+    ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--bucket-mb", type=float, default=32.0)
     args = ap.parse_args()
 

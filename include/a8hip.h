@@ -52,6 +52,11 @@ int a8_gemm(const a8_gemm_desc* d, void* stream);
 /* developer tuning knob (key 0: GEMM stage geometry variant); never needed for correctness */
 int a8_set_tuning(int key, int value);
 
+/* ---- per-step weight preparation (the f32 -> compute-dtype casts the reference's autocast-free f32 path never needs;
+ * conv kernels [rows][cols/kw][kw] are re-laid-out to [rows][kk*(cols/kw) + ci]).  dst [rows][cols] and/or dstT [cols][rows]. */
+typedef struct a8_wprep_desc { const float* src; void* dst; void* dstT; int rows, cols, kw; } a8_wprep_desc;
+int a8_prepare_weights(int dtype, const a8_wprep_desc* descs /* host array */, int n, void* stream);
+
 /* ---- conv layer 0 + GroupNorm + GELU (audio8/wav2vec2.py:417-423, Cin=1, k=10, s=5) --------------
  * x f32 [B,L]; w f32 [C,10]; out dtype [B,L0,C] channels-last; stats f32 [B,C,2] = (mean, rstd).
  * part is scratch f32 [B, nchunk, C, 2] with nchunk = ceil(L0 / 256). */

@@ -247,3 +247,49 @@ def test_direct_grad_accumulation_and_stepper_match_autograd(restore_dtype):
         ops.DIRECT_GRADS = False
         ops.GRAD_READY_HOOK = None
         ops.WGRAD_SIDE_STREAM = None
+        ops.WEIGHT_CACHE = None
+
+
+def test_stepper_bf16_weight_cache_matches_uncached(restore_dtype):
+    """bf16 Stepper mode (prepared W / W^T working copies, NT data gradients, side-stream wgrad) against the plain
+    autograd path in the same dtype: same loss and gradients up to atomic-order noise; cache follows the optimizer."""
+    from audio8_amd import ops, wav2vec2 as W
+    from audio8_amd.trainer import Stepper
+    from oracle import ref_cpu as R
+    ops.set_compute_dtype(torch.bfloat16)
+    sd = R.init_state_dict(seed=4, num_layers=2)
+    x = synth(2, 16000, 8).cuda()
+    gum = (-torch.empty(2 * 21 * 2, 320).exponential_(generator=torch.Generator().manual_seed(6)).log()).cuda()
+
+    def make():
+        m = W.create_model(num_layers=2, dropout=0.0, dropout_input=0.0, dropout_features=0.0)
+        m.load_state_dict(sd)
+        m = m.cuda().train()
+        m.quantizer.gumbel_override = gum
+        return m
+
+    ref = make()
+    np.random.seed(0)
+    l_ref = W.create_loss(640, 100)(ref, x)
+    l_ref.backward()
+    mdl = make()
+    st = Stepper(mdl, lr=2e-4, weight_decay=1e-2, clip=1.0)
+    try:
+        assert ops.WEIGHT_CACHE is not None and len(ops.WEIGHT_CACHE) > 10
+        st.zero_grad()
+        np.random.seed(0)
+        l = W.create_loss(640, 100)(mdl, x)
+        l.backward()
+        torch.cuda.current_stream().wait_stream(st.wgrad_stream)
+        np.testing.assert_allclose(l.item(), l_ref.item(), rtol=1e-5)
+        for (k, p), (_, q) in zip(mdl.named_parameters(), ref.named_parameters()):
+            assert rel_err(p.grad, q.grad) < 2e-2, k          # bf16 dgrad via W^T copy vs transposed read: same math, other rounding order
+        w = mdl.final_proj.layer.weight
+        before = ops.WEIGHT_CACHE[id(w)][0].float().clone()
+        st.step()
+        torch.cuda.synchronize()
+        after = ops.WEIGHT_CACHE[id(w)]
+        assert not torch.equal(before, after[0].float())
+        assert torch.equal(after[0], w.detach().to(torch.bfloat16)) and torch.equal(after[1], w.detach().to(torch.bfloat16).t())
+    finally:
+        st.close()
