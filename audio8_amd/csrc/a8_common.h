@@ -68,6 +68,14 @@ A8_DEV uint32_t a8_hash(uint32_t seed, uint32_t stream, uint32_t idx) {
     h += idx; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
     return h;
 }
+// Attention-probability dropout: one cheap 32-bit mix per PAIR of adjacent keys, a 16-bit field per key.
+// keep(q, key) = field(key & 1) of mix(seed, pair_base(q) + (key >> 1)) >= thr16, thr16 = round(p * 65536).
+A8_DEV uint32_t a8_mix(uint32_t seed, uint32_t idx) {
+    uint32_t h = (idx ^ seed) * 0x9E3779B1u;
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+    return h;
+}
+
 // keep-mask: true with probability (1 - p); thr = p * 2^32
 A8_DEV bool a8_keep(uint32_t seed, uint32_t stream, uint32_t idx, uint32_t thr) {
     return a8_hash(seed, stream, idx) >= thr;

@@ -138,11 +138,13 @@ struct AttnP {
     const uint8_t* keymask;
     int B, T, H;
     long long ld_qkv, ld_o, ld_d;
-    float scale, pscale;
-    uint32_t thr, seed;
+    float scale, pscale, dscale;   // scale = softmax scale * log2(e) (scores and lse live in the log2 domain); dscale = softmax scale
+    uint32_t thr, seed;       // thr: 16-bit keep threshold (0 = dropout off)
+    int Th;                   // key pairs per query row = ceil(T / 2)
 };
 
-A8_DEV uint32_t drop_idx(int bh, int T, int q, int key) { return ((uint32_t)bh * (uint32_t)T + (uint32_t)q) * (uint32_t)T + (uint32_t)key; }
+A8_DEV uint32_t pair_base(int bh, int T, int Th, int q) { return ((uint32_t)bh * (uint32_t)T + (uint32_t)q) * (uint32_t)Th; }
+A8_DEV bool keep16(uint32_t h, int key, uint32_t thr) { return ((key & 1) ? (h >> 16) : (h & 0xFFFFu)) >= thr; }
 
 template <typename T> A8_DEV void store4(T* p, float a, float b, float c, float d);
 template <> A8_DEV void store4<bf16>(bf16* p, float a, float b, float c, float d) {
@@ -186,36 +188,48 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP P) {
         f32x4 s[4];
         tile_times_rows<T>(kt, qf, s, lane);          // s[i][r] = S^T[key 16i+4g+r][query li]
         const int key0 = kt_i * BT + 4 * g;
+        const bool edge = km != nullptr || (kt_i + 1) * BT > P.T;      // wave-uniform: masks / tail only here
         float mt = -INFINITY;
+        if (!edge) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = key0 + 16 * i + r;
-                float x = s[i][r] * P.scale;
-                if (km && key < P.T && !km[key]) x = -1e9f;
-                if (key >= P.T) x = -INFINITY;
-                s[i][r] = x;
-                mt = fmaxf(mt, x);
+            for (int i = 0; i < 4; ++i) {
+                s[i] *= P.scale;
+                mt = fmaxf(mt, fmaxf(fmaxf(s[i][0], s[i][1]), fmaxf(s[i][2], s[i][3])));
             }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = key0 + 16 * i + r;
+                    float x = s[i][r] * P.scale;
+                    if (km && key < P.T && !km[key]) x = -1.4426950408889634e9f;     // masked_fill(-1e9), log2 domain
+                    if (key >= P.T) x = -INFINITY;
+                    s[i][r] = x;
+                    mt = fmaxf(mt, x);
+                }
+        }
         mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
         const float mn = fmaxf(m, mt);
-        const float alpha = __expf(m - mn);            // first tile: exp(-inf) = 0
+        const float alpha = exp2f(m - mn);             // first tile: exp2(-inf) = 0
         m = mn;
         float ls = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float p = __expf(s[i][r] - mn);
-                ls += p;
-                if (P.thr) {
-                    const int key = key0 + 16 * i + r;
-                    p = a8_keep(P.seed, 0x51u, drop_idx(bh, P.T, qi, key), P.thr) ? p * P.pscale : 0.f;
-                }
-                s[i][r] = p;
+            for (int r = 0; r < 4; ++r) { s[i][r] = exp2f(s[i][r] - mn); ls += s[i][r]; }
+        if (P.thr) {
+            const uint32_t pb = pair_base(bh, P.T, P.Th, qi) + (uint32_t)(key0 >> 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t h0 = a8_mix(P.seed, pb + 8 * i), h1 = a8_mix(P.seed, pb + 8 * i + 1);
+                s[i][0] = (h0 & 0xFFFFu) >= P.thr ? s[i][0] * P.pscale : 0.f;
+                s[i][1] = (h0 >> 16) >= P.thr ? s[i][1] * P.pscale : 0.f;
+                s[i][2] = (h1 & 0xFFFFu) >= P.thr ? s[i][2] * P.pscale : 0.f;
+                s[i][3] = (h1 >> 16) >= P.thr ? s[i][3] * P.pscale : 0.f;
             }
+        }
         l = l * alpha + ls;
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
@@ -231,7 +245,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP P) {
         T* op = reinterpret_cast<T*>(P.out) + ((long long)b * P.T + qi) * P.ld_o + h * DH + 4 * g;
 #pragma unroll
         for (int db = 0; db < 4; ++db) store4<T>(op + 16 * db, oacc[db][0] * inv, oacc[db][1] * inv, oacc[db][2] * inv, oacc[db][3] * inv);
-        if (g == 0) P.lse[((long long)bh) * P.T + qi] = m + __logf(l);
+        if (g == 0) P.lse[((long long)bh) * P.T + qi] = m + log2f(l);     // log2-domain log-sum-exp
     }
 }
 
@@ -305,22 +319,25 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnP P) {
         f32x4 s[4], dp[4];
         rows_times_tile<T>(qt, kf, s, lane);           // s[i][r]  = S[q 16i+4g+r][key li]
         rows_times_tile<T>(dot, vf, dp, lane);         // dp[i][r] = (dO V^T)[q][key]
+        const bool qedge = (qt_i + 1) * BT > P.T;                       // wave-uniform
+        const int keyh = key >> 1;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ql = 16 * i + 4 * g + r, qq = qt_i * BT + ql;
                 float x = s[i][r] * P.scale;
-                if (key_masked) x = -1e9f;
-                float p = (key_ok && qq < P.T) ? __expf(x - s_lse[ql]) : 0.f;
+                if (key_masked) x = -1.4426950408889634e9f;
+                float p = exp2f(x - s_lse[ql]);
+                if (!key_ok || (qedge && qq >= P.T)) p = 0.f;
                 float pd = p, dpv = dp[i][r];
                 if (P.thr) {
-                    const bool keep = a8_keep(P.seed, 0x51u, drop_idx(bh, P.T, qq, key), P.thr);
+                    const bool keep = keep16(a8_mix(P.seed, pair_base(bh, P.T, P.Th, qq) + keyh), key, P.thr);
                     pd = keep ? p * P.pscale : 0.f;
                     dpv = keep ? dpv * P.pscale : 0.f;
                 }
                 s[i][r] = pd;                                        // P (dropped) for dV
-                dp[i][r] = p * (dpv - s_delta[ql]) * P.scale;        // dS for dK
+                dp[i][r] = p * (dpv - s_delta[ql]) * P.dscale;       // dS for dK
             }
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
@@ -382,18 +399,27 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnP P) {
         tile_times_rows<T>(kt, qf, s, lane);           // S^T[key][q]
         tile_times_rows<T>(vt, dof, dp, lane);         // (V dO^T)[key][q]
         const int key0 = kt_i * BT + 4 * g;
+        const bool edge = km != nullptr || (kt_i + 1) * BT > P.T;      // wave-uniform
+        const uint32_t pb = pair_base(bh, P.T, P.Th, qi) + (uint32_t)(key0 >> 1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
+            uint32_t h0 = 0, h1 = 0;
+            if (P.thr) { h0 = a8_mix(P.seed, pb + 8 * i); h1 = a8_mix(P.seed, pb + 8 * i + 1); }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = key0 + 16 * i + r;
                 float x = s[i][r] * P.scale;
-                if (km && key < P.T && !km[key]) x = -1e9f;
-                const float p = (key < P.T && q_ok) ? __expf(x - lse) : 0.f;
+                if (edge && km && key < P.T && !km[key]) x = -1.4426950408889634e9f;
+                float p = exp2f(x - lse);
+                if ((edge && key >= P.T) || !q_ok) p = 0.f;
                 float dpv = dp[i][r];
-                if (P.thr) dpv = a8_keep(P.seed, 0x51u, drop_idx(bh, P.T, qi, key), P.thr) ? dpv * P.pscale : 0.f;
-                s[i][r] = p * (dpv - delta) * P.scale;   // dS^T[key][q]
+                if (P.thr) {
+                    const uint32_t hh = (r < 2) ? h0 : h1;
+                    dpv = (((r & 1) ? (hh >> 16) : (hh & 0xFFFFu)) >= P.thr) ? dpv * P.pscale : 0.f;
+                }
+                s[i][r] = p * (dpv - delta) * P.dscale;   // dS^T[key][q]
             }
+        }
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
             dq[db] = ATile<T>::mma_xt_p(kt, 0, 16 * db, s[0], s[1], dq[db], lane);
@@ -407,13 +433,24 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnP P) {
     }
 }
 
+void set_softmax_params(AttnP& P, float scale, float p, uint32_t seed) {
+    P.scale = scale * 1.4426950408889634f;
+    P.dscale = scale;
+    P.Th = (P.T + 1) / 2;
+    uint32_t thr = p > 0.f ? (uint32_t)(p * 65536.0f + 0.5f) : 0u;
+    if (p > 0.f && thr == 0) thr = 1;
+    P.thr = thr;
+    P.pscale = thr ? 65536.0f / (65536.0f - (float)thr) : 1.0f;      // unbiased for the realised keep probability
+    P.seed = seed;
+}
+
 int check_common(const char* what, int dtype, int B, int T_, int H, long long ld_qkv, long long ld_o, float p) {
     A8_REQUIRE(dtype == A8_F32 || dtype == A8_BF16, "%s: bad dtype", what);
     A8_REQUIRE(B >= 1 && T_ >= 1 && H >= 1, "%s: bad sizes B=%d T=%d H=%d", what, B, T_, H);
     const int epc = dtype == A8_BF16 ? 8 : 4;
     A8_REQUIRE(ld_qkv % epc == 0 && ld_o % epc == 0 && ld_qkv >= (long long)H * DH && ld_o >= (long long)H * DH, "%s: bad leading dimensions", what);
     A8_REQUIRE(p >= 0.f && p < 1.f, "%s: bad dropout p", what);
-    A8_REQUIRE((long long)B * H * T_ * T_ < (1ll << 32), "%s: B*H*T*T exceeds the dropout counter range", what);
+    A8_REQUIRE((long long)B * H * T_ * ((T_ + 1) / 2) < (1ll << 32), "%s: B*H*T*T/2 exceeds the dropout counter range", what);
     return A8_OK;
 }
 
@@ -424,10 +461,8 @@ extern "C" int a8_attn_fwd(int dtype, const void* q, const void* k, const void* 
     if (int e = check_common("a8_attn_fwd", dtype, B, T_, H, ld_qkv, ld_o, p)) return e;
     AttnP P = {};
     P.q = (const char*)q; P.k = (const char*)k; P.v = (const char*)v; P.out = (char*)o; P.lse = lse; P.keymask = keymask;
-    P.B = B; P.T = T_; P.H = H; P.ld_qkv = ld_qkv; P.ld_o = ld_o; P.scale = scale;
-    P.pscale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
-    P.thr = p > 0.f ? (uint32_t)((double)p * 4294967296.0) : 0u;
-    P.seed = seed;
+    P.B = B; P.T = T_; P.H = H; P.ld_qkv = ld_qkv; P.ld_o = ld_o;
+    set_softmax_params(P, scale, p, seed);
     const dim3 grid(cdiv(T_, BT), B * H);
     if (dtype == A8_BF16) hipLaunchKernelGGL(attn_fwd_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, P);
     else hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, P);
@@ -442,10 +477,8 @@ extern "C" int a8_attn_bwd(int dtype, const void* q, const void* k, const void* 
     P.q = (const char*)q; P.k = (const char*)k; P.v = (const char*)v; P.o = (const char*)o; P.dout = (const char*)dout;
     P.lse = (float*)lse; P.delta = delta; P.keymask = keymask;
     P.dq = (char*)dq; P.dk = (char*)dk; P.dv = (char*)dv;
-    P.B = B; P.T = T_; P.H = H; P.ld_qkv = ld_qkv; P.ld_o = ld_o; P.ld_d = ld_dqkv; P.scale = scale;
-    P.pscale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
-    P.thr = p > 0.f ? (uint32_t)((double)p * 4294967296.0) : 0u;
-    P.seed = seed;
+    P.B = B; P.T = T_; P.H = H; P.ld_qkv = ld_qkv; P.ld_o = ld_o; P.ld_d = ld_dqkv;
+    set_softmax_params(P, scale, p, seed);
     hipStream_t s = (hipStream_t)stream;
     const long long nrow = (long long)B * T_ * H;
     const dim3 grid(cdiv(T_, BT), B * H);
