@@ -36,6 +36,45 @@ __global__ __launch_bounds__(256) void wprep_kernel(const float* __restrict__ sr
     }
 }
 
+// single-launch variant: blockIdx.x walks a prefix table of 32x32 tiles over all matrices
+template <typename T>
+__global__ __launch_bounds__(256) void wprep_multi_kernel(const a8_wprep_desc* __restrict__ descs, const int* __restrict__ tile_start, int n) {
+    __shared__ float tile[32][33];
+    // binary search: largest i with tile_start[i] <= blockIdx.x
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tile_start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const a8_wprep_desc d = descs[lo];
+    const int tl = blockIdx.x - tile_start[lo];
+    const int tcols = (d.cols + 31) >> 5;
+    const int c0 = (tl % tcols) * 32, r0 = (tl / tcols) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int cin = d.cols / d.kw;
+    T* dst = reinterpret_cast<T*>(d.dst);
+    T* dstT = reinterpret_cast<T*>(d.dstT);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = r0 + ty + 8 * j, c = c0 + tx;
+        float v = 0.f;
+        if (r < d.rows && c < d.cols) {
+            const int kk = c / cin, ci = c - kk * cin;
+            v = d.src[(long long)r * d.cols + (long long)ci * d.kw + kk];
+            if (dst) dst[(long long)r * d.cols + c] = from_f<T>(v);
+        }
+        tile[ty + 8 * j][tx] = v;
+    }
+    __syncthreads();
+    if (dstT) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c0 + ty + 8 * j, r = r0 + tx;
+            if (r < d.rows && c < d.cols) dstT[(long long)c * d.rows + r] = from_f<T>(tile[tx][ty + 8 * j]);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int a8_prepare_weights(int dtype, const a8_wprep_desc* descs, int n, void* stream) {
@@ -50,4 +89,15 @@ extern "C" int a8_prepare_weights(int dtype, const a8_wprep_desc* descs, int n, 
         else hipLaunchKernelGGL(wprep_kernel<float>, grid, dim3(256), 0, s, d.src, (float*)d.dst, (float*)d.dstT, d.rows, d.cols, d.kw);
     }
     return a8_check_launch("a8_prepare_weights");
+}
+
+// descs/tile_start live in DEVICE memory (built once by the host); tile_start[i] = first 32x32-tile index of matrix i,
+// total_tiles = tile_start[n].  One launch prepares every weight of the model.
+extern "C" int a8_prepare_weights_device(int dtype, const a8_wprep_desc* descs_dev, const int* tile_start_dev, int n, int total_tiles, void* stream) {
+    A8_REQUIRE(dtype == A8_F32 || dtype == A8_BF16, "a8_prepare_weights_device: bad dtype");
+    if (n == 0 || total_tiles == 0) return A8_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == A8_BF16) hipLaunchKernelGGL(wprep_multi_kernel<bf16>, dim3(total_tiles), dim3(256), 0, s, descs_dev, tile_start_dev, n);
+    else hipLaunchKernelGGL(wprep_multi_kernel<float>, dim3(total_tiles), dim3(256), 0, s, descs_dev, tile_start_dev, n);
+    return a8_check_launch("a8_prepare_weights_device");
 }

@@ -108,12 +108,23 @@ class WeightCache:
             self.descs[i] = L.WPrepDesc(src.data_ptr(), dst.data_ptr(), dst_t.data_ptr(), r, c, kw)
             self.cache[id(key)] = (dst, dst_t)
         self._src_ptrs = [e[1].data_ptr() for e in entries]
+        # device-resident descriptor table + tile prefix for the single-launch kernel
+        import ctypes as C
+        import numpy as np
+        raw = np.frombuffer(C.string_at(C.addressof(self.descs), C.sizeof(self.descs)), dtype=np.uint8).copy()
+        self.descs_dev = torch.from_numpy(raw).to(dev)
+        starts = [0]
+        for _, _, r, c, _ in entries:
+            starts.append(starts[-1] + ((r + 31) // 32) * ((c + 31) // 32))
+        self.total_tiles = starts[-1]
+        self.tile_start_dev = torch.tensor(starts, dtype=torch.int32, device=dev)
 
     def refresh(self):
         for i, p in enumerate(self.params):               # parameters may have been re-pointed (e.g. .to(), load)
             if p.data_ptr() != self._src_ptrs[i]:
                 raise RuntimeError("WeightCache: a parameter's storage moved; rebuild the Stepper")
-        K.prepare_weights(L.dt(self.arena), self.descs, self.n)
+        L.check(L.lib().a8_prepare_weights_device(L.dt(self.arena), L.ptr(self.descs_dev), L.ptr(self.tile_start_dev), self.n,
+                                                  self.total_tiles, L.stream()), "a8_prepare_weights_device")
 
 
 class GradReducer:

@@ -56,6 +56,8 @@ int a8_set_tuning(int key, int value);
  * conv kernels [rows][cols/kw][kw] are re-laid-out to [rows][kk*(cols/kw) + ci]).  dst [rows][cols] and/or dstT [cols][rows]. */
 typedef struct a8_wprep_desc { const float* src; void* dst; void* dstT; int rows, cols, kw; } a8_wprep_desc;
 int a8_prepare_weights(int dtype, const a8_wprep_desc* descs /* host array */, int n, void* stream);
+/* one-launch form: descs and tile_start (n+1 ints, prefix sums of ceil(rows/32)*ceil(cols/32)) in device memory */
+int a8_prepare_weights_device(int dtype, const a8_wprep_desc* descs_dev, const int* tile_start_dev, int n, int total_tiles, void* stream);
 
 /* ---- conv layer 0 + GroupNorm + GELU (audio8/wav2vec2.py:417-423, Cin=1, k=10, s=5) --------------
  * x f32 [B,L]; w f32 [C,10]; out dtype [B,L0,C] channels-last; stats f32 [B,C,2] = (mean, rstd).
