@@ -27,14 +27,15 @@ class GemmDesc(C.Structure):
         ("C", C.c_void_p), ("ldc", C.c_int64), ("c_rpb", C.c_int64), ("c_bs", C.c_int64),
         ("bias", C.c_void_p), ("bias_rows", C.c_int),
         ("act", C.c_int),
-        ("zin", C.c_void_p), ("zout", C.c_void_p), ("ldz", C.c_int64),
+        ("zin", C.c_void_p), ("zout", C.c_void_p), ("ldz", C.c_int64), ("z_rpb", C.c_int64), ("z_bs", C.c_int64),
         ("out_f32", C.c_int), ("accumulate", C.c_int), ("splitk", C.c_int),
         ("alpha", C.c_float),
     ]
 
 
 class WPrepDesc(C.Structure):
-    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("dstT", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("kw", C.c_int)]
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("dstT", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("kw", C.c_int),
+                ("tap", C.c_int), ("ld_dst", C.c_int), ("ld_dstT", C.c_int)]
 
 
 def lib():

@@ -22,7 +22,7 @@ struct Op { const char* p; long long ld, rpb, bs; };
 struct GemmArgs {
     Op A, B;
     char* C; long long ldc, c_rpb, c_bs;
-    const char* zin; char* zout; long long ldz;
+    const char* zin; char* zout; long long ldz, z_rpb, z_bs;
     const float* bias;
     int M, N, K, kchunk, nsplit, tiles_m, tiles_n;
     int act, out_f32, atomic, bias_rows;
@@ -147,15 +147,28 @@ __global__ __launch_bounds__(256, (NST * 2 * 8192 * KB <= 65536) ? 2 : 1) void g
         }
     }
 
-    // K-strided operands walk their outer index by BK per k-tile: keep (batch, row-in-batch) incrementally
-    // instead of a 64-bit division per DMA (the conv weight gradient has rows_per_batch != 0).
-    long long a_q[PPW], a_r[PPW], b_q[PPW], b_r[PPW];
+    // K-strided operands walk their outer index by BK per k-tile: each lane keeps a running source pointer (one
+    // 64-bit add per DMA piece per k-tile); a batch remap (rows_per_batch != 0, the conv weight gradient) only adds
+    // a 32-bit row counter and a wrap correction.  a_k/b_k then hold the lane's CURRENT k.
+    const char* a_cur[PPW]; int a_r[PPW];
+    const char* b_cur[PPW]; int b_r[PPW];
+    const long long a_step = (long long)BK * g.A.ld * SZ, a_wrap = (g.A.bs - g.A.rpb * g.A.ld) * SZ;
+    const long long b_step = (long long)BK * g.B.ld * SZ, b_wrap = (g.B.bs - g.B.rpb * g.B.ld) * SZ;
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
-        if constexpr (AKS) { const long long k = kbeg + a_k[j]; a_q[j] = g.A.rpb ? k / g.A.rpb : 0; a_r[j] = g.A.rpb ? k % g.A.rpb : k; }
-        if constexpr (BKS) { const long long k = kbeg + b_k[j]; b_q[j] = g.B.rpb ? k / g.B.rpb : 0; b_r[j] = g.B.rpb ? k % g.B.rpb : k; }
+        if constexpr (AKS) {
+            const long long k = kbeg + a_k[j];
+            a_cur[j] = a_ptr[j] + outer_off(g.A, k) * SZ;
+            a_r[j] = g.A.rpb ? (int)(k % g.A.rpb) : 0;
+            a_k[j] = (int)k;
+        }
+        if constexpr (BKS) {
+            const long long k = kbeg + b_k[j];
+            b_cur[j] = b_ptr[j] + outer_off(g.B, k) * SZ;
+            b_r[j] = g.B.rpb ? (int)(k % g.B.rpb) : 0;
+            b_k[j] = (int)k;
+        }
     }
-    int kb_issued = 0;                      // issue() is always called with kb = 0, 1, 2, ... in order
     auto issue = [&](int kb) {
         char* ta = lds + (kb % NST) * 2 * TILE;
         char* tb = ta + TILE;
@@ -168,10 +181,10 @@ __global__ __launch_bounds__(256, (NST * 2 * 8192 * KB <= 65536) ? 2 : 1) void g
                 const int k = k0 + a_k[j];
                 sa = (a_ok[j] && k + EPC <= kend) ? a_ptr[j] + (long long)k * SZ : zero;
             } else {
-                const int k = k0 + a_k[j];
-                sa = (a_ok[j] && k < kend) ? a_ptr[j] + (a_q[j] * g.A.bs + a_r[j] * g.A.ld) * SZ : zero;
-                a_r[j] += BK;
-                if (g.A.rpb) while (a_r[j] >= g.A.rpb) { a_r[j] -= g.A.rpb; ++a_q[j]; }
+                sa = (a_ok[j] && a_k[j] < kend) ? a_cur[j] : zero;
+                a_k[j] += BK;
+                a_cur[j] += a_step;
+                if (g.A.rpb) { a_r[j] += BK; while (a_r[j] >= (int)g.A.rpb) { a_r[j] -= (int)g.A.rpb; a_cur[j] += a_wrap; } }
             }
             glds16(sa, ta + p * 1024);
             const char* sb;
@@ -179,14 +192,13 @@ __global__ __launch_bounds__(256, (NST * 2 * 8192 * KB <= 65536) ? 2 : 1) void g
                 const int k = k0 + b_k[j];
                 sb = (b_ok[j] && k + EPC <= kend) ? b_ptr[j] + (long long)k * SZ : zero;
             } else {
-                const int k = k0 + b_k[j];
-                sb = (b_ok[j] && k < kend) ? b_ptr[j] + (b_q[j] * g.B.bs + b_r[j] * g.B.ld) * SZ : zero;
-                b_r[j] += BK;
-                if (g.B.rpb) while (b_r[j] >= g.B.rpb) { b_r[j] -= g.B.rpb; ++b_q[j]; }
+                sb = (b_ok[j] && b_k[j] < kend) ? b_cur[j] : zero;
+                b_k[j] += BK;
+                b_cur[j] += b_step;
+                if (g.B.rpb) { b_r[j] += BK; while (b_r[j] >= (int)g.B.rpb) { b_r[j] -= (int)g.B.rpb; b_cur[j] += b_wrap; } }
             }
             glds16(sb, tb + p * 1024);
         }
-        (void)kb_issued;
     };
 
     f32x4 acc[4][4];
@@ -241,6 +253,7 @@ __global__ __launch_bounds__(256, (NST * 2 * 8192 * KB <= 65536) ? 2 : 1) void g
     }
     __builtin_amdgcn_wave_barrier();      // the tile is wave-private: program order of this wave's LDS ops suffices
     const int mw = m0 + wm * 64, nw = n0 + wn * 64;
+    auto zrow = [&](int m) -> long long { return g.z_rpb ? (m / g.z_rpb) * g.z_bs + (m % g.z_rpb) * g.ldz : (long long)m * g.ldz; };
     const bool f32_rows = g.out_f32 || sizeof(T) == 4;
     if (f32_rows) {
         const int n = nw + lane;
@@ -252,9 +265,9 @@ __global__ __launch_bounds__(256, (NST * 2 * 8192 * KB <= 65536) ? 2 : 1) void g
             float v = cw[rr * 64 + ((((lane >> 2) ^ (rr & 15))) << 2) + (lane & 3)] + bn;
             if (g.bias && g.bias_rows) v += g.bias[m];
             if (!n_ok) continue;
-            if (g.zout) reinterpret_cast<T*>(g.zout)[(long long)m * g.ldz + n] = from_f<T>(v);
+            if (g.zout) reinterpret_cast<T*>(g.zout)[zrow(m) + n] = from_f<T>(v);
             if (g.act == A8_ACT_GELU) v = gelu_f(v);
-            else if (g.act == A8_ACT_MUL_GELU_GRAD) v *= gelu_grad_f(to_f(reinterpret_cast<const T*>(g.zin)[(long long)m * g.ldz + n]));
+            else if (g.act == A8_ACT_MUL_GELU_GRAD) v *= gelu_grad_f(to_f(reinterpret_cast<const T*>(g.zin)[zrow(m) + n]));
             const long long crow = g.c_rpb ? (m / g.c_rpb) * g.c_bs + (m % g.c_rpb) * g.ldc : (long long)m * g.ldc;
             float* cp = reinterpret_cast<float*>(g.C) + crow + n;
             if (g.atomic) atomicAdd(cp, v);
@@ -285,13 +298,13 @@ __global__ __launch_bounds__(256, (NST * 2 * 8192 * KB <= 65536) ? 2 : 1) void g
                 T8 zv;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) zv[e] = from_f<T>(v[e]);
-                *reinterpret_cast<T8*>(reinterpret_cast<T*>(g.zout) + (long long)m * g.ldz + n) = zv;
+                *reinterpret_cast<T8*>(reinterpret_cast<T*>(g.zout) + zrow(m) + n) = zv;
             }
             if (g.act == A8_ACT_GELU) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
             } else if (g.act == A8_ACT_MUL_GELU_GRAD) {
-                const T8 zz = *reinterpret_cast<const T8*>(reinterpret_cast<const T*>(g.zin) + (long long)m * g.ldz + n);
+                const T8 zz = *reinterpret_cast<const T8*>(reinterpret_cast<const T*>(g.zin) + zrow(m) + n);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(to_f(zz[e]));
             }
@@ -355,7 +368,7 @@ extern "C" int a8_gemm(const a8_gemm_desc* d, void* stream) {
     g.A = Op{(const char*)d->A, d->lda, d->a_rpb, d->a_bs};
     g.B = Op{(const char*)d->B, d->ldb, d->b_rpb, d->b_bs};
     g.C = (char*)d->C; g.ldc = d->ldc; g.c_rpb = d->c_rpb; g.c_bs = d->c_bs;
-    g.zin = (const char*)d->zin; g.zout = (char*)d->zout; g.ldz = d->ldz;
+    g.zin = (const char*)d->zin; g.zout = (char*)d->zout; g.ldz = d->ldz; g.z_rpb = d->z_rpb; g.z_bs = d->z_bs;
     g.bias = d->bias; g.bias_rows = d->bias_rows;
     g.M = d->M; g.N = d->N; g.K = d->K;
     g.tiles_m = cdiv(d->M, 128); g.tiles_n = cdiv(d->N, 128);

@@ -59,9 +59,13 @@ __global__ __launch_bounds__(256) void wprep_multi_kernel(const a8_wprep_desc* _
         const int r = r0 + ty + 8 * j, c = c0 + tx;
         float v = 0.f;
         if (r < d.rows && c < d.cols) {
-            const int kk = c / cin, ci = c - kk * cin;
-            v = d.src[(long long)r * d.cols + (long long)ci * d.kw + kk];
-            if (dst) dst[(long long)r * d.cols + c] = from_f<T>(v);
+            if (d.tap >= 0) {
+                v = d.src[((long long)r * d.cols + c) * d.kw + d.tap];
+            } else {
+                const int kk = c / cin, ci = c - kk * cin;
+                v = d.src[(long long)r * d.cols + (long long)ci * d.kw + kk];
+            }
+            if (dst) dst[(long long)r * (d.ld_dst ? d.ld_dst : d.cols) + c] = from_f<T>(v);
         }
         tile[ty + 8 * j][tx] = v;
     }
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(256) void wprep_multi_kernel(const a8_wprep_desc* _
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int c = c0 + ty + 8 * j, r = r0 + tx;
-            if (r < d.rows && c < d.cols) dstT[(long long)c * d.rows + r] = from_f<T>(tile[tx][ty + 8 * j]);
+            if (r < d.rows && c < d.cols) dstT[(long long)c * (d.ld_dstT ? d.ld_dstT : d.rows) + r] = from_f<T>(tile[tx][ty + 8 * j]);
         }
     }
 }
@@ -84,6 +88,7 @@ extern "C" int a8_prepare_weights(int dtype, const a8_wprep_desc* descs, int n, 
     for (int i = 0; i < n; ++i) {
         const a8_wprep_desc& d = descs[i];
         A8_REQUIRE(d.rows > 0 && d.cols > 0 && d.kw >= 1 && d.cols % d.kw == 0 && d.src, "a8_prepare_weights: bad descriptor %d", i);
+        A8_REQUIRE(d.tap < 0 && d.ld_dst == 0 && d.ld_dstT == 0, "a8_prepare_weights: tap / leading dimensions need the device-table form");
         const dim3 grid(cdiv(d.cols, 32), cdiv(d.rows, 32));
         if (dtype == A8_BF16) hipLaunchKernelGGL(wprep_kernel<bf16>, grid, dim3(256), 0, s, d.src, (bf16*)d.dst, (bf16*)d.dstT, d.rows, d.cols, d.kw);
         else hipLaunchKernelGGL(wprep_kernel<float>, grid, dim3(256), 0, s, d.src, (float*)d.dst, (float*)d.dstT, d.rows, d.cols, d.kw);

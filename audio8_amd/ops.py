@@ -50,6 +50,7 @@ def reset_seed_stream():
 # id(param) -> (W2 [rows, cols] compute dtype, W2^T [cols, rows]); the fused QKV matrix is keyed by the w_Q weight.
 WEIGHT_CACHE = None
 WEIGHT_CACHE_DTYPE = None
+CONV_DGRAD_CACHE = None      # id(conv weight, k = 3) -> (B_even [cin, 2co], B_odd [cin, co]) for the fused stride-2 data gradient
 
 
 def cached_weights(p, dtype):
@@ -83,10 +84,10 @@ def _tiles(m, n):
     return ((m + 127) // 128) * ((n + 127) // 128)
 
 
-def wgrad(dy, x, n_out, n_in, m, lda=None, ldb=None, b_rpb=0, b_bs=0):
-    """dW[n_out, n_in] (f32) = dy[m, n_out]^T . x[m, n_in]   (split-K over m)."""
+def wgrad(dy, x, n_out, n_in, m, **kw):
+    """dW[n_out, n_in] (f32) = dy[m, n_out]^T . x[m, n_in]   (split-K over m); kw: leading dims / row remaps of the operands."""
     out = torch.zeros((n_out, n_in), device=dy.device, dtype=torch.float32)
-    K.gemm(L.TN, dy, x, n_out, n_in, m, out=out, lda=lda, ldb=ldb, b_rpb=b_rpb, b_bs=b_bs, splitk=_splitk(_tiles(n_out, n_in), m))
+    K.gemm(L.TN, dy, x, n_out, n_in, m, out=out, splitk=_splitk(_tiles(n_out, n_in), m), **kw)
     return out
 
 
@@ -369,6 +370,7 @@ class ConvStackFn(torch.autograd.Function):
             lens.append(Lout)
         ctx.feats, ctx.lens, ctx.B = feats, lens, B
         ctx.wcTs = wcTs
+        ctx.ws = ws
         ctx.params = (ws[0], gn_w, gn_b)
         ctx.save_for_backward(x, gn_w, gn_b, stats, ws[0], *acts[:-1], *zs[1:], *wcs[1:])
         ctx.nl = len(ws)
@@ -389,16 +391,48 @@ class ConvStackFn(torch.autograd.Function):
             da = K.cast(da, dtype)
         co = feats[-1][0]
         dz = K.gelu_bwd_bias(da.view(-1, co), zs[nl - 1], None)
+        ws = ctx.ws
+        fusable = (CONV_DGRAD_CACHE is not None and WEIGHT_CACHE_DTYPE == dtype and feats[-1][1] == 2 and all(f[2] == 2 and f[1] in (2, 3) for f in feats[1:])
+                   and all(ctx.wcTs[i] is not None for i in range(1, nl)) and all(feats[i][1] == 2 or id(ws[i]) in CONV_DGRAD_CACHE for i in range(1, nl)))
+        pad = 0                                   # dz of layer i is stored with `pad` zero rows around each utterance
         for i in range(nl - 1, 0, -1):
             co, k, s = feats[i]
             cin = acts[i - 1].shape[-1]
             Lin, Lout = lens[i - 1], lens[i]
             M = B * Lout
-            dw2 = wgrad(dz, acts[i - 1], co, k * cin, M, ldb=s * cin, b_rpb=Lout, b_bs=Lin * cin)
+            dzrows = Lout + 2 * pad
+            akw = dict(a_off=pad * co, a_rpb=Lout, a_bs=dzrows * co) if pad else {}
+            dw2 = wgrad(dz, acts[i - 1], co, k * cin, M, ldb=s * cin, b_rpb=Lout, b_bs=Lin * cin, lda=co, **akw)
             grads[i] = dw2.view(co, k, cin).permute(0, 2, 1).contiguous()
-            dcol = _dgrad(dz, wcs[i], ctx.wcTs[i], M, k * cin, co)
-            dz = K.col2im_gelu_grad(dcol, zs[i - 1] if i - 1 >= 1 else None, B, Lin, Lout, cin, k, s).view(-1, cin)
-            del dcol
+            zprev = zs[i - 1] if i - 1 >= 1 else None
+            if not fusable:
+                dcol = _dgrad(dz, wcs[i], ctx.wcTs[i], M, k * cin, co)
+                dz = K.col2im_gelu_grad(dcol, zprev, B, Lin, Lout, cin, k, s).view(-1, cin)
+                del dcol
+                continue
+            # fused data gradient: write dx[b, p, :] (* gelu'(z)) straight from the GEMM epilogues
+            npad = 1 if (i - 1 >= 1 and feats[i - 1][1] == 3) else 0          # the layer below reads dz[t-1], dz[t]
+            prow = Lin + 2 * npad
+            dx = torch.zeros((B * prow, cin), device=dz.device, dtype=dtype) if (npad or Lin > 2 * (Lout - 1) + k) else \
+                torch.empty((B * prow, cin), device=dz.device, dtype=dtype)
+            act = L.ACT_MUL_GELU_GRAD if zprev is not None else L.ACT_NONE
+            zk = dict(zin=zprev, ldz=2 * cin, z_bs=Lin * cin) if zprev is not None else {}
+            if k == 2:
+                K.gemm(L.NT, dz, ctx.wcTs[i], M, 2 * cin, co, out=dx, lda=co, ldc=2 * cin, c_off=npad * cin, c_rpb=Lout, c_bs=prow * cin,
+                       act=act, **akw, **(dict(zk, z_rpb=Lout) if zk else {}))
+            else:
+                assert pad == 1
+                b_even, b_odd = CONV_DGRAD_CACHE[id(ws[i])]
+                # even positions p = 2t, t = 0..Lout: rows [dz[t-1] | dz[t]] of the zero-padded dz (K = 2 co)
+                K.gemm(L.NT, dz, b_even, B * (Lout + 1), cin, 2 * co, out=dx, lda=co, a_rpb=Lout + 1, a_bs=dzrows * co,
+                       ldc=2 * cin, c_off=npad * cin, c_rpb=Lout + 1, c_bs=prow * cin, act=act,
+                       **(dict(zk, z_rpb=Lout + 1) if zk else {}))
+                # odd positions p = 2t + 1, t = 0..Lout-1
+                K.gemm(L.NT, dz, b_odd, M, cin, co, out=dx, lda=co, a_off=co, a_rpb=Lout, a_bs=dzrows * co,
+                       ldc=2 * cin, c_off=(npad + 1) * cin, c_rpb=Lout, c_bs=prow * cin, act=act,
+                       **(dict(zk, z_rpb=Lout, z_off=cin) if zk else {}))
+            dz, pad = dx, npad
+        assert pad == 0
         pw0, pgw, pgb = ctx.params
         t0, t1, t2 = _target(pw0), _target(pgw), _target(pgb)
         direct = t0 is not None and t1 is not None and t2 is not None

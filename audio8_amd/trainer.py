@@ -70,52 +70,69 @@ class FlatState:
 
 
 class WeightCache:
-    """bf16 working copies (and transposes) of every GEMM weight, rebuilt from the f32 masters by ONE C call per
-    optimizer step (a8_prepare_weights).  Registered in ops.WEIGHT_CACHE; see ops.cached_weights."""
+    """Compute-dtype working copies of every GEMM weight, rebuilt from the f32 masters by ONE kernel launch per
+    optimizer step (a8_prepare_weights_device):
+        ops.WEIGHT_CACHE[id(w)]      = (W2 [rows, cols], W2^T [cols, rows])      Linear / fused QKV / conv [co][kk*cin+ci]
+        ops.CONV_DGRAD_CACHE[id(w)]  = (B_even [cin, 2*co], B_odd [cin, co])     k = 3, stride 2 conv data gradient
+    """
 
     def __init__(self, model: torch.nn.Module, dtype=torch.bfloat16):
+        import ctypes as C
+        import numpy as np
         from .layers import MultiHeadedAttention
         self.dtype = dtype
-        entries = []            # (key_param, src_tensor, rows, cols, kw)
+        dev = next(model.parameters()).device
+        jobs = []               # (src_param, rows, cols, kw, tap, dst, dstT, ld_dst, ld_dstT)
+        self.cache, self.conv_dgrad = {}, {}
+        self._keep = []
+
+        def alloc(*shape):
+            t = torch.empty(shape, device=dev, dtype=dtype)
+            self._keep.append(t)
+            return t
+
         fused = set()
         for m in model.modules():
             if isinstance(m, MultiHeadedAttention):
                 wq, wk, wv = m.w_Q.layer.weight, m.w_K.layer.weight, m.w_V.layer.weight
                 if ops._adjacent(wq, wk, wv):
-                    d = wq.shape[1]
-                    entries.append((wq, wq, 3 * wq.shape[0], d, 1))
+                    r, c = 3 * wq.shape[0], wq.shape[1]
+                    dst, dst_t = alloc(r, c), alloc(c, r)
+                    jobs.append((wq, r, c, 1, -1, dst, dst_t, 0, 0))
+                    self.cache[id(wq)] = (dst, dst_t)
                     fused.update((id(wq), id(wk), id(wv)))
         for n, p in model.named_parameters():
-            if id(p) in fused or not p.requires_grad:
+            if id(p) in fused or not p.requires_grad or "quantizer" in n or "pos_conv" in n:
                 continue
-            if p.dim() == 2 and "quantizer" not in n:
-                entries.append((p, p, p.shape[0], p.shape[1], 1))
-            elif p.dim() == 3 and p.shape[1] > 1 and "pos_conv" not in n and "quantizer" not in n:
-                entries.append((p, p, p.shape[0], p.shape[1] * p.shape[2], p.shape[2]))
-        dev = next(model.parameters()).device
-        total = sum(r * c for _, _, r, c, _ in entries)
-        self.arena = torch.empty(total + 8, device=dev, dtype=dtype)
-        self.arena_t = torch.empty(total + 8, device=dev, dtype=dtype)
-        self.n = len(entries)
+            if p.dim() == 2:
+                r, c = p.shape
+                dst, dst_t = alloc(r, c), alloc(c, r)
+                jobs.append((p, r, c, 1, -1, dst, dst_t, 0, 0))
+                self.cache[id(p)] = (dst, dst_t)
+            elif p.dim() == 3 and p.shape[1] > 1:
+                co, cin, kw = p.shape
+                dst, dst_t = alloc(co, kw * cin), alloc(kw * cin, co)
+                jobs.append((p, co, kw * cin, kw, -1, dst, dst_t, 0, 0))
+                self.cache[id(p)] = (dst, dst_t)
+                if kw == 3:
+                    b_even, b_odd = alloc(cin, 2 * co), alloc(cin, co)
+                    # dx[2t]   = dz[t-1] W[:, :, 2] + dz[t] W[:, :, 0]  ->  B_even[ci] = [W[:, ci, 2] | W[:, ci, 0]]
+                    jobs.append((p, co, cin, kw, 2, None, b_even, 0, 2 * co))
+                    jobs.append((p, co, cin, kw, 0, None, b_even[:, co:], 0, 2 * co))
+                    # dx[2t+1] = dz[t] W[:, :, 1]
+                    jobs.append((p, co, cin, kw, 1, None, b_odd, 0, 0))
+                    self.conv_dgrad[id(p)] = (b_even, b_odd)
+        self.n = len(jobs)
         self.descs = (L.WPrepDesc * self.n)()
-        self.cache = {}
-        self.params = [e[0] for e in entries]
-        off = 0
-        for i, (key, src, r, c, kw) in enumerate(entries):
-            dst = self.arena[off:off + r * c].view(r, c)
-            dst_t = self.arena_t[off:off + r * c].view(c, r)
-            off += (r * c + 7) // 8 * 8
-            self.descs[i] = L.WPrepDesc(src.data_ptr(), dst.data_ptr(), dst_t.data_ptr(), r, c, kw)
-            self.cache[id(key)] = (dst, dst_t)
-        self._src_ptrs = [e[1].data_ptr() for e in entries]
-        # device-resident descriptor table + tile prefix for the single-launch kernel
-        import ctypes as C
-        import numpy as np
+        starts = [0]
+        for i, (src, r, c, kw, tap, dst, dst_t, ld, ld_t) in enumerate(jobs):
+            self.descs[i] = L.WPrepDesc(src.data_ptr(), dst.data_ptr() if dst is not None else None,
+                                        dst_t.data_ptr() if dst_t is not None else None, r, c, kw, tap, ld, ld_t)
+            starts.append(starts[-1] + ((r + 31) // 32) * ((c + 31) // 32))
+        self.params = [j[0] for j in jobs]
+        self._src_ptrs = [p.data_ptr() for p in self.params]
         raw = np.frombuffer(C.string_at(C.addressof(self.descs), C.sizeof(self.descs)), dtype=np.uint8).copy()
         self.descs_dev = torch.from_numpy(raw).to(dev)
-        starts = [0]
-        for _, _, r, c, _ in entries:
-            starts.append(starts[-1] + ((r + 31) // 32) * ((c + 31) // 32))
         self.total_tiles = starts[-1]
         self.tile_start_dev = torch.tensor(starts, dtype=torch.int32, device=dev)
 
@@ -123,7 +140,7 @@ class WeightCache:
         for i, p in enumerate(self.params):               # parameters may have been re-pointed (e.g. .to(), load)
             if p.data_ptr() != self._src_ptrs[i]:
                 raise RuntimeError("WeightCache: a parameter's storage moved; rebuild the Stepper")
-        L.check(L.lib().a8_prepare_weights_device(L.dt(self.arena), L.ptr(self.descs_dev), L.ptr(self.tile_start_dev), self.n,
+        L.check(L.lib().a8_prepare_weights_device(L.dt(self._keep[0]), L.ptr(self.descs_dev), L.ptr(self.tile_start_dev), self.n,
                                                   self.total_tiles, L.stream()), "a8_prepare_weights_device")
 
 
@@ -233,6 +250,7 @@ class Stepper:
             self.wcache = WeightCache(model, torch.bfloat16)
             self.wcache.refresh()
             ops.WEIGHT_CACHE, ops.WEIGHT_CACHE_DTYPE = self.wcache.cache, torch.bfloat16
+            ops.CONV_DGRAD_CACHE = self.wcache.conv_dgrad
         self._versions = [p._version for p in self.state.params]
         if self.reducer.enabled:                         # C1 of SURVEY 2.2: rank 0's parameters everywhere
             dist.broadcast(self.state.flat_p, src=0)
@@ -260,6 +278,7 @@ class Stepper:
         ops.WGRAD_SIDE_STREAM = None
         ops.WEIGHT_CACHE = None
         ops.WEIGHT_CACHE_DTYPE = None
+        ops.CONV_DGRAD_CACHE = None
 
     def step(self):
         if self.wgrad_stream is not None:                # join the weight-gradient stream before gradients are read

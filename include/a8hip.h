@@ -42,7 +42,7 @@ typedef struct a8_gemm_desc {
     void* C;       int64_t ldc, c_rpb, c_bs;
     const float* bias;  int bias_rows;   /* bias[N] (or bias[M] when bias_rows) */
     int act;                              /* A8_ACT_* ; MUL_GELU_GRAD multiplies by gelu'(zin) */
-    const void* zin; void* zout; int64_t ldz;   /* zout: pre-activation copy (dtype), same rows as C */
+    const void* zin; void* zout; int64_t ldz, z_rpb, z_bs;   /* zout: pre-activation copy (dtype); z rows use their own remap */
     int out_f32;                          /* C is f32 regardless of dtype */
     int accumulate;                       /* C += (f32 atomics) */
     int splitk;                           /* >1: split the K range over workgroups (f32 atomics) */
@@ -54,7 +54,12 @@ int a8_set_tuning(int key, int value);
 
 /* ---- per-step weight preparation (the f32 -> compute-dtype casts the reference's autocast-free f32 path never needs;
  * conv kernels [rows][cols/kw][kw] are re-laid-out to [rows][kk*(cols/kw) + ci]).  dst [rows][cols] and/or dstT [cols][rows]. */
-typedef struct a8_wprep_desc { const float* src; void* dst; void* dstT; int rows, cols, kw; } a8_wprep_desc;
+typedef struct a8_wprep_desc {
+    const float* src; void* dst; void* dstT;
+    int rows, cols, kw;      /* logical [rows][cols]; kw > 1: src is a conv kernel [rows][cols/kw][kw] */
+    int tap;                 /* -1: all taps, column c = kk*(cols/kw)+ci; >= 0: single tap, src[(r*cols + c)*kw + tap] */
+    int ld_dst, ld_dstT;     /* leading dimensions of dst / dstT (0: dense) */
+} a8_wprep_desc;
 int a8_prepare_weights(int dtype, const a8_wprep_desc* descs /* host array */, int n, void* stream);
 /* one-launch form: descs and tile_start (n+1 ints, prefix sums of ceil(rows/32)*ceil(cols/32)) in device memory */
 int a8_prepare_weights_device(int dtype, const a8_wprep_desc* descs_dev, const int* tile_start_dev, int n, int total_tiles, void* stream);
