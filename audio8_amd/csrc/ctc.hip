@@ -4,22 +4,38 @@
 // The alpha/beta recurrences over the 2S+1 extended labels are serial in time and tiny per step, so the
 // kernel is latency-bound: each lane keeps a CONTIGUOUS run of SPL states in registers, the s-1 / s-2
 // neighbours of a run's first states come from the previous lane by wave shuffle, and nothing but the
-// per-frame class probabilities passes through LDS.  Instead of ATen's log-space recursion (whose f32
-// values reach about -2000 at T = 624, one ulp = 1.2e-4) the kernel uses the scaled linear-domain
-// forward-backward: alpha-hat is renormalised every frame by c_t, log-likelihood = sum log c_t, and
-// the posterior occupancy is alpha-hat * beta-hat / Z -- no exp/log in the inner loop and ~1e-6 relative
-// accuracy in f32 (checked against the f64 oracle).
+// per-frame class log-probabilities passes through LDS.
+//
+// Numerics: ATen recurses on raw log-alpha, whose f32 values reach about -2000 at T = 624 (one ulp = 1.2e-4, so
+// its own gradients carry ~1e-3 of noise).  Here the recursion runs in the log2 domain on PER-FRAME-NORMALISED
+// values: after every frame log2-alpha is shifted by the frame's log-sum (kept separately), so the stored numbers
+// stay near 0 where f32 resolves ~1e-7, while tight alignments (T barely above S), whose end-state mass is
+// 1e-40 of the prefix mass, neither underflow nor lose precision.  Posteriors are normalised per frame.
 #include "a8_common.h"
 #include "a8hip_internal.h"
 
 namespace {
+
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+constexpr float NEG = -INFINITY;
+
+A8_DEV float lse2_3(float a, float b, float c) {           // log2(2^a + 2^b + 2^c), -inf safe
+    const float m = fmaxf(a, fmaxf(b, c));
+    if (m == NEG) return NEG;
+    return m + log2f(exp2f(a - m) + exp2f(b - m) + exp2f(c - m));
+}
+A8_DEV float wave_lse2(float v) {                            // log2 sum_lanes 2^v, -inf safe
+    const float m = wave_max(v);
+    if (m == NEG) return NEG;
+    return m + log2f(wave_sum(exp2f(v - m)));
+}
 
 template <int SPL>
 __global__ __launch_bounds__(64) void ctc_kernel(const float* __restrict__ lp, const int32_t* __restrict__ targets,
                                                  const int32_t* __restrict__ tgt_off, const int32_t* __restrict__ in_len,
                                                  float* __restrict__ nll, float* __restrict__ grad, float* __restrict__ abuf,
                                                  int Tmax, int B, int V, int Lmax, int blank, int zero_infinity) {
-    extern __shared__ float sm[];            // pr[V] | occ[V]
+    extern __shared__ float sm[];            // pr[V] (log2 class probabilities of the frame) | occ[V]
     float* pr = sm;
     float* occ = sm + V;
     const int b = blockIdx.x, lane = threadIdx.x;
@@ -28,13 +44,12 @@ __global__ __launch_bounds__(64) void ctc_kernel(const float* __restrict__ lp, c
     int Tb = in_len[b];
     if (Tb > Tmax) Tb = Tmax;
     const int32_t* lab = targets + tgt_off[b];
-    const long long astride = Lmax + 1;      // per-frame record: alpha-hat[0..Lmax) then c_t
-    float* ab = abuf + (long long)b * Tmax * astride;
+    float* ab = abuf + (long long)b * Tmax * Lmax;       // normalised log2-alpha of every frame
 
     // gradient defaults to zero (frames beyond the input length, infeasible utterances)
     for (int t = 0; t < Tmax; ++t)
         for (int c = lane; c < V; c += 64) grad[((long long)t * B + b) * V + c] = 0.f;
-    if (Tb <= 0) { if (lane == 0) nll[b] = zero_infinity ? 0.f : INFINITY; return; }
+    if (Tb <= 0 || L > 64 * SPL) { if (lane == 0) nll[b] = zero_infinity ? 0.f : INFINITY; return; }
 
     int ext[SPL];
     bool skip[SPL];
@@ -46,103 +61,118 @@ __global__ __launch_bounds__(64) void ctc_kernel(const float* __restrict__ lp, c
     }
     float a[SPL];
 #pragma unroll
-    for (int j = 0; j < SPL; ++j) a[j] = 0.f;
-    float ll = 0.f;
-    bool dead = false;
-    // ---------------- forward (alpha-hat), scaled per frame
+    for (int j = 0; j < SPL; ++j) a[j] = NEG;
+    float ll2 = 0.f;                         // log2-likelihood accumulated from the per-frame normalisers
+    // ---------------- forward
     for (int t = 0; t < Tb; ++t) {
         __syncthreads();
-        for (int c = lane; c < V; c += 64) pr[c] = __expf(lp[((long long)t * B + b) * V + c]);
+        for (int c = lane; c < V; c += 64) pr[c] = lp[((long long)t * B + b) * V + c] * LOG2E;
         __syncthreads();
         float na[SPL];
         if (t == 0) {
 #pragma unroll
-            for (int j = 0; j < SPL; ++j) { const int s = lane * SPL + j; na[j] = (s < 2 && s < L) ? pr[ext[j]] : 0.f; }
+            for (int j = 0; j < SPL; ++j) { const int s = lane * SPL + j; na[j] = (s < 2 && s < L) ? pr[ext[j]] : NEG; }
         } else {
             const float up1 = __shfl_up(a[SPL - 1], 1, 64);
             const float up2 = SPL >= 2 ? __shfl_up(a[SPL >= 2 ? SPL - 2 : 0], 1, 64) : __shfl_up(a[0], 2, 64);
-            const float p1 = lane >= 1 ? up1 : 0.f;
-            const float p2 = SPL >= 2 ? (lane >= 1 ? up2 : 0.f) : (lane >= 2 ? up2 : 0.f);
+            const float p1 = lane >= 1 ? up1 : NEG;
+            const float p2 = SPL >= 2 ? (lane >= 1 ? up2 : NEG) : (lane >= 2 ? up2 : NEG);
 #pragma unroll
             for (int j = 0; j < SPL; ++j) {
                 const int s = lane * SPL + j;
                 const float m1 = j >= 1 ? a[j >= 1 ? j - 1 : 0] : p1;
                 const float m2 = j >= 2 ? a[j >= 2 ? j - 2 : 0] : (j == 1 ? p1 : p2);
-                float v = a[j] + m1 + (skip[j] ? m2 : 0.f);
-                na[j] = s < L ? v * pr[ext[j]] : 0.f;
+                const float v = lse2_3(a[j], m1, skip[j] ? m2 : NEG);
+                na[j] = s < L ? v + pr[ext[j]] : NEG;
             }
         }
-        float c = 0.f;
+        float mx = NEG;
 #pragma unroll
-        for (int j = 0; j < SPL; ++j) c += na[j];
-        c = wave_sum(c);
-        const float ic = c > 0.f ? 1.0f / c : 0.f;
-        if (!(c > 0.f)) dead = true;
-        ll += __logf(c);
+        for (int j = 0; j < SPL; ++j) mx = fmaxf(mx, na[j]);
+        mx = wave_max(mx);
+        float sum = 0.f;
+        if (mx != NEG) {
+#pragma unroll
+            for (int j = 0; j < SPL; ++j) sum += exp2f(na[j] - mx);
+        }
+        sum = wave_sum(sum);
+        const float c2 = mx == NEG ? NEG : mx + log2f(sum);          // log2 of the frame's total mass
+        if (c2 == NEG) {                                             // no alignment survives: infeasible
+            if (lane == 0) nll[b] = zero_infinity ? 0.f : INFINITY;
+            return;
+        }
+        ll2 += c2;
 #pragma unroll
         for (int j = 0; j < SPL; ++j) {
-            a[j] = na[j] * ic;
+            a[j] = na[j] - c2;
             const int s = lane * SPL + j;
-            if (s < L) ab[(long long)t * astride + s] = a[j];
+            if (s < L) ab[(long long)t * Lmax + s] = a[j];
         }
-        if (lane == 0) ab[(long long)t * astride + Lmax] = c;
     }
-    // termination: Z = alpha-hat_{T-1}(L-1) + alpha-hat_{T-1}(L-2)
-    float z = 0.f;
+    // termination: log2 Z = log2(alpha_{T-1}(L-1) + alpha_{T-1}(L-2)) in normalised units
+    float zt = NEG;
 #pragma unroll
-    for (int j = 0; j < SPL; ++j) { const int s = lane * SPL + j; if (s == L - 1 || (s == L - 2 && s >= 0)) z += a[j]; }
-    z = wave_sum(z);
-    if (dead || !(z > 0.f)) {                 // infeasible alignment: loss = inf (zero_infinity -> 0, zero gradient)
+    for (int j = 0; j < SPL; ++j) { const int s = lane * SPL + j; if (s == L - 1 || s == L - 2) zt = zt == NEG ? a[j] : lse2_3(zt, a[j], NEG); }
+    const float z2 = wave_lse2(zt);
+    if (z2 == NEG) {
         if (lane == 0) nll[b] = zero_infinity ? 0.f : INFINITY;
         return;
     }
-    if (lane == 0) nll[b] = -(ll + __logf(z));
-    const float iz = 1.0f / z;
-    // ---------------- backward (beta-hat) + gradient
+    if (lane == 0) nll[b] = -(ll2 + z2) * LN2;
+    // ---------------- backward + gradient (beta excludes the emission of its own frame; re-normalised per frame)
     float bt[SPL];
 #pragma unroll
-    for (int j = 0; j < SPL; ++j) { const int s = lane * SPL + j; bt[j] = (s == L - 1 || s == L - 2) && s >= 0 && s < L ? 1.f : 0.f; }
+    for (int j = 0; j < SPL; ++j) { const int s = lane * SPL + j; bt[j] = (s < L && (s == L - 1 || s == L - 2)) ? 0.f : NEG; }
     for (int t = Tb - 1; t >= 0; --t) {
         __syncthreads();
-        for (int c = lane; c < V; c += 64) { pr[c] = __expf(lp[((long long)t * B + b) * V + c]); occ[c] = 0.f; }
+        for (int c = lane; c < V; c += 64) { pr[c] = lp[((long long)t * B + b) * V + c] * LOG2E; occ[c] = 0.f; }
         __syncthreads();
-        // occupancy of frame t
+        // posterior occupancy of frame t: 2^(alpha + beta) normalised over the states
+        float g2[SPL];
+        float mx = NEG;
 #pragma unroll
         for (int j = 0; j < SPL; ++j) {
             const int s = lane * SPL + j;
-            if (s < L) {
-                const float gam = ab[(long long)t * astride + s] * bt[j] * iz;
-                if (gam != 0.f) atomicAdd(&occ[ext[j]], gam);
-            }
+            g2[j] = s < L ? ab[(long long)t * Lmax + s] + bt[j] : NEG;
+            mx = fmaxf(mx, g2[j]);
         }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) { g2[j] = g2[j] == NEG ? 0.f : exp2f(g2[j] - mx); sum += g2[j]; }
+        const float inv = 1.0f / wave_sum(sum);
+#pragma unroll
+        for (int j = 0; j < SPL; ++j)
+            if (g2[j] != 0.f) atomicAdd(&occ[ext[j]], g2[j] * inv);
         __syncthreads();
-        for (int c = lane; c < V; c += 64) grad[((long long)t * B + b) * V + c] = pr[c] - occ[c];
+        for (int c = lane; c < V; c += 64) grad[((long long)t * B + b) * V + c] = exp2f(pr[c]) - occ[c];
         if (t == 0) break;
-        // beta-hat_{t-1}(s) = sum_{s' in {s, s+1, s+2 if skip(s+2)}} beta-hat_t(s') p_t(s') / c_t
-        const float ict = 1.0f / ab[(long long)t * astride + Lmax];
+        // beta_{t-1}(s) = sum_{s' in {s, s+1, s+2 if skip(s+2)}} beta_t(s') p_t(s'), then shift by the frame's log-sum
         float w[SPL];
         bool sk[SPL];
 #pragma unroll
-        for (int j = 0; j < SPL; ++j) { w[j] = bt[j] * pr[ext[j]]; sk[j] = skip[j]; }
+        for (int j = 0; j < SPL; ++j) { w[j] = bt[j] + pr[ext[j]]; sk[j] = skip[j]; }
         const float dn1 = __shfl_down(w[0], 1, 64);
         const float dn2 = SPL >= 2 ? __shfl_down(w[SPL >= 2 ? 1 : 0], 1, 64) : __shfl_down(w[0], 2, 64);
         const int dsk1i = __shfl_down((int)sk[0], 1, 64);
         const int dsk2i = SPL >= 2 ? __shfl_down((int)sk[SPL >= 2 ? 1 : 0], 1, 64) : __shfl_down((int)sk[0], 2, 64);
         const bool has1 = lane < 63, has2 = SPL >= 2 ? lane < 63 : lane < 62;
         float nb[SPL];
+        float bm = NEG;
 #pragma unroll
         for (int j = 0; j < SPL; ++j) {
             const int s = lane * SPL + j;
-            const float n1 = j + 1 < SPL ? w[j + 1 < SPL ? j + 1 : 0] : (has1 ? dn1 : 0.f);
+            const float n1 = j + 1 < SPL ? w[j + 1 < SPL ? j + 1 : 0] : (has1 ? dn1 : NEG);
             float n2; bool s2;
             if (j + 2 < SPL) { n2 = w[j + 2 < SPL ? j + 2 : 0]; s2 = sk[j + 2 < SPL ? j + 2 : 0]; }
-            else if (j + 1 < SPL) { n2 = has1 ? dn1 : 0.f; s2 = has1 && dsk1i; }       // j == SPL-2: s+2 is next lane's state 0
-            else if (SPL >= 2) { n2 = has2 ? dn2 : 0.f; s2 = has2 && dsk2i; }           // j == SPL-1: next lane's state 1
-            else { n2 = has2 ? dn2 : 0.f; s2 = has2 && dsk2i; }                          // SPL == 1: lane+2's state
-            nb[j] = s < L ? (w[j] + n1 + (s2 ? n2 : 0.f)) * ict : 0.f;
+            else if (j + 1 < SPL) { n2 = has1 ? dn1 : NEG; s2 = has1 && dsk1i; }       // j == SPL-2: next lane's state 0
+            else { n2 = has2 ? dn2 : NEG; s2 = has2 && dsk2i; }                          // next lane's state 1 (or lane+2's, SPL == 1)
+            nb[j] = s < L ? lse2_3(w[j], n1, s2 ? n2 : NEG) : NEG;
+            bm = fmaxf(bm, nb[j]);
         }
+        bm = wave_max(bm);                     // keep beta near 0: subtract the frame maximum (any shift cancels in the posterior)
 #pragma unroll
-        for (int j = 0; j < SPL; ++j) bt[j] = nb[j];
+        for (int j = 0; j < SPL; ++j) bt[j] = nb[j] == NEG ? NEG : nb[j] - bm;
     }
 }
 

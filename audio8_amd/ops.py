@@ -402,8 +402,18 @@ class ConvStackFn(torch.autograd.Function):
             M = B * Lout
             dzrows = Lout + 2 * pad
             akw = dict(a_off=pad * co, a_rpb=Lout, a_bs=dzrows * co) if pad else {}
-            dw2 = wgrad(dz, acts[i - 1], co, k * cin, M, ldb=s * cin, b_rpb=Lout, b_bs=Lin * cin, lda=co, **akw)
-            grads[i] = dw2.view(co, k, cin).permute(0, 2, 1).contiguous()
+            tgt = _target(ws[i])
+            if tgt is not None:
+                # off the critical path: wgrad GEMM + re-layout [co][k][cin] -> [co][cin][k] + accumulate on the side stream
+                def run(dz=dz, a=acts[i - 1], co=co, k=k, cin=cin, M=M, s=s, Lout=Lout, Lin=Lin, akw=akw, tgt=tgt, p=ws[i]):
+                    dw2 = wgrad(dz, a, co, k * cin, M, ldb=s * cin, b_rpb=Lout, b_bs=Lin * cin, lda=co, **akw)
+                    tgt.add_(dw2.view(co, k, cin).permute(0, 2, 1))
+                    _ready(p)
+                _on_side(run, dz, acts[i - 1])
+                grads[i] = None
+            else:
+                dw2 = wgrad(dz, acts[i - 1], co, k * cin, M, ldb=s * cin, b_rpb=Lout, b_bs=Lin * cin, lda=co, **akw)
+                grads[i] = dw2.view(co, k, cin).permute(0, 2, 1).contiguous()
             zprev = zs[i - 1] if i - 1 >= 1 else None
             if not fusable:
                 dcol = _dgrad(dz, wcs[i], ctx.wcTs[i], M, k * cin, co)
