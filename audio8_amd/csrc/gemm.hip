@@ -109,7 +109,15 @@ __global__ __launch_bounds__(256, (NST * 2 * 8192 * KB <= 65536) ? 2 : 1) void g
     const int bid = xcd_remap(blockIdx.x, nblk);
     const int split = bid / (g.tiles_m * g.tiles_n);
     const int tile = bid - split * (g.tiles_m * g.tiles_n);
-    const int m0 = (tile / g.tiles_n) * 128, n0 = (tile % g.tiles_n) * 128;
+    // grouped tile order: consecutive ids (= one XCD's co-resident blocks) cover GROUP_M m-tiles x several n-tiles, so
+    // both the A row-panels and the B tiles they touch stay resident in that XCD's 4 MB L2 (sweeping all n-tiles per
+    // m-panel streamed the whole weight matrix through L2 once per panel: 5-10x over-fetch measured with FETCH_SIZE).
+    constexpr int GROUP_M = 8;
+    const int tpg = GROUP_M * g.tiles_n;
+    const int grp = tile / tpg, first_m = grp * GROUP_M;
+    const int gsz = min(GROUP_M, g.tiles_m - first_m);
+    const int tin = tile - grp * tpg;
+    const int m0 = (first_m + tin % gsz) * 128, n0 = (tin / gsz) * 128;
     const int kbeg = split * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
     const int nkb = (kend - kbeg + BK - 1) / BK;
@@ -213,23 +221,33 @@ __global__ __launch_bounds__(256, (NST * 2 * 8192 * KB <= 65536) ? 2 : 1) void g
         // stage kb has landed once all but the (NST-2) youngest stages' DMAs of this wave are done (2*PPW per stage per lane)
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NST - 2) * 2 * PPW) : "memory");
         __builtin_amdgcn_s_barrier();
-        issue(kb + NST - 1);                  // refills the buffer every wave finished reading last iteration
+        // DMA issue order, measured: with plain b128 fragment reads (NT) issuing the refill first is best; with
+        // transposed reads (twice the LDS instructions) issuing it after the reads hides its issue slots in their latency
+        if constexpr (!(AKS || BKS)) issue(kb + NST - 1);
         const char* ta = lds + (kb % NST) * 2 * TILE;
         const char* tb = ta + TILE;
+        // all fragment reads of the k-tile are issued up front (one exposed LDS latency per tile, counted lgkmcnt waits
+        // after that), pinned ahead of the MFMA block
+        typename MM::Frag fa[ST::KSTEPS][4], fb[ST::KSTEPS][4];
 #pragma unroll
-        for (int ks = 0; ks < ST::KSTEPS; ++ks) {
-            typename MM::Frag fa[4], fb[4];
+        for (int ks = 0; ks < ST::KSTEPS; ++ks)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                fa[i] = AKS ? ST::ks_frag(ta, wm * 64 + 16 * i, ks, lane) : ST::kc_frag(ta, wm * 64 + 16 * i, ks, lane);
-                fb[i] = BKS ? ST::ks_frag(tb, wn * 64 + 16 * i, ks, lane) : ST::kc_frag(tb, wn * 64 + 16 * i, ks, lane);
+                fa[ks][i] = AKS ? ST::ks_frag(ta, wm * 64 + 16 * i, ks, lane) : ST::kc_frag(ta, wm * 64 + 16 * i, ks, lane);
+                fb[ks][i] = BKS ? ST::ks_frag(tb, wn * 64 + 16 * i, ks, lane) : ST::kc_frag(tb, wn * 64 + 16 * i, ks, lane);
             }
-            // swapped operands: accumulator reg r <-> 4 consecutive n, lane&15 <-> m  (vector C stores)
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (AKS || BKS) {
+            issue(kb + NST - 1);              // refills the buffer every wave finished reading last iteration
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // swapped operands: accumulator reg r <-> 4 consecutive n, lane&15 <-> m  (row-contiguous C stores)
+#pragma unroll
+        for (int ks = 0; ks < ST::KSTEPS; ++ks)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = MM::mma(fb[j], fa[i], acc[i][j]);
-        }
+                for (int j = 0; j < 4; ++j) acc[i][j] = MM::mma(fb[ks][j], fa[ks][i], acc[i][j]);
     }
     // no DMA may still be in flight, and every wave must be done reading the ring, before LDS is reused
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
