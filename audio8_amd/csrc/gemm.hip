@@ -93,18 +93,20 @@ template <int KB> struct StageTile<float, KB> {
 
 // Main loop: NST-deep ring of LDS stages filled by LDS-DMA (global_load_lds, 16 B per lane), NST-1 k-tiles in
 // flight per block; one raw s_barrier and one counted s_waitcnt vmcnt per k-tile; no register staging.
-template <typename T, bool AKS, bool BKS, int KB, int NST>
-__global__ __launch_bounds__(256, (NST * 2 * 8192 * KB <= 65536) ? 2 : 1) void gemm_kernel(const GemmArgs g) {
+template <typename T, bool AKS, bool BKS, int KB, int NST, int NWM>
+__global__ __launch_bounds__(128 * NWM, (NST * 2 * 8192 * KB <= 65536) ? NWM : NWM / 2) void gemm_kernel(const GemmArgs g) {
     typedef StageTile<T, KB> ST;
     typedef KcGeom<KB> G;
     typedef Mma<T> MM;
     constexpr int BK = ST::BK, TILE = G::OPBYTES, EPC = 16 / (int)sizeof(T), SZ = (int)sizeof(T);
-    constexpr int PPW = G::NPIECE / 4;            // LDS-DMA pieces per wave per operand per stage
+    constexpr int NW = 2 * NWM;                   // waves per block: NWM along M x 2 along N; a wave owns (64 * 2 / NWM) x 64 of the tile
+    constexpr int MI = 8 / NWM;                   // 16-row fragments per wave along M (4 or 2)
+    constexpr int PPW = G::NPIECE / NW;           // LDS-DMA pieces per wave per operand per stage
     __shared__ __attribute__((aligned(1024))) char lds[NST * 2 * TILE];
 
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = w >> 1, wn = w & 1;
+    const int wm = w >> 1, wn = w & 1;            // wm in [0, NWM)
     const int nblk = g.tiles_m * g.tiles_n * g.nsplit;
     const int bid = xcd_remap(blockIdx.x, nblk);
     const int split = bid / (g.tiles_m * g.tiles_n);
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256, (NST * 2 * 8192 * KB <= 65536) ? 2 : 1) void g
     const char* b_ptr[PPW]; int b_k[PPW]; bool b_ok[PPW];
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
-        const int p = w + 4 * j;
+        const int p = w + NW * j;
         if constexpr (!AKS) {
             const int rl = G::RPP * p + lane / G::SPR, row = m0 + rl;
             a_k[j] = (((lane % G::SPR) ^ G::swz(rl)) & (G::SPR - 1)) * EPC;
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(256, (NST * 2 * 8192 * KB <= 65536) ? 2 : 1) void g
         const int k0 = kbeg + kb * BK;
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
-            const int p = w + 4 * j;
+            const int p = w + NW * j;
             const char* sa;
             if constexpr (!AKS) {
                 const int k = k0 + a_k[j];
@@ -209,9 +211,9 @@ __global__ __launch_bounds__(256, (NST * 2 * 8192 * KB <= 65536) ? 2 : 1) void g
         }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[MI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -228,14 +230,16 @@ __global__ __launch_bounds__(256, (NST * 2 * 8192 * KB <= 65536) ? 2 : 1) void g
         const char* tb = ta + TILE;
         // all fragment reads of the k-tile are issued up front (one exposed LDS latency per tile, counted lgkmcnt waits
         // after that), pinned ahead of the MFMA block
-        typename MM::Frag fa[ST::KSTEPS][4], fb[ST::KSTEPS][4];
+        typename MM::Frag fa[ST::KSTEPS][MI], fb[ST::KSTEPS][4];
 #pragma unroll
-        for (int ks = 0; ks < ST::KSTEPS; ++ks)
+        for (int ks = 0; ks < ST::KSTEPS; ++ks) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                fa[ks][i] = AKS ? ST::ks_frag(ta, wm * 64 + 16 * i, ks, lane) : ST::kc_frag(ta, wm * 64 + 16 * i, ks, lane);
+            for (int i = 0; i < MI; ++i)
+                fa[ks][i] = AKS ? ST::ks_frag(ta, wm * (16 * MI) + 16 * i, ks, lane) : ST::kc_frag(ta, wm * (16 * MI) + 16 * i, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
                 fb[ks][i] = BKS ? ST::ks_frag(tb, wn * 64 + 16 * i, ks, lane) : ST::kc_frag(tb, wn * 64 + 16 * i, ks, lane);
-            }
+        }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (AKS || BKS) {
             issue(kb + NST - 1);              // refills the buffer every wave finished reading last iteration
@@ -245,7 +249,7 @@ __global__ __launch_bounds__(256, (NST * 2 * 8192 * KB <= 65536) ? 2 : 1) void g
 #pragma unroll
         for (int ks = 0; ks < ST::KSTEPS; ++ks)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = MM::mma(fb[ks][j], fa[ks][i], acc[i][j]);
     }
@@ -257,11 +261,12 @@ __global__ __launch_bounds__(256, (NST * 2 * 8192 * KB <= 65536) ? 2 : 1) void g
     // walks it row by row so that every global store / f32 atomic wave-instruction is ONE contiguous row segment
     // (256 B of f32, 128 B of bf16) instead of 16 rows x 16 B -- the shape the memory-side atomic units need.
     static_assert(NST * 2 * TILE >= 65536, "epilogue staging needs 64 KB of LDS");
-    float* cw = reinterpret_cast<float*>(lds) + w * 4096;
+    constexpr int WROWS = 16 * MI;                                    // rows of the tile owned by a wave
+    float* cw = reinterpret_cast<float*>(lds) + w * (WROWS * 64);
     {
         const int g4 = lane >> 4, li = lane & 15;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 f32x4 v = acc[i][j];
@@ -270,14 +275,14 @@ __global__ __launch_bounds__(256, (NST * 2 * 8192 * KB <= 65536) ? 2 : 1) void g
             }
     }
     __builtin_amdgcn_wave_barrier();      // the tile is wave-private: program order of this wave's LDS ops suffices
-    const int mw = m0 + wm * 64, nw = n0 + wn * 64;
+    const int mw = m0 + wm * WROWS, nw = n0 + wn * 64;
     auto zrow = [&](int m) -> long long { return g.z_rpb ? (m / g.z_rpb) * g.z_bs + (m % g.z_rpb) * g.ldz : (long long)m * g.ldz; };
     const bool f32_rows = g.out_f32 || sizeof(T) == 4;
     if (f32_rows) {
         const int n = nw + lane;
         const bool n_ok = n < g.N;
         const float bn = (g.bias && !g.bias_rows && n_ok) ? g.bias[n] : 0.f;
-        for (int rr = 0; rr < 64; ++rr) {
+        for (int rr = 0; rr < WROWS; ++rr) {
             const int m = mw + rr;
             if (m >= g.M) break;
             float v = cw[rr * 64 + ((((lane >> 2) ^ (rr & 15))) << 2) + (lane & 3)] + bn;
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(256, (NST * 2 * 8192 * KB <= 65536) ? 2 : 1) void g
 #pragma unroll
         for (int e = 0; e < 8; ++e) bn[e] = (g.bias && !g.bias_rows && n_ok) ? g.bias[n + e] : 0.f;
         typedef T T8 __attribute__((ext_vector_type(8)));
-        for (int it = 0; it < 8; ++it) {
+        for (int it = 0; it < WROWS / 8; ++it) {
             if (mw + 8 * it >= g.M) break;
             const int rr = 8 * it + (lane >> 3);
             const int m = mw + rr;
@@ -335,13 +340,15 @@ __global__ __launch_bounds__(256, (NST * 2 * 8192 * KB <= 65536) ? 2 : 1) void g
     }
 }
 
-int g_variant = 2;      // tuning knob (a8_set_tuning): 0 = 128 B of K per row x 3 stages, 1 = 64 B x 4, 2 = 128 B x 2 (default: measured best), 3 = 64 B x 5
+int g_variant = 5;      // tuning knob (a8_set_tuning key 0): 5 = 128 B of K per row, 2-deep ring, 8 waves (default: measured best);
+                        // 2 = same with 4 waves; 1 = 64 B rows, 4-deep ring, 4 waves
 
-template <typename T, int KB, int NST> int launch2(const a8_gemm_desc* d, const GemmArgs& g, int grid, hipStream_t s) {
+template <typename T, int KB, int NST, int NWM> int launch2(const a8_gemm_desc* d, const GemmArgs& g, int grid, hipStream_t s) {
+    const dim3 blk(128 * NWM);
     switch (d->layout) {
-        case A8_GEMM_NT: hipLaunchKernelGGL((gemm_kernel<T, false, false, KB, NST>), dim3(grid), dim3(256), 0, s, g); break;
-        case A8_GEMM_NN: hipLaunchKernelGGL((gemm_kernel<T, false, true, KB, NST>), dim3(grid), dim3(256), 0, s, g); break;
-        case A8_GEMM_TN: hipLaunchKernelGGL((gemm_kernel<T, true, true, KB, NST>), dim3(grid), dim3(256), 0, s, g); break;
+        case A8_GEMM_NT: hipLaunchKernelGGL((gemm_kernel<T, false, false, KB, NST, NWM>), dim3(grid), blk, 0, s, g); break;
+        case A8_GEMM_NN: hipLaunchKernelGGL((gemm_kernel<T, false, true, KB, NST, NWM>), dim3(grid), blk, 0, s, g); break;
+        case A8_GEMM_TN: hipLaunchKernelGGL((gemm_kernel<T, true, true, KB, NST, NWM>), dim3(grid), blk, 0, s, g); break;
         default: return a8_set_error(A8_ERR_ARG, "a8_gemm: bad layout %d", d->layout);
     }
     return a8_check_launch("a8_gemm");
@@ -349,13 +356,12 @@ template <typename T, int KB, int NST> int launch2(const a8_gemm_desc* d, const 
 template <typename T> int launch(const a8_gemm_desc* d, const GemmArgs& g, int grid, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
         switch (g_variant) {
-            case 1: return launch2<T, 1, 4>(d, g, grid, s);
-            case 2: return launch2<T, 2, 2>(d, g, grid, s);
-            case 3: return launch2<T, 1, 5>(d, g, grid, s);
-            default: return launch2<T, 2, 3>(d, g, grid, s);
+            case 1: return launch2<T, 1, 4, 2>(d, g, grid, s);
+            case 5: return launch2<T, 2, 2, 4>(d, g, grid, s);      // 8 waves per block (4 waves/SIMD at 2 blocks/CU)
+            default: return launch2<T, 2, 2, 2>(d, g, grid, s);
         }
     } else {
-        return launch2<T, 1, 4>(d, g, grid, s);
+        return launch2<T, 1, 4, 2>(d, g, grid, s);
     }
 }
 
@@ -381,7 +387,7 @@ extern "C" int a8_gemm(const a8_gemm_desc* d, void* stream) {
     A8_REQUIRE(d->lda % epc == 0 && d->ldb % epc == 0 && d->ldc % 4 == 0, "a8_gemm: leading dimensions must keep 16-byte alignment");
     A8_REQUIRE(((uintptr_t)d->A % 16) == 0 && ((uintptr_t)d->B % 16) == 0 && ((uintptr_t)d->C % 16) == 0, "a8_gemm: pointers must be 16-byte aligned");
     A8_REQUIRE(d->a_bs % epc == 0 && d->b_bs % epc == 0, "a8_gemm: batch strides must keep 16-byte alignment");
-    const int bk = d->dtype == A8_BF16 ? ((g_variant == 1 || g_variant == 3) ? 32 : 64) : 16;
+    const int bk = d->dtype == A8_BF16 ? (g_variant == 1 ? 32 : 64) : 16;
     GemmArgs g;
     g.A = Op{(const char*)d->A, d->lda, d->a_rpb, d->a_bs};
     g.B = Op{(const char*)d->B, d->ldb, d->b_rpb, d->b_bs};

@@ -73,11 +73,10 @@ def _wcast(w, dtype):
 
 def _splitk(out_tiles, kred):
     """Split the reduction so the grid fills, but does not exceed, one round of the chip's 512 co-resident
-    128x128-tile blocks (2 per CU): 576 blocks would run as two rounds at 56 % utilisation."""
-    s = max(1, min(16, 512 // max(1, out_tiles)))
-    while s > 1 and kred // s < 256:
-        s -= 1
-    return s
+    128x128-tile blocks (576 blocks would run as two rounds at 56 % utilisation), while every split keeps at
+    least ~800 reduction rows (shorter splits are dominated by prologue + atomic epilogue; measured with
+    tools/splitk_sweep.py)."""
+    return max(1, min(16, 512 // max(1, out_tiles), kred // 800))
 
 
 def _tiles(m, n):

@@ -103,3 +103,27 @@ def test_gemm_rejects_bad_args():
     A = torch.zeros((16, 12), device="cuda", dtype=torch.bfloat16)
     with pytest.raises(RuntimeError, match="multiple of"):
         Kn.gemm(L.NT, A, A, 16, 16, 12)
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("layout", ["NT", "NN", "TN"])
+def test_gemm_tuning_variants_are_exact(variant, layout):
+    """Every stage-geometry / wave-count variant selectable through a8_set_tuning computes the same exact result."""
+    from audio8_amd import kernels as Kn, _lib as L
+    M, N, K = 264, 392, 200
+    A = _mk((M, K), torch.bfloat16, 21, integer=True)
+    B = _mk((N, K), torch.bfloat16, 22, integer=True)
+    ref = A.double() @ B.double().T
+    dev = "cuda"
+    L.check(L.lib().a8_set_tuning(0, variant))
+    try:
+        if layout == "NT":
+            out = Kn.gemm(L.NT, A.to(dev), B.to(dev), M, N, K, out_dtype=torch.float32)
+        elif layout == "NN":
+            out = Kn.gemm(L.NN, A.to(dev), B.T.contiguous().to(dev), M, N, K, out_dtype=torch.float32)
+        else:
+            out = Kn.gemm(L.TN, A.T.contiguous().to(dev), B.T.contiguous().to(dev), M, N, K, out_dtype=torch.float32)
+        torch.cuda.synchronize()
+    finally:
+        L.check(L.lib().a8_set_tuning(0, 5))
+    assert torch.equal(out.cpu().double(), ref)
