@@ -16,6 +16,47 @@ NT, NN, TN = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_MUL_GELU_GRAD = 0, 1, 2
 
 _lib = None
+_dev_index = None
+
+# ctypes signatures of every entry point of include/a8hip.h (generated from the header): with argtypes declared,
+# plain Python ints / floats / None are marshalled directly (no per-call c_void_p objects).
+ARGTYPES = {
+    "a8_version": [],
+    "a8_gemm": [C.c_void_p, C.c_void_p],
+    "a8_set_tuning": [C.c_int, C.c_int],
+    "a8_prepare_weights": [C.c_int, C.c_void_p, C.c_int, C.c_void_p],
+    "a8_prepare_weights_device": [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p],
+    "a8_conv0_gn_gelu_fwd": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p],
+    "a8_conv0_gn_gelu_bwd": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "a8_col2im_gelu_grad": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "a8_layernorm_fwd": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_void_p],
+    "a8_layernorm_bwd": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_uint32, C.c_uint32, C.c_void_p],
+    "a8_cast": [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
+    "a8_dropout": [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_uint32, C.c_uint32, C.c_void_p],
+    "a8_mask_fill_rows": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p],
+    "a8_mask_fill_rows_bwd": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p],
+    "a8_mask_zero_cols": [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "a8_zero_rows": [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p],
+    "a8_gather_rows": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p],
+    "a8_scatter_add_rows": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p],
+    "a8_add": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
+    "a8_posconv_fwd": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "a8_posconv_wgrad": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "a8_gelu_bwd_bias": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p],
+    "a8_attn_fwd": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_uint32, C.c_void_p],
+    "a8_attn_bwd": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_uint32, C.c_void_p],
+    "a8_vq_select": [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p],
+    "a8_vq_gather": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "a8_vq_ppl": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p],
+    "a8_vq_bwd": [C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "a8_contrastive_fwd": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "a8_contrastive_bwd": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "a8_ctc_fwd_bwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "a8_log_softmax_fwd": [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p],
+    "a8_log_softmax_bwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "a8_sumsq": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p],
+    "a8_adamw": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p],
+}
 
 
 class GemmDesc(C.Structure):
@@ -49,6 +90,10 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         _lib.a8_last_error.restype = C.c_char_p
         _lib.a8_version.restype = C.c_int
+        for name, argtypes in ARGTYPES.items():
+            fn = getattr(_lib, name)
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
     return _lib
 
 
@@ -67,11 +112,15 @@ def dt(t: torch.Tensor) -> int:
 
 
 def ptr(t):
-    return C.c_void_p(0 if t is None else t.data_ptr())
+    return None if t is None else t.data_ptr()
 
 
 def stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """Raw hipStream_t of torch's current stream on this process's device (one GPU per process)."""
+    global _dev_index
+    if _dev_index is None:
+        _dev_index = torch.cuda.current_device()
+    return torch._C._cuda_getCurrentRawStream(_dev_index)
 
 
 def require_cuda(*ts):

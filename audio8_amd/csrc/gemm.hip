@@ -358,6 +358,7 @@ template <typename T> int launch(const a8_gemm_desc* d, const GemmArgs& g, int g
         switch (g_variant) {
             case 1: return launch2<T, 1, 4, 2>(d, g, grid, s);
             case 5: return launch2<T, 2, 2, 4>(d, g, grid, s);      // 8 waves per block (4 waves/SIMD at 2 blocks/CU)
+            case 6: return launch2<T, 1, 4, 4>(d, g, grid, s);      // 8 waves, 64-byte rows, 4-deep ring
             default: return launch2<T, 2, 2, 2>(d, g, grid, s);
         }
     } else {
@@ -387,7 +388,7 @@ extern "C" int a8_gemm(const a8_gemm_desc* d, void* stream) {
     A8_REQUIRE(d->lda % epc == 0 && d->ldb % epc == 0 && d->ldc % 4 == 0, "a8_gemm: leading dimensions must keep 16-byte alignment");
     A8_REQUIRE(((uintptr_t)d->A % 16) == 0 && ((uintptr_t)d->B % 16) == 0 && ((uintptr_t)d->C % 16) == 0, "a8_gemm: pointers must be 16-byte aligned");
     A8_REQUIRE(d->a_bs % epc == 0 && d->b_bs % epc == 0, "a8_gemm: batch strides must keep 16-byte alignment");
-    const int bk = d->dtype == A8_BF16 ? (g_variant == 1 ? 32 : 64) : 16;
+    const int bk = d->dtype == A8_BF16 ? ((g_variant == 1 || g_variant == 6) ? 32 : 64) : 16;
     GemmArgs g;
     g.A = Op{(const char*)d->A, d->lda, d->a_rpb, d->a_bs};
     g.B = Op{(const char*)d->B, d->ldb, d->b_rpb, d->b_bs};

@@ -71,11 +71,11 @@ def gemm(layout, A, B, M, N, K, *, out=None, out_dtype=None, lda=None, ldb=None,
 
 # ----------------------------------------------------------------------------- helpers
 def _u32(x):
-    return C.c_uint32(int(x) & 0xFFFFFFFF)
+    return int(x) & 0xFFFFFFFF
 
 
 def _f(x):
-    return C.c_float(float(x))
+    return float(x)
 
 
 def conv_out_len(L, k, s):
@@ -138,13 +138,13 @@ def layernorm_bwd(dy, dy2, x, res, gamma, mean, rstd, dgamma, dbeta, p=0.0, seed
 # ----------------------------------------------------------------------------- element-wise
 def cast(src, dst_dtype):
     dst = torch.empty(src.shape, device=src.device, dtype=dst_dtype)
-    L.check(L.lib().a8_cast(L.dt(src), L.dt(dst), L.ptr(_c(src)), L.ptr(dst), C.c_int64(src.numel()), L.stream()), "a8_cast")
+    L.check(L.lib().a8_cast(L.dt(src), L.dt(dst), L.ptr(_c(src)), L.ptr(dst), int(src.numel()), L.stream()), "a8_cast")
     return dst
 
 
 def dropout(x, p, seed, rng_stream):
     y = torch.empty_like(x)
-    L.check(L.lib().a8_dropout(L.dt(x), L.ptr(_c(x)), L.ptr(y), C.c_int64(x.numel()), _f(p), _u32(seed), _u32(rng_stream), L.stream()), "a8_dropout")
+    L.check(L.lib().a8_dropout(L.dt(x), L.ptr(_c(x)), L.ptr(y), int(x.numel()), _f(p), _u32(seed), _u32(rng_stream), L.stream()), "a8_dropout")
     return y
 
 
@@ -187,7 +187,7 @@ def scatter_add_rows_(dst2d, idx_i32, src2d):
 
 def add(a, b):
     y = torch.empty_like(a)
-    L.check(L.lib().a8_add(L.dt(a), L.ptr(_c(a)), L.ptr(_c(b)), L.ptr(y), C.c_int64(a.numel()), L.stream()), "a8_add")
+    L.check(L.lib().a8_add(L.dt(a), L.ptr(_c(a)), L.ptr(_c(b)), L.ptr(y), int(a.numel()), L.stream()), "a8_add")
     return y
 
 
@@ -219,8 +219,8 @@ def attn_fwd(q, k, v, B, T, H, ld_qkv, scale, keymask=None, p=0.0, seed=0):
     """q,k,v: [B*T, ld_qkv] views (head h at columns h*64..); returns (o [B*T, H*64], lse f32 [B,H,T])."""
     o = torch.empty((B * T, H * 64), device=q.device, dtype=q.dtype)
     lse = torch.empty((B, H, T), device=q.device, dtype=torch.float32)
-    L.check(L.lib().a8_attn_fwd(L.dt(q), L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), L.ptr(lse), L.ptr(keymask), B, T, H, C.c_int64(ld_qkv),
-                                C.c_int64(H * 64), _f(scale), _f(p), _u32(seed), L.stream()), "a8_attn_fwd")
+    L.check(L.lib().a8_attn_fwd(L.dt(q), L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), L.ptr(lse), L.ptr(keymask), B, T, H, int(ld_qkv),
+                                int(H * 64), _f(scale), _f(p), _u32(seed), L.stream()), "a8_attn_fwd")
     return o, lse
 
 
@@ -232,7 +232,7 @@ def attn_bwd(q, k, v, o, dout, lse, B, T, H, ld_qkv, scale, keymask=None, p=0.0,
     delta = torch.empty((B, H, T), device=q.device, dtype=torch.float32)
     dq, dk, dv = dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:]
     L.check(L.lib().a8_attn_bwd(L.dt(q), L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), L.ptr(_c(dout)), L.ptr(lse), L.ptr(keymask),
-                                L.ptr(dq), L.ptr(dk), L.ptr(dv), L.ptr(delta), B, T, H, C.c_int64(ld_qkv), C.c_int64(d), C.c_int64(3 * d),
+                                L.ptr(dq), L.ptr(dk), L.ptr(dv), L.ptr(delta), B, T, H, int(ld_qkv), int(d), int(3 * d),
                                 _f(scale), _f(p), _u32(seed), L.stream()), "a8_attn_bwd")
     return dq, dk, dv, dqkv
 
@@ -317,11 +317,11 @@ def log_softmax_bwd(y, dy, dtype):
 
 # ----------------------------------------------------------------------------- optimizer
 def sumsq_(x, out):
-    L.check(L.lib().a8_sumsq(L.ptr(x), C.c_int64(x.numel()), L.ptr(out), L.stream()), "a8_sumsq")
+    L.check(L.lib().a8_sumsq(L.ptr(x), int(x.numel()), L.ptr(out), L.stream()), "a8_sumsq")
 
 
 def adamw_(p, g, m, v, lr, beta1, beta2, eps, wd, step, gnorm_sq=None, max_norm=0.0, grad_scale=1.0):
-    L.check(L.lib().a8_adamw(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), C.c_int64(p.numel()), _f(lr), _f(beta1), _f(beta2), _f(eps), _f(wd),
+    L.check(L.lib().a8_adamw(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), int(p.numel()), _f(lr), _f(beta1), _f(beta2), _f(eps), _f(wd),
                              int(step), L.ptr(gnorm_sq), _f(max_norm), _f(grad_scale), L.stream()), "a8_adamw")
 
 

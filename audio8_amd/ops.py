@@ -18,6 +18,18 @@ _COMPUTE_DTYPE = torch.bfloat16
 _SEED_STATE = {"base": None, "ctr": 0}
 
 
+# One-shot callbacks run by TransformerEncoderStack right after its layer-drop draws, i.e. at the point of the forward
+# where the host RNG is next needed by the loss (negative sampling); LAST_MASK_INFO = (B, Tm) of the latest time mask.
+POST_RNG_HOOKS = []
+LAST_MASK_INFO = None
+
+
+def run_post_rng_hooks():
+    hooks, POST_RNG_HOOKS[:] = list(POST_RNG_HOOKS), []
+    for h in hooks:
+        h()
+
+
 def set_compute_dtype(dtype):
     """torch.bfloat16 (throughput mode: bf16 activations, f32 accumulate/statistics) or
     torch.float32 (parity mode: exact-f32 MFMA everywhere)."""

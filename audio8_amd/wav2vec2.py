@@ -10,6 +10,7 @@ Deliberate, documented differences from the reference implementation (not from i
 """
 import contextlib
 import math
+import os
 from collections import namedtuple
 from typing import Dict, Optional, Tuple
 
@@ -32,6 +33,8 @@ XE_WGT = 0.1
 DIVERSITY_WGT = 10
 
 CheckpointMapping = namedtuple('CheckpointMapping', ['nested', 'flat'])
+# optional: sample the negatives right after the encoder layer-drop draws (same RNG order, earlier on the host)
+EARLY_NEGATIVES = os.environ.get("A8_EARLY_NEG", "0") == "1"      # measured 1 ms slower: off by default
 
 
 def _nested_map(src_prefix: str, dst_prefix: str) -> Dict[str, str]:
@@ -182,13 +185,36 @@ class Wav2Vec2Loss(nn.Module):
         self.sample = Sampler(n_negatives)
         self.last_logits = None
 
+    def _prefetch_negatives(self):
+        """Runs (via ops.POST_RNG_HOOKS) right after the encoder's layer-drop draws.  The negatives are the next consumer
+        of the global numpy RNG, so sampling them here keeps the reference's draw order; at this point of the forward the
+        GPU still has the whole conv stack queued, so the ~2 ms of host sampling no longer leaves it idle (sampling after
+        the forward, as the reference does, hits an already drained queue)."""
+        info = ops.LAST_MASK_INFO
+        if info is None:
+            return
+        B, Tm = info
+        idx = self.sample.indices(B, Tm).reshape(B * Tm, self.sample.n_negatives)       # row (b,t): its N negatives
+        self._pending = (idx.astype(np.int32), B, Tm)
+
     def __call__(self, model, features):
-        outputs, latents, gs_probs, time_mask = model(features)
+        self._pending = None
+        if EARLY_NEGATIVES:
+            ops.POST_RNG_HOOKS.append(self._prefetch_negatives)
+        try:
+            outputs, latents, gs_probs, time_mask = model(features)
+        finally:
+            if self._prefetch_negatives in ops.POST_RNG_HOOKS:
+                ops.POST_RNG_HOOKS.remove(self._prefetch_negatives)
         B, T, C = outputs.shape
         Tm = latents.shape[1]
         rows = _mask_row_index(time_mask)
         ctx = ops.GatherRowsFn.apply(outputs.reshape(B * T, C), rows)
-        idx = self.sample.indices(B, Tm).reshape(B * Tm, self.sample.n_negatives)       # row (b,t): its N negatives
+        if self._pending is not None and self._pending[1:] == (B, Tm):
+            idx = self._pending[0]
+        else:
+            idx = self.sample.indices(B, Tm).reshape(B * Tm, self.sample.n_negatives)
+        self._pending = None
         neg_idx = ops.host_i32(idx, outputs.device)
         xe_loss, logits = ops.ContrastiveXEFn.apply(ctx, latents.reshape(B * Tm, C), neg_idx)
         self.last_logits = logits
@@ -417,6 +443,7 @@ class Wav2Vec2Model(nn.Module):
         time_mask, tm_u8, rows = _mask_to_device(time_mask_np, x.device)                          # :938
         features = ops.MaskFillRowsFn.apply(features, tm_u8, self.mask_emb)                      # :939
         Tm = rows.numel() // B
+        ops.LAST_MASK_INFO = (B, Tm)
         y = ops.GatherRowsFn.apply(unmasked_d, rows).view(B, Tm, C0)                              # :946
         ctx = self.encoder(features.view(B, T, -1))                                               # :947
         y, vq_probs = self.quantizer(y)                                                           # :948

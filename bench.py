@@ -93,7 +93,8 @@ def main():
         cfg.update(d_model=1024, num_heads=16, num_layers=24, d_ff=4096)
     model = W.create_model(16, **cfg).to(dev).train()
     loss_fn = W.create_loss(640, 100)
-    stepper = Stepper(model, lr=2.0e-4, weight_decay=1.0e-2, clip=1.0, bucket_mb=args.bucket_mb)
+    stepper = Stepper(model, lr=2.0e-4, weight_decay=1.0e-2, clip=1.0, bucket_mb=args.bucket_mb,
+                      wgrad_side_stream=os.environ.get("A8_SIDE_WGRAD", "1") != "0")
     x = synth(args.batch, args.samples, rank).to(dev)
 
     def one_step():
