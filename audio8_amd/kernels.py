@@ -63,7 +63,9 @@ def gemm(layout, A, B, M, N, K, *, out=None, out_dtype=None, lda=None, ldb=None,
         ev0.record()
         L.check(L.lib().a8_gemm(C.byref(d), L.stream()), "a8_gemm")
         ev1.record()
-        GEMM_PROFILE.append((ev0, ev1, 2.0 * M * N * K, layout))
+        esz = A.element_size()
+        alg_bytes = (M * K + N * K) * esz + M * N * out.element_size() * (2 if zout is not None else 1) + (M * N * esz if zin is not None else 0)
+        GEMM_PROFILE.append((ev0, ev1, 2.0 * M * N * K, layout, alg_bytes))
     else:
         L.check(L.lib().a8_gemm(C.byref(d), L.stream()), "a8_gemm")
     return out

@@ -129,16 +129,28 @@ def main():
     # HIP events on the launch stream around every a8_gemm launch
     roofline = None
     if rank == 0:
-        K.GEMM_PROFILE = []
-        one_step()
-        torch.cuda.synchronize()
-        prof, K.GEMM_PROFILE = K.GEMM_PROFILE, None
-        tot_ms = sum(a.elapsed_time(b) for a, b, _, _ in prof)
-        tot_fl = sum(f for _, _, f, _ in prof)
+        def gemm_rate():
+            K.GEMM_PROFILE = []
+            one_step()
+            torch.cuda.synchronize()
+            prof, K.GEMM_PROFILE = K.GEMM_PROFILE, None
+            return prof, sum(a.elapsed_time(b) for a, b, *_ in prof), sum(f for _, _, f, *_ in prof)
+        prof, tot_ms, tot_fl = gemm_rate()                     # as the step runs (weight-gradient GEMMs overlap on a side stream)
+        side, ops.WGRAD_SIDE_STREAM = ops.WGRAD_SIDE_STREAM, None
+        _, ser_ms, ser_fl = gemm_rate()                        # the same launches one after another (kernel's own rate)
+        ops.WGRAD_SIDE_STREAM = side
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
+        if os.path.exists(tpath) and args.dtype == "bf16" and args.model == "base" and args.batch == 8 and args.samples == 250000:
+            tj = json.load(open(tpath))            # HBM bytes per launch from separate rocprofv3 --pmc passes of this same command
+            traffic, traffic_src = round(tj["hbm_bytes_per_launch"]), "profiles/r01_gemm_traffic.json (" + tj["method"] + ")"
         roofline = {"bound": "mfma", "kernel": "gemm_kernel<%s> (a8_gemm: all Linear/conv-as-GEMM fwd, dgrad, wgrad)" % args.dtype,
-                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                    "achieved_serial": round(ser_fl / (ser_ms * 1e-3) / 1e12, 2), "frac_serial": round(ser_fl / (ser_ms * 1e-3) / 1e12 / peak, 4),
+                    "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": round(sum(b for *_, b in prof) / max(1, len(prof))),
                     "launches_per_step": len(prof), "avg_launch_us": round(tot_ms * 1e3 / max(1, len(prof)), 2),
                     "gemm_ms_per_step": round(tot_ms, 3), "algorithmic_gflop_per_step": round(tot_fl / 1e9, 1)}
     cpu = None
