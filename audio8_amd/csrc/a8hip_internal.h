@@ -1,3 +1,6 @@
 // internal: pulls in the public C ABI next to the device helpers
 #pragma once
 #include "../../include/a8hip.h"
+
+// a8_set_tuning table (runtime.hip): [0] GEMM variant, [1] ln_bwd geometry NW*100 + rows per wave
+extern int g_a8_tuning[8];

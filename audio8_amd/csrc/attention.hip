@@ -11,7 +11,14 @@
 //    with ds_read_b64_tr_b16 (bf16) / ds_read_b32 (f32).  P and dS never touch LDS.
 //  * Softmax statistics are lane-local per query (query = lane&15) + two xor-shuffles over the 4 key groups.
 //  * One LDS image per 64x64 tile serves both the row reads (b128, XOR-swizzled) and the transposed reads.
-//  * Dropout regenerates its keep-mask from a counter hash of (b,h,query,key) in all three kernels.
+//  * Dropout regenerates its keep-mask from a counter hash of (b,h,query,key) in all three kernels: one 32-bit
+//    word per PAIR of adjacent keys, h = fin((pair_index + seed) * C1), a 16-bit field per key.  The pair index
+//    is affine in the tile / fragment coordinates, so the product is carried as a running sum (one add per word).
+//  * The softmax inner loops are VALU-bound at head dim 64, so they are written for instruction count: scores stay
+//    raw, exp2(fma(s, scale, -max)) with the bare v_exp_f32; the running max is only raised when a tile exceeds it
+//    by more than 2^8 (probabilities stay <= 256, exact same result after the final 1/l); the constant factors
+//    1/(1-p) and the softmax scale are applied once to the accumulators; tails need no per-element tests in the
+//    backward kernels because staged rows beyond T are zero.
 //  * Backward is two kernels (dK/dV stationary per key block; dQ stationary per query block): no atomics,
 //    bit-reproducible.  delta = rowsum(dO*O) is a tiny pre-pass.
 #include "a8_common.h"
@@ -139,12 +146,32 @@ struct AttnP {
     int B, T, H;
     long long ld_qkv, ld_o, ld_d;
     float scale, pscale, dscale;   // scale = softmax scale * log2(e) (scores and lse live in the log2 domain); dscale = softmax scale
-    uint32_t thr, seed;       // thr: 16-bit keep threshold (0 = dropout off)
-    int Th;                   // key pairs per query row = ceil(T / 2)
+    float lazy;                    // raise the running max only past this margin (log2 units)
+    uint32_t thr, seed;            // thr: 16-bit keep threshold (0 = dropout off)
+    int Th;                        // key pairs per query row = ceil(T / 2)
 };
 
+constexpr uint32_t HC1 = 0x9E3779B1u, HC2 = 0x2C1B3C6Du;
+constexpr float MASKED_LOG2 = -1.4426950408889634e9f;      // masked_fill(-1e9) in the log2 domain
+// dropout word of key pair `idx`: fin((idx + seed) * HC1); callers carry the product as a running sum
+A8_DEV uint32_t hfin(uint32_t h) { h ^= h >> 15; return h * HC2; }
 A8_DEV uint32_t pair_base(int bh, int T, int Th, int q) { return ((uint32_t)bh * (uint32_t)T + (uint32_t)q) * (uint32_t)Th; }
-A8_DEV bool keep16(uint32_t h, int key, uint32_t thr) { return ((key & 1) ? (h >> 16) : (h & 0xFFFFu)) >= thr; }
+A8_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// 1-D grid -> (tile block, batch*head).  Workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so
+// when B*H divides by 8 every block of one (batch, head) is placed on the same XCD and its K/V (or Q/dO) panel
+// is fetched from HBM/MALL once per XCD instead of once per block.
+A8_DEV void block_coords(int nblk, int nbh, int& blk, int& bh) {
+    const int L = blockIdx.x;
+    if (nbh % 8 == 0) {
+        const int xcd = L & 7, slot = L >> 3;
+        bh = xcd + 8 * (slot / nblk);
+        blk = slot % nblk;
+    } else {
+        bh = L / nblk;
+        blk = L % nblk;
+    }
+}
 
 template <typename T> A8_DEV void store4(T* p, float a, float b, float c, float d);
 template <> A8_DEV void store4<bf16>(bf16* p, float a, float b, float c, float d) {
@@ -159,8 +186,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP P) {
     char* kt = lds;
     char* vt = lds + ATile<T>::BYTES;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
-    const int bh = blockIdx.y, b = bh / P.H, h = bh % P.H;
-    const int q0 = blockIdx.x * BT + wv * 16, qi = q0 + li;
+    int blk, bh;
+    block_coords((P.T + BT - 1) / BT, P.B * P.H, blk, bh);
+    const int b = bh / P.H, h = bh % P.H;
+    const int q0 = blk * BT + wv * 16, qi = q0 + li;
     const T* qb = reinterpret_cast<const T*>(P.q) + (long long)b * P.T * P.ld_qkv + h * DH;
     const T* kb = reinterpret_cast<const T*>(P.k) + (long long)b * P.T * P.ld_qkv + h * DH;
     const T* vb = reinterpret_cast<const T*>(P.v) + (long long)b * P.T * P.ld_qkv + h * DH;
@@ -171,8 +200,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP P) {
     f32x4 oacc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) oacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m = -INFINITY, l = 0.f;
+    float m = -INFINITY, l = 0.f;                     // m: the max the probabilities are referred to (log2 domain)
     const int ntiles = (P.T + BT - 1) / BT;
+    uint32_t hb = (pair_base(bh, P.T, P.Th, qi) + (uint32_t)(2 * g) + P.seed) * HC1;    // dropout word base of this tile
     AStage<T> sk, sv;
     sk.load(kb, P.ld_qkv, 0, P.T);
     sv.load(vb, P.ld_qkv, 0, P.T);
@@ -186,54 +216,66 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP P) {
             sv.load(vb, P.ld_qkv, (kt_i + 1) * BT, P.T);
         }
         f32x4 s[4];
-        tile_times_rows<T>(kt, qf, s, lane);          // s[i][r] = S^T[key 16i+4g+r][query li]
-        const int key0 = kt_i * BT + 4 * g;
+        tile_times_rows<T>(kt, qf, s, lane);          // s[i][r] = raw S^T[key 16i+4g+r][query li]
         const bool edge = km != nullptr || (kt_i + 1) * BT > P.T;      // wave-uniform: masks / tail only here
-        float mt = -INFINITY;
+        float mt;
         if (!edge) {
+            mt = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                s[i] *= P.scale;
-                mt = fmaxf(mt, fmaxf(fmaxf(s[i][0], s[i][1]), fmaxf(s[i][2], s[i][3])));
-            }
+            for (int i = 1; i < 4; ++i) mt = fmaxf(fmaxf(mt, s[i][0]), fmaxf(fmaxf(s[i][1], s[i][2]), s[i][3]));
+            mt *= P.scale;
         } else {
+            const int key0 = kt_i * BT + 4 * g;
+            mt = -INFINITY;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = key0 + 16 * i + r;
                     float x = s[i][r] * P.scale;
-                    if (km && key < P.T && !km[key]) x = -1.4426950408889634e9f;     // masked_fill(-1e9), log2 domain
+                    if (km && key < P.T && !km[key]) x = MASKED_LOG2;
                     if (key >= P.T) x = -INFINITY;
-                    s[i][r] = x;
+                    s[i][r] = x;                     // already scaled on this path
                     mt = fmaxf(mt, x);
                 }
         }
         mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        const float mn = fmaxf(m, mt);
-        const float alpha = exp2f(m - mn);             // first tile: exp2(-inf) = 0
-        m = mn;
+        if (__any(mt > m + P.lazy)) {                 // first tile: m = -inf -> always taken, alpha = 0
+            const float mn = fmaxf(m, mt);
+            const float alpha = fast_exp2(m - mn);
+            m = mn;
+            l *= alpha;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) oacc[db] *= alpha;
+        }
         float ls = 0.f;
+        if (!edge) {
+            const float nb = -m;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { s[i][r] = exp2f(s[i][r] - mn); ls += s[i][r]; }
+                for (int r = 0; r < 4; ++r) { s[i][r] = fast_exp2(__builtin_fmaf(s[i][r], P.scale, nb)); ls += s[i][r]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s[i][r] = fast_exp2(s[i][r] - m); ls += s[i][r]; }
+        }
+        l += ls;
         if (P.thr) {
-            const uint32_t pb = pair_base(bh, P.T, P.Th, qi) + (uint32_t)(key0 >> 1);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const uint32_t h0 = a8_mix(P.seed, pb + 8 * i), h1 = a8_mix(P.seed, pb + 8 * i + 1);
-                s[i][0] = (h0 & 0xFFFFu) >= P.thr ? s[i][0] * P.pscale : 0.f;
-                s[i][1] = (h0 >> 16) >= P.thr ? s[i][1] * P.pscale : 0.f;
-                s[i][2] = (h1 & 0xFFFFu) >= P.thr ? s[i][2] * P.pscale : 0.f;
-                s[i][3] = (h1 >> 16) >= P.thr ? s[i][3] * P.pscale : 0.f;
+                const uint32_t h0 = hfin(hb + (uint32_t)(8 * i) * HC1), h1 = hfin(hb + (uint32_t)(8 * i + 1) * HC1);
+                s[i][0] = (h0 & 0xFFFFu) >= P.thr ? s[i][0] : 0.f;
+                s[i][1] = (h0 >> 16) >= P.thr ? s[i][1] : 0.f;
+                s[i][2] = (h1 & 0xFFFFu) >= P.thr ? s[i][2] : 0.f;
+                s[i][3] = (h1 >> 16) >= P.thr ? s[i][3] : 0.f;
             }
+            hb += (uint32_t)(BT / 2) * HC1;
         }
-        l = l * alpha + ls;
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
-            oacc[db] *= alpha;
             oacc[db] = ATile<T>::mma_xt_p(vt, 0, 16 * db, s[0], s[1], oacc[db], lane);
             oacc[db] = ATile<T>::mma_xt_p(vt, 32, 16 * db, s[2], s[3], oacc[db], lane);
         }
@@ -241,7 +283,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP P) {
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     if (qi < P.T) {
-        const float inv = 1.0f / l;
+        const float inv = P.pscale / l;               // 1/(1-p) of the dropout is applied here, once
         T* op = reinterpret_cast<T*>(P.out) + ((long long)b * P.T + qi) * P.ld_o + h * DH + 4 * g;
 #pragma unroll
         for (int db = 0; db < 4; ++db) store4<T>(op + 16 * db, oacc[db][0] * inv, oacc[db][1] * inv, oacc[db][2] * inv, oacc[db][3] * inv);
@@ -279,12 +321,14 @@ __global__ void attn_delta_kernel(const AttnP P) {
 template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnP P) {
     __shared__ __attribute__((aligned(16))) char lds[2 * ATile<T>::BYTES];
-    __shared__ float s_lse[BT], s_delta[BT];
+    __shared__ __attribute__((aligned(16))) float s_lse[BT], s_delta[BT];
     char* qt = lds;
     char* dot = lds + ATile<T>::BYTES;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
-    const int bh = blockIdx.y, b = bh / P.H, h = bh % P.H;
-    const int key = blockIdx.x * BT + wv * 16 + li;
+    int blk, bh;
+    block_coords((P.T + BT - 1) / BT, P.B * P.H, blk, bh);
+    const int b = bh / P.H, h = bh % P.H;
+    const int key = blk * BT + wv * 16 + li;
     const T* qb = reinterpret_cast<const T*>(P.q) + (long long)b * P.T * P.ld_qkv + h * DH;
     const T* kb = reinterpret_cast<const T*>(P.k) + (long long)b * P.T * P.ld_qkv + h * DH;
     const T* vb = reinterpret_cast<const T*>(P.v) + (long long)b * P.T * P.ld_qkv + h * DH;
@@ -299,6 +343,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnP P) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) { dk[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     const int ntiles = (P.T + BT - 1) / BT;
+    // dropout word of (query qq, this lane's key): fin(hk + (qq - tile base - 4g) * ThC); field (key & 1)
+    const uint32_t ThC = (uint32_t)P.Th * HC1;
+    uint32_t hk = (pair_base(bh, P.T, P.Th, 4 * g) + (uint32_t)(key >> 1) + P.seed) * HC1;
+    const uint32_t fsh = (key & 1) << 4;
     AStage<T> sq, sd;
     sq.load(qb, P.ld_qkv, 0, P.T);
     sd.load(dob, P.ld_o, 0, P.T);
@@ -306,7 +354,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnP P) {
         __syncthreads();
         sq.store(qt);
         sd.store(dot);
-        if (threadIdx.x < BT) {
+        if (threadIdx.x < BT) {                        // rows beyond T: Q = dO = 0 (staged zero), lse = delta = 0 -> dS = 0, P^T dO = 0
             const int qq = qt_i * BT + threadIdx.x;
             s_lse[threadIdx.x] = qq < P.T ? P.lse[(long long)bh * P.T + qq] : 0.f;
             s_delta[threadIdx.x] = qq < P.T ? P.delta[(long long)bh * P.T + qq] : 0.f;
@@ -317,28 +365,29 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnP P) {
             sd.load(dob, P.ld_o, (qt_i + 1) * BT, P.T);
         }
         f32x4 s[4], dp[4];
-        rows_times_tile<T>(qt, kf, s, lane);           // s[i][r]  = S[q 16i+4g+r][key li]
+        rows_times_tile<T>(qt, kf, s, lane);           // s[i][r]  = raw S[q 16i+4g+r][key li]
         rows_times_tile<T>(dot, vf, dp, lane);         // dp[i][r] = (dO V^T)[q][key]
-        const bool qedge = (qt_i + 1) * BT > P.T;                       // wave-uniform
-        const int keyh = key >> 1;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 lse4 = *reinterpret_cast<const f32x4*>(&s_lse[16 * i + 4 * g]);
+            const f32x4 del4 = *reinterpret_cast<const f32x4*>(&s_delta[16 * i + 4 * g]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int ql = 16 * i + 4 * g + r, qq = qt_i * BT + ql;
-                float x = s[i][r] * P.scale;
-                if (key_masked) x = -1.4426950408889634e9f;
-                float p = exp2f(x - s_lse[ql]);
-                if (!key_ok || (qedge && qq >= P.T)) p = 0.f;
+                float x = __builtin_fmaf(s[i][r], P.scale, -lse4[r]);
+                if (P.keymask && key_masked) x = MASKED_LOG2 - lse4[r];
+                const float p = fast_exp2(x);          // keys beyond T: harmless garbage in rows that are never stored
                 float pd = p, dpv = dp[i][r];
                 if (P.thr) {
-                    const bool keep = keep16(a8_mix(P.seed, pair_base(bh, P.T, P.Th, qq) + keyh), key, P.thr);
-                    pd = keep ? p * P.pscale : 0.f;
-                    dpv = keep ? dpv * P.pscale : 0.f;
+                    const uint32_t hh = hfin(hk + (uint32_t)(16 * i + r) * ThC);
+                    const bool keep = ((hh >> fsh) & 0xFFFFu) >= P.thr;
+                    pd = keep ? p : 0.f;
+                    dpv = keep ? dpv : 0.f;
                 }
-                s[i][r] = pd;                                        // P (dropped) for dV
-                dp[i][r] = p * (dpv - s_delta[ql]) * P.dscale;       // dS for dK
+                s[i][r] = pd;                                                     // P (dropped, unscaled) for dV
+                dp[i][r] = p * __builtin_fmaf(dpv, P.pscale, -del4[r]);          // dS / softmax scale for dK
             }
+        }
+        hk += (uint32_t)BT * ThC;
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
             dv[db] = ATile<T>::mma_xt_p(dot, 0, 16 * db, s[0], s[1], dv[db], lane);
@@ -352,8 +401,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnP P) {
         T* dvp = reinterpret_cast<T*>(P.dv) + ((long long)b * P.T + key) * P.ld_d + h * DH + 4 * g;
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
-            store4<T>(dkp + 16 * db, dk[db][0], dk[db][1], dk[db][2], dk[db][3]);
-            store4<T>(dvp + 16 * db, dv[db][0], dv[db][1], dv[db][2], dv[db][3]);
+            store4<T>(dkp + 16 * db, dk[db][0] * P.dscale, dk[db][1] * P.dscale, dk[db][2] * P.dscale, dk[db][3] * P.dscale);
+            store4<T>(dvp + 16 * db, dv[db][0] * P.pscale, dv[db][1] * P.pscale, dv[db][2] * P.pscale, dv[db][3] * P.pscale);
         }
     }
 }
@@ -365,8 +414,10 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnP P) {
     char* kt = lds;
     char* vt = lds + ATile<T>::BYTES;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
-    const int bh = blockIdx.y, b = bh / P.H, h = bh % P.H;
-    const int qi = blockIdx.x * BT + wv * 16 + li;
+    int blk, bh;
+    block_coords((P.T + BT - 1) / BT, P.B * P.H, blk, bh);
+    const int b = bh / P.H, h = bh % P.H;
+    const int qi = blk * BT + wv * 16 + li;
     const bool q_ok = qi < P.T;
     const T* qb = reinterpret_cast<const T*>(P.q) + (long long)b * P.T * P.ld_qkv + h * DH;
     const T* kb = reinterpret_cast<const T*>(P.k) + (long long)b * P.T * P.ld_qkv + h * DH;
@@ -383,6 +434,8 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnP P) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) dq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int ntiles = (P.T + BT - 1) / BT;
+    uint32_t hb = (pair_base(bh, P.T, P.Th, qi) + (uint32_t)(2 * g) + P.seed) * HC1;
+    const float nlse = -lse, ndelta = -delta;
     AStage<T> sk, sv;
     sk.load(kb, P.ld_qkv, 0, P.T);
     sv.load(vb, P.ld_qkv, 0, P.T);
@@ -396,30 +449,30 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnP P) {
             sv.load(vb, P.ld_qkv, (kt_i + 1) * BT, P.T);
         }
         f32x4 s[4], dp[4];
-        tile_times_rows<T>(kt, qf, s, lane);           // S^T[key][q]
+        tile_times_rows<T>(kt, qf, s, lane);           // raw S^T[key][q]
         tile_times_rows<T>(vt, dof, dp, lane);         // (V dO^T)[key][q]
-        const int key0 = kt_i * BT + 4 * g;
-        const bool edge = km != nullptr || (kt_i + 1) * BT > P.T;      // wave-uniform
-        const uint32_t pb = pair_base(bh, P.T, P.Th, qi) + (uint32_t)(key0 >> 1);
+        // keys beyond T: staged K = V = 0, so dS is finite garbage that multiplies zero K rows -- no tail test needed
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             uint32_t h0 = 0, h1 = 0;
-            if (P.thr) { h0 = a8_mix(P.seed, pb + 8 * i); h1 = a8_mix(P.seed, pb + 8 * i + 1); }
+            if (P.thr) { h0 = hfin(hb + (uint32_t)(8 * i) * HC1); h1 = hfin(hb + (uint32_t)(8 * i + 1) * HC1); }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int key = key0 + 16 * i + r;
-                float x = s[i][r] * P.scale;
-                if (edge && km && key < P.T && !km[key]) x = -1.4426950408889634e9f;
-                float p = exp2f(x - lse);
-                if ((edge && key >= P.T) || !q_ok) p = 0.f;
+                float x = __builtin_fmaf(s[i][r], P.scale, nlse);
+                if (km) {                                                  // wave-uniform
+                    const int key = kt_i * BT + 4 * g + 16 * i + r;
+                    if (key < P.T && !km[key]) x = MASKED_LOG2 + nlse;
+                }
+                const float p = fast_exp2(x);
                 float dpv = dp[i][r];
                 if (P.thr) {
                     const uint32_t hh = (r < 2) ? h0 : h1;
-                    dpv = (((r & 1) ? (hh >> 16) : (hh & 0xFFFFu)) >= P.thr) ? dpv * P.pscale : 0.f;
+                    dpv = (((r & 1) ? (hh >> 16) : (hh & 0xFFFFu)) >= P.thr) ? dpv : 0.f;
                 }
-                s[i][r] = p * (dpv - delta) * P.dscale;   // dS^T[key][q]
+                s[i][r] = p * __builtin_fmaf(dpv, P.pscale, ndelta);      // dS^T[key][q] / softmax scale
             }
         }
+        hb += (uint32_t)(BT / 2) * HC1;
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
             dq[db] = ATile<T>::mma_xt_p(kt, 0, 16 * db, s[0], s[1], dq[db], lane);
@@ -429,13 +482,14 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnP P) {
     if (q_ok) {
         T* dqp = reinterpret_cast<T*>(P.dq) + ((long long)b * P.T + qi) * P.ld_d + h * DH + 4 * g;
 #pragma unroll
-        for (int db = 0; db < 4; ++db) store4<T>(dqp + 16 * db, dq[db][0], dq[db][1], dq[db][2], dq[db][3]);
+        for (int db = 0; db < 4; ++db) store4<T>(dqp + 16 * db, dq[db][0] * P.dscale, dq[db][1] * P.dscale, dq[db][2] * P.dscale, dq[db][3] * P.dscale);
     }
 }
 
 void set_softmax_params(AttnP& P, float scale, float p, uint32_t seed) {
     P.scale = scale * 1.4426950408889634f;
     P.dscale = scale;
+    P.lazy = 8.0f;
     P.Th = (P.T + 1) / 2;
     uint32_t thr = p > 0.f ? (uint32_t)(p * 65536.0f + 0.5f) : 0u;
     if (p > 0.f && thr == 0) thr = 1;
@@ -463,7 +517,7 @@ extern "C" int a8_attn_fwd(int dtype, const void* q, const void* k, const void* 
     P.q = (const char*)q; P.k = (const char*)k; P.v = (const char*)v; P.out = (char*)o; P.lse = lse; P.keymask = keymask;
     P.B = B; P.T = T_; P.H = H; P.ld_qkv = ld_qkv; P.ld_o = ld_o;
     set_softmax_params(P, scale, p, seed);
-    const dim3 grid(cdiv(T_, BT), B * H);
+    const dim3 grid(cdiv(T_, BT) * B * H);
     if (dtype == A8_BF16) hipLaunchKernelGGL(attn_fwd_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, P);
     else hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, P);
     return a8_check_launch("a8_attn_fwd");
@@ -481,7 +535,7 @@ extern "C" int a8_attn_bwd(int dtype, const void* q, const void* k, const void* 
     set_softmax_params(P, scale, p, seed);
     hipStream_t s = (hipStream_t)stream;
     const long long nrow = (long long)B * T_ * H;
-    const dim3 grid(cdiv(T_, BT), B * H);
+    const dim3 grid(cdiv(T_, BT) * B * H);
     if (dtype == A8_BF16) {
         hipLaunchKernelGGL(attn_delta_kernel<bf16>, dim3(cdiv(nrow * 8, 256)), dim3(256), 0, s, P);
         hipLaunchKernelGGL(attn_bwd_kv_kernel<bf16>, grid, dim3(256), 0, s, P);

@@ -340,7 +340,8 @@ __global__ __launch_bounds__(128 * NWM, (NST * 2 * 8192 * KB <= 65536) ? NWM : N
     }
 }
 
-int g_variant = 5;      // tuning knob (a8_set_tuning key 0): 5 = 128 B of K per row, 2-deep ring, 8 waves (default: measured best);
+#define g_variant g_a8_tuning[0]
+                        // tuning knob (a8_set_tuning key 0): 5 = 128 B of K per row, 2-deep ring, 8 waves (default: measured best);
                         // 2 = same with 4 waves; 1 = 64 B rows, 4-deep ring, 4 waves
 
 template <typename T, int KB, int NST, int NWM> int launch2(const a8_gemm_desc* d, const GemmArgs& g, int grid, hipStream_t s) {
@@ -367,11 +368,6 @@ template <typename T> int launch(const a8_gemm_desc* d, const GemmArgs& g, int g
 }
 
 }  // namespace
-
-extern "C" int a8_set_tuning(int key, int value) {
-    if (key == 0) { g_variant = value; return A8_OK; }
-    return a8_set_error(A8_ERR_ARG, "a8_set_tuning: unknown key %d", key);
-}
 
 extern "C" int a8_gemm(const a8_gemm_desc* d, void* stream) {
     A8_REQUIRE(d != nullptr, "a8_gemm: null descriptor");

@@ -98,31 +98,54 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     }
 }
 
-// Column sums held per wave in registers -> LDS [4][cols] (one slab per wave, no serial phases) -> one atomic
-// per column per block.  acc[c][i] belongs to column (lane + 64c)*8 + i.  lds: float[4 * cols].
+// Column sums held per wave in registers -> LDS [NS][cols] (one slab per wave; with more than NS waves the upper
+// waves add into the lower waves' slabs in a second pass) -> one atomic per column per block.
+// acc[c][i] belongs to column (lane + 64c)*8 + i.  lds: float[NS * cols], NS = min(NW, 8).
+template <int NW>
 A8_DEV void flush_colsum(float (&acc)[MAXC][8], float* lds, float* __restrict__ out, int cols) {
+    constexpr int NS = NW < 8 ? NW : 8;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nch = cols >> 3;
     __syncthreads();
+    if (w < NS) {
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c)
-        if (lane + 64 * c < nch) {
-            float* p = lds + w * cols + (lane + 64 * c) * 8;
-            *reinterpret_cast<f32x4*>(p) = (f32x4){acc[c][0], acc[c][1], acc[c][2], acc[c][3]};
-            *reinterpret_cast<f32x4*>(p + 4) = (f32x4){acc[c][4], acc[c][5], acc[c][6], acc[c][7]};
-        }
+        for (int c = 0; c < MAXC; ++c)
+            if (lane + 64 * c < nch) {
+                float* p = lds + w * cols + (lane + 64 * c) * 8;
+                *reinterpret_cast<f32x4*>(p) = (f32x4){acc[c][0], acc[c][1], acc[c][2], acc[c][3]};
+                *reinterpret_cast<f32x4*>(p + 4) = (f32x4){acc[c][4], acc[c][5], acc[c][6], acc[c][7]};
+            }
+    }
     __syncthreads();
-    for (int i = threadIdx.x; i < cols; i += 256) atomicAdd(out + i, lds[i] + lds[cols + i] + lds[2 * cols + i] + lds[3 * cols + i]);
+    if constexpr (NW > NS) {
+        if (w >= NS) {
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c)
+                if (lane + 64 * c < nch) {
+                    float* p = lds + (w - NS) * cols + (lane + 64 * c) * 8;
+                    const f32x4 a = *reinterpret_cast<f32x4*>(p), b = *reinterpret_cast<f32x4*>(p + 4);
+                    *reinterpret_cast<f32x4*>(p) = (f32x4){a[0] + acc[c][0], a[1] + acc[c][1], a[2] + acc[c][2], a[3] + acc[c][3]};
+                    *reinterpret_cast<f32x4*>(p + 4) = (f32x4){b[0] + acc[c][4], b[1] + acc[c][5], b[2] + acc[c][6], b[3] + acc[c][7]};
+                }
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < cols; i += NW * 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) t += lds[k * cols + i];
+        atomicAdd(out + i, t);
+    }
 }
 
 // ------------------------------------------------------------------ LayerNorm backward
-template <typename T>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ dy2,
+template <typename T, int NW>
+__global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ dy2,
                                                      const T* __restrict__ x, const T* __restrict__ res,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, T* __restrict__ dx, T* __restrict__ dres,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                      int rows, int cols, Drop dr) {
-    __shared__ __attribute__((aligned(16))) float lds[4 * MAXC * 512];
+    __shared__ __attribute__((aligned(16))) float lds[(NW < 8 ? NW : 8) * MAXC * 512];
     const int lane = threadIdx.x & 63, nch = cols >> 3;
     const float inv = 1.0f / (float)cols;
     float ag[MAXC][8], ab[MAXC][8];
@@ -130,7 +153,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     for (int c = 0; c < MAXC; ++c)
 #pragma unroll
         for (int i = 0; i < 8; ++i) { ag[c][i] = 0.f; ab[c][i] = 0.f; }
-    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+    for (int row = blockIdx.x * NW + (threadIdx.x >> 6); row < rows; row += gridDim.x * NW) {
         const float mu = mean[row], rs = rstd[row];
         float xh[MAXC][8], g[MAXC][8];
         float s1 = 0.f, s2 = 0.f;
@@ -190,8 +213,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
             }
         }
     }
-    flush_colsum(ag, lds, dgamma, cols);
-    flush_colsum(ab, lds, dbeta, cols);
+    if (!dgamma) return;
+    flush_colsum<NW>(ag, lds, dgamma, cols);
+    flush_colsum<NW>(ab, lds, dbeta, cols);
 }
 
 // ------------------------------------------------------------------ dz = dy * gelu'(z); dbias += colsum(dz)
@@ -268,7 +292,7 @@ __global__ __launch_bounds__(256) void mask_fill_rows_bwd_kernel(T* __restrict__
             }
         }
     }
-    flush_colsum(ab, lds, demb, cols);
+    flush_colsum<4>(ab, lds, demb, cols);
 }
 
 template <typename T>
@@ -462,9 +486,16 @@ extern "C" int a8_layernorm_bwd(int dtype, const void* dy, const void* dy2, cons
     A8_REQUIRE(cols % 8 == 0 && cols <= MAXC * 512, "a8_layernorm_bwd: cols=%d must be a multiple of 8 and <= %d", cols, MAXC * 512);
     if (rows == 0) return A8_OK;
     const Drop dr = make_drop(p, seed, rng_stream);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(ln_bwd_kernel<T>, dim3(grid_for(rows, 12)), dim3(256), 0, (hipStream_t)stream,
-                                         (const T*)dy, (const T*)dy2, (const T*)x, (const T*)res, gamma, mean, rstd, (T*)dx, (T*)dres,
-                                         dgamma, dbeta, rows, cols, dr));
+    // rows per wave R and waves per block NW (a8_set_tuning key 1 = NW*100 + R): fewer, fatter blocks mean fewer
+    // same-address atomics on dgamma/dbeta
+    const int nw = g_a8_tuning[1] / 100, rpw = g_a8_tuning[1] % 100;
+    const int grid = cdiv(rows, nw * rpw);
+#define LN_BWD(NW) DISPATCH_T(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T, NW>), dim3(grid), dim3(NW * 64), 0, (hipStream_t)stream, \
+                                         (const T*)dy, (const T*)dy2, (const T*)x, (const T*)res, gamma, mean, rstd, (T*)dx, (T*)dres, \
+                                         dgamma, dbeta, rows, cols, dr))
+    if (nw == 4) LN_BWD(4); else if (nw == 8) LN_BWD(8); else if (nw == 16) LN_BWD(16);
+    else return a8_set_error(A8_ERR_ARG, "a8_layernorm_bwd: bad tuning %d", g_a8_tuning[1]);
+#undef LN_BWD
     return a8_check_launch("a8_layernorm_bwd");
 }
 

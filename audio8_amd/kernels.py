@@ -65,7 +65,7 @@ def gemm(layout, A, B, M, N, K, *, out=None, out_dtype=None, lda=None, ldb=None,
         ev1.record()
         esz = A.element_size()
         alg_bytes = (M * K + N * K) * esz + M * N * out.element_size() * (2 if zout is not None else 1) + (M * N * esz if zin is not None else 0)
-        GEMM_PROFILE.append((ev0, ev1, 2.0 * M * N * K, layout, alg_bytes))
+        GEMM_PROFILE.append((ev0, ev1, 2.0 * M * N * K, layout, alg_bytes, (M, N, K, splitk)))
     else:
         L.check(L.lib().a8_gemm(C.byref(d), L.stream()), "a8_gemm")
     return out

@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--model", default="base", choices=["base", "large"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm-table", action="store_true", help="print the per-shape table of the serialised instrumented step to stderr")
     ap.add_argument("--cpu-batch", type=int, default=1)
     ap.add_argument("--cpu-steps", type=int, default=1)
     ap.add_argument("--cpu-threads", type=int, default=16)
@@ -134,10 +135,19 @@ def main():
             one_step()
             torch.cuda.synchronize()
             prof, K.GEMM_PROFILE = K.GEMM_PROFILE, None
-            return prof, sum(a.elapsed_time(b) for a, b, *_ in prof), sum(f for _, _, f, *_ in prof)
+            return prof, sum(p[0].elapsed_time(p[1]) for p in prof), sum(p[2] for p in prof)
         prof, tot_ms, tot_fl = gemm_rate()                     # as the step runs (weight-gradient GEMMs overlap on a side stream)
         side, ops.WGRAD_SIDE_STREAM = ops.WGRAD_SIDE_STREAM, None
-        _, ser_ms, ser_fl = gemm_rate()                        # the same launches one after another (kernel's own rate)
+        sprof, ser_ms, ser_fl = gemm_rate()                    # the same launches one after another (kernel's own rate)
+        if args.gemm_table:
+            tab = {}
+            for e0, e1, fl, lay, _, shp in sprof:
+                t = tab.setdefault((lay,) + shp, [0, 0.0, fl])
+                t[0] += 1
+                t[1] += e0.elapsed_time(e1)
+            for k, (n, ms, fl) in sorted(tab.items(), key=lambda kv: -kv[1][1]):
+                print("gemm %s M=%d N=%d K=%d splitk=%d  n=%3d  avg %7.1f us  total %6.3f ms  %6.1f TFLOP/s"
+                      % (("NT", "NN", "TN")[k[0]], k[1], k[2], k[3], k[4], n, ms / n * 1e3, ms, fl * n / ms / 1e9), file=sys.stderr)
         ops.WGRAD_SIDE_STREAM = side
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
@@ -150,7 +160,7 @@ def main():
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                     "achieved_serial": round(ser_fl / (ser_ms * 1e-3) / 1e12, 2), "frac_serial": round(ser_fl / (ser_ms * 1e-3) / 1e12 / peak, 4),
                     "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": traffic_src,
-                    "algorithmic_bytes_per_launch": round(sum(b for *_, b in prof) / max(1, len(prof))),
+                    "algorithmic_bytes_per_launch": round(sum(p[4] for p in prof) / max(1, len(prof))),
                     "launches_per_step": len(prof), "avg_launch_us": round(tot_ms * 1e3 / max(1, len(prof)), 2),
                     "gemm_ms_per_step": round(tot_ms, 3), "algorithmic_gflop_per_step": round(tot_fl / 1e9, 1)}
     cpu = None

@@ -283,6 +283,81 @@ def test_attention_dropout_mask_consistency():
     close(dv.reshape(B, T, H, 64), v.grad.permute(0, 2, 1, 3), 1e-4)
 
 
+def _extract_keep(K, B, H, T, p, seed, dtype):
+    """The kernel's keep-mask [B,H,q,key]: q = k = 0 -> uniform P; V one-hot over 64-key slabs."""
+    d = H * 64
+    dev = "cuda"
+    z = torch.zeros((B * T, d), device=dev, dtype=dtype)
+    keep = torch.zeros(B, H, T, T)
+    for k0 in range(0, T, 64):
+        v = torch.zeros(B, T, H, 64, device=dev)
+        n = min(64, T - k0)
+        v[:, k0:k0 + n] = torch.eye(64, device=dev)[:n, None, :]
+        o, _ = K.attn_fwd(z, z, v.reshape(B * T, d).to(dtype), B, T, H, d, 0.125, None, p=p, seed=seed)
+        keep[:, :, :, k0:k0 + n] = (o.view(B, T, H, 64).permute(0, 2, 1, 3)[..., :n] > 0).float().cpu()
+    return keep
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_attention_dropout_multi_tile(dtype):
+    """Several key/query tiles with a tail (T = 200): forward and both backward kernels must regenerate the same
+    keep-mask from the running hash sums."""
+    from audio8_amd import kernels as K
+    B, H, T, p, seed = 2, 2, 200, 0.1, 77
+    d = H * 64
+    dev = "cuda"
+    keep = _extract_keep(K, B, H, T, p, seed, dtype)
+    assert abs(keep.mean().item() - (1 - p)) < 0.01
+    # neighbouring rows / keys must not share a mask
+    assert (keep[:, :, 1:] == keep[:, :, :-1]).float().mean().item() < 0.9
+    assert (keep[..., 1:] == keep[..., :-1]).float().mean().item() < 0.9
+    qkv = rnd((B * T, 3 * d), 5).to(dtype)
+    dout = rnd((B * T, d), 6).to(dtype)
+    f = qkv.float().view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    q, k, v = (f[i].clone().requires_grad_(True) for i in range(3))
+    oref = _attn_ref(q, k, v, None, 0.125, keep, p)
+    oref.backward(dout.float().view(B, T, H, 64).permute(0, 2, 1, 3))
+    g = qkv.to(dev)
+    o, lse = K.attn_fwd(g[:, :d], g[:, d:2 * d], g[:, 2 * d:], B, T, H, 3 * d, 0.125, None, p=p, seed=seed)
+    tol, tolb = (2e-5, 1e-4) if dtype == torch.float32 else (2e-2, 3e-2)
+    close(o.view(B, T, H, 64), oref.permute(0, 2, 1, 3), tol, "attn o (dropout)")
+    dq, dk, dv, _ = K.attn_bwd(g[:, :d], g[:, d:2 * d], g[:, 2 * d:], o, dout.to(dev), lse, B, T, H, 3 * d, 0.125, None, p=p, seed=seed)
+    close(dq.reshape(B, T, H, 64), q.grad.permute(0, 2, 1, 3), tolb, "attn dq (dropout)")
+    close(dk.reshape(B, T, H, 64), k.grad.permute(0, 2, 1, 3), tolb, "attn dk (dropout)")
+    close(dv.reshape(B, T, H, 64), v.grad.permute(0, 2, 1, 3), tolb, "attn dv (dropout)")
+
+
+def test_attention_running_max_rescale():
+    """Scores that grow from key tile to key tile by far more than the lazy-rescale margin (and, for other rows,
+    by less than it): the deferred max update must give the exact softmax."""
+    from audio8_amd import kernels as K
+    B, H, T = 1, 2, 320
+    d = H * 64
+    torch.manual_seed(11)
+    q = torch.randn(B, H, T, 64)
+    k = torch.randn(B, H, T, 64) * 0.3
+    ramp = torch.linspace(0.0, 6.0, T)                       # key t has a component along u growing with t
+    u = torch.nn.functional.normalize(torch.randn(64), dim=0)
+    k = k + ramp[None, None, :, None] * u
+    q[:, :, ::2] += 40.0 * u                                  # even queries: scores climb ~ 0.125*40*6 = 30 nats across tiles
+    q[:, :, 1::2] += 4.0 * u                                  # odd queries: ~3 nats, inside the margin
+    v = torch.randn(B, H, T, 64)
+    qkv = torch.stack([q, k, v], 0).permute(1, 3, 0, 2, 4).reshape(B * T, 3 * d)   # [B,T,3,H,64]
+    dout = rnd((B * T, d), 8)
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    oref = _attn_ref(qr, kr, vr, None, 0.125)
+    oref.backward(dout.view(B, T, H, 64).permute(0, 2, 1, 3))
+    g = qkv.to("cuda")
+    o, lse = K.attn_fwd(g[:, :d], g[:, d:2 * d], g[:, 2 * d:], B, T, H, 3 * d, 0.125, None)
+    close(o.view(B, T, H, 64), oref.permute(0, 2, 1, 3), 3e-5, "attn o (rescale)")
+    lse_ref = torch.logsumexp(torch.matmul(q, k.transpose(-2, -1)) * 0.125, -1) * 1.4426950408889634
+    close(lse.view(B, H, T), lse_ref, 1e-5, "attn lse (rescale)")
+    dq, dk, dv, _ = K.attn_bwd(g[:, :d], g[:, d:2 * d], g[:, 2 * d:], o, dout.to("cuda"), lse, B, T, H, 3 * d, 0.125, None)
+    close(dq.reshape(B, T, H, 64), qr.grad.permute(0, 2, 1, 3), 1e-4, "attn dq (rescale)")
+    close(dk.reshape(B, T, H, 64), kr.grad.permute(0, 2, 1, 3), 1e-4, "attn dk (rescale)")
+    close(dv.reshape(B, T, H, 64), vr.grad.permute(0, 2, 1, 3), 1e-4, "attn dv (rescale)")
+
+
 # ------------------------------------------------------------------ VQ (golden G4)
 def test_vq_against_golden(golden_dir):
     from audio8_amd import kernels as K, _lib as L

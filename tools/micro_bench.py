@@ -42,5 +42,24 @@ def main():
     print(f"dropout elementwise: {timeit(lambda: K.dropout(x, 0.1, 1, 2)):.1f} us; add: {timeit(lambda: K.add(x, res)):.1f} us")
 
 
+def attention():
+    d = "cuda"
+    B, T, H = 8, 781, 12
+    dm = H * 64
+    bf = torch.bfloat16
+    qkv = (torch.randn(B * T, 3 * dm, device=d) * 0.5).to(bf)
+    dout = torch.randn(B * T, dm, device=d).to(bf)
+    for p in (0.0, 0.1):
+        o, lse = K.attn_fwd(qkv[:, :dm], qkv[:, dm:2 * dm], qkv[:, 2 * dm:], B, T, H, 3 * dm, 0.125, None, p=p, seed=3)
+        tf = timeit(lambda: K.attn_fwd(qkv[:, :dm], qkv[:, dm:2 * dm], qkv[:, 2 * dm:], B, T, H, 3 * dm, 0.125, None, p=p, seed=3))
+        dq = torch.empty(B * T, 3 * dm, device=d, dtype=bf)
+        tb = timeit(lambda: K.attn_bwd(qkv[:, :dm], qkv[:, dm:2 * dm], qkv[:, 2 * dm:], o, dout, lse, B, T, H, 3 * dm, 0.125, None, p=p, seed=3, dqkv=dq))
+        gf = 4.0 * B * H * T * T * 64 / 1e9
+        print(f"attention p={p}: fwd {tf:.1f} us ({gf / tf * 1e3:.0f} TFLOP/s)  bwd (delta+kv+q) {tb:.1f} us ({2.5 * gf / tb * 1e3:.0f} TFLOP/s algorithmic)")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "attn":
+        attention()
+        sys.exit(0)
     main()
