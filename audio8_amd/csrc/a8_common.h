@@ -37,6 +37,24 @@ A8_DEV float gelu_grad_f(float x) {
 template <typename T> A8_DEV float to_f(T v) { return (float)v; }
 template <typename T> A8_DEV T from_f(float v) { return (T)v; }
 
+// Reductions over the 4 rows of 16 lanes (lanes with equal lane&15), all-VALU via the gfx950 permlane swaps
+// (no ds_bpermute round trip through the LDS pipeline).  Every lane receives the result.
+A8_DEV float rows_max(float x) {
+    auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    float lo = __uint_as_float(a[0]), hi = __uint_as_float(a[1]), m;
+    asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(lo), "v"(hi));
+    auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+    lo = __uint_as_float(b[0]); hi = __uint_as_float(b[1]);
+    asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(lo), "v"(hi));
+    return m;
+}
+A8_DEV float rows_sum(float x) {
+    auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    float m = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 A8_DEV float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

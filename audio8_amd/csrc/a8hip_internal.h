@@ -2,5 +2,6 @@
 #pragma once
 #include "../../include/a8hip.h"
 
-// a8_set_tuning table (runtime.hip): [0] GEMM variant, [1] ln_bwd geometry NW*100 + rows per wave
+// a8_set_tuning table (runtime.hip): [0] GEMM variant, [1] ln_bwd geometry NW*100 + rows per wave,
+// [2..4] attention fwd / dK,dV / dQ geometry NW*10 + row groups per wave
 extern int g_a8_tuning[8];

@@ -30,18 +30,23 @@ constexpr int DH = 64;      // head dim
 constexpr int BT = 64;      // tile rows (queries or keys)
 
 // ------------------------------------------------------------------ 64x64 LDS tile image
+// row_frag:  MFMA operand of 16 tile rows (k-slots = head-dim columns), read along the rows (b128, XOR-swizzled).
+// xt_frag:   MFMA operand of 16 tile COLUMNS c0.. (k-slots = 32 tile rows kb.. in ACCUMULATOR order: slot 4g+r of
+//            the first 16 rows, then of the next 16), read transposed -- it pairs with a probability fragment built
+//            from two score accumulators (pfrag), so P / dS go from accumulator registers straight into the next MFMA.
 template <typename T> struct ATile;
 template <> struct ATile<bf16> {
     static constexpr int BYTES = BT * 128;
     static constexpr int CPR = 8;                       // 16-byte chunks per row
+    typedef bf16x8 RF;
+    typedef bf16x8 XT;
+    typedef bf16x8 PF;
     static A8_DEV int off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
-    static A8_DEV bf16x8 row_frag(const char* t, int rb, int ks, int lane) {
+    static A8_DEV RF row_frag(const char* t, int rb, int ks, int lane) {
         const int row = rb + (lane & 15);
         return *reinterpret_cast<const bf16x8*>(t + off(row, ks * 4 + (lane >> 4)));
     }
-    // acc += X[rows kb..kb+31 in accumulator order][cols c0..c0+15]^T-contracted with the accumulator pair (p0,p1):
-    //   acc[reg r][lane] = out[c0 + 4g + r][lane&15] += sum_rows X[row][c0 + 4g + r] * P[row][lane&15]
-    static A8_DEV f32x4 mma_xt_p(const char* t, int kb, int c0, f32x4 p0, f32x4 p1, f32x4 acc, int lane) {
+    static A8_DEV XT xt_frag(const char* t, int kb, int c0, int lane) {
         const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
         const int r0 = kb + 4 * g + q, r1 = r0 + 16;
         const int ch = (c0 >> 3) + (p >> 1), sub = (p & 1) << 3;
@@ -49,38 +54,48 @@ template <> struct ATile<bf16> {
         s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, t + off(r1, ch) + sub));
         typedef short s16x8 __attribute__((ext_vector_type(8)));
         s16x8 xv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        bf16x8 pv = {(bf16)p0[0], (bf16)p0[1], (bf16)p0[2], (bf16)p0[3], (bf16)p1[0], (bf16)p1[1], (bf16)p1[2], (bf16)p1[3]};
-        return Mma<bf16>::mma(__builtin_bit_cast(bf16x8, xv), pv, acc);
+        return __builtin_bit_cast(bf16x8, xv);
     }
+    static A8_DEV PF pfrag(f32x4 p0, f32x4 p1) {
+        return (bf16x8){(bf16)p0[0], (bf16)p0[1], (bf16)p0[2], (bf16)p0[3], (bf16)p1[0], (bf16)p1[1], (bf16)p1[2], (bf16)p1[3]};
+    }
+    static A8_DEV f32x4 mma_xp(XT x, PF p, f32x4 acc) { return Mma<bf16>::mma(x, p, acc); }
 };
 template <> struct ATile<float> {
     static constexpr int LDF = 68;                      // floats per row (272 B, 16-byte aligned)
     static constexpr int BYTES = BT * LDF * 4;
     static constexpr int CPR = 16;
+    typedef float RF;
+    struct XT { float a[8]; };
+    struct PF { f32x4 p0, p1; };
     static A8_DEV int off(int row, int chunk) { return (row * LDF + chunk * 4) * 4; }
-    static A8_DEV float row_frag(const char* t, int rb, int ks, int lane) {
+    static A8_DEV RF row_frag(const char* t, int rb, int ks, int lane) {
         return *reinterpret_cast<const float*>(t + ((rb + (lane & 15)) * LDF + ks * 4 + (lane >> 4)) * 4);
     }
-    static A8_DEV f32x4 mma_xt_p(const char* t, int kb, int c0, f32x4 p0, f32x4 p1, f32x4 acc, int lane) {
+    static A8_DEV XT xt_frag(const char* t, int kb, int c0, int lane) {
         const int g = lane >> 4, i = lane & 15;
+        XT x;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float a = *reinterpret_cast<const float*>(t + ((kb + 4 * g + r) * LDF + c0 + i) * 4);
-            acc = Mma<float>::mma(a, p0[r], acc);
+            x.a[r] = *reinterpret_cast<const float*>(t + ((kb + 4 * g + r) * LDF + c0 + i) * 4);
+            x.a[4 + r] = *reinterpret_cast<const float*>(t + ((kb + 16 + 4 * g + r) * LDF + c0 + i) * 4);
         }
+        return x;
+    }
+    static A8_DEV PF pfrag(f32x4 p0, f32x4 p1) { return PF{p0, p1}; }
+    static A8_DEV f32x4 mma_xp(const XT& x, const PF& p, f32x4 acc) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float a = *reinterpret_cast<const float*>(t + ((kb + 16 + 4 * g + r) * LDF + c0 + i) * 4);
-            acc = Mma<float>::mma(a, p1[r], acc);
-        }
+        for (int r = 0; r < 4; ++r) acc = Mma<float>::mma(x.a[r], p.p0[r], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = Mma<float>::mma(x.a[4 + r], p.p1[r], acc);
         return acc;
     }
 };
 
-template <typename T> struct AStage {               // global -> registers -> LDS for one 64x64 tile, 256 threads
+template <typename T, int NT> struct AStage {       // global -> registers -> LDS for one 64x64 tile, NT threads
     static constexpr int CPR = ATile<T>::CPR;
-    static constexpr int NCH = BT * CPR / 256;       // chunks per thread (bf16: 2, f32: 4)
-    static constexpr int RSTEP = 256 / CPR;
+    static constexpr int NCH = BT * CPR / NT;        // chunks per thread
+    static constexpr int RSTEP = NT / CPR;
     u32x4 r[NCH];
     A8_DEV void load(const T* base, long long ld, int row0, int nrows) {   // base -> element (row 0, col 0 of the head)
         const int c = threadIdx.x % CPR, r0 = threadIdx.x / CPR;
@@ -117,26 +132,38 @@ template <> struct RowFrags<float> {
     }
 };
 
-// S^T tile block: acc[i] (i = 0..3) = rows 16i.. of (Tile . RowFrags^T): acc[i][r] = sum_d Tile[16i+4g+r][d] * row[lane&15][d]
-template <typename T> A8_DEV void tile_times_rows(const char* tile, const RowFrags<T>& rf, f32x4 (&acc)[4], int lane) {
+// acc[j][i] (i = 0..3) = 16x16 blocks of Tile . rows_j^T for G register-resident row groups: each tile fragment is
+// read from LDS once and feeds G MFMAs.   acc[j][i][r] = sum_d Tile[16i+4g+r][d] * rows_j[lane&15][d]
+template <typename T, int G> A8_DEV void tile_times_rows(const char* tile, const RowFrags<T> (&rf)[G], f32x4 (&acc)[G][4], int lane) {
     constexpr int NKS = DH / Mma<T>::KI;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < G; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = Mma<T>::mma(ATile<T>::row_frag(tile, 16 * i, ks, lane), rf.f[ks], acc[i]);
+        for (int i = 0; i < 4; ++i) {
+            const typename ATile<T>::RF a = ATile<T>::row_frag(tile, 16 * i, ks, lane);
+#pragma unroll
+            for (int j = 0; j < G; ++j) acc[j][i] = Mma<T>::mma(a, rf[j].f[ks], acc[j][i]);
+        }
 }
-// the mirrored product: acc[i][r] = sum_d row... with the tile as the B-side: out[q = 16i+4g+r][key = lane&15]
-template <typename T> A8_DEV void rows_times_tile(const char* tile, const RowFrags<T>& rf, f32x4 (&acc)[4], int lane) {
-    constexpr int NKS = DH / Mma<T>::KI;
+// out[j][db] += (tile columns 16db..)^T-contracted with the probability fragments pf[j][half] (half = tile rows 32*half..)
+template <typename T, int G> A8_DEV void xt_times_p(const char* tile, const typename ATile<T>::PF (&pf)[G][2], f32x4 (&out)[G][4], int lane) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int db = 0; db < 4; ++db)
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks)
+        for (int hf = 0; hf < 2; ++hf) {
+            const typename ATile<T>::XT x = ATile<T>::xt_frag(tile, 32 * hf, 16 * db, lane);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = Mma<T>::mma(ATile<T>::row_frag(tile, 16 * i, ks, lane), rf.f[ks], acc[i]);
+            for (int j = 0; j < G; ++j) out[j][db] = ATile<T>::mma_xp(x, pf[j][hf], out[j][db]);
+        }
 }
+
+// Streaming two 64x64 tiles (K,V or Q,dO) through LDS.  16-bit: two LDS buffers, the tile after next is in flight in
+// registers, ONE barrier per tile.  f32 (parity mode, 2 x 17 KB tiles): single buffer, two barriers.
+template <typename T> constexpr int attn_nbuf() { return sizeof(T) == 2 ? 2 : 1; }
 
 struct AttnP {
     const char *q, *k, *v, *o, *dout;
@@ -179,115 +206,150 @@ template <> A8_DEV void store4<bf16>(bf16* p, float a, float b, float c, float d
 }
 template <> A8_DEV void store4<float>(float* p, float a, float b, float c, float d) { *reinterpret_cast<f32x4*>(p) = (f32x4){a, b, c, d}; }
 
+// Common prologue/stream loop for a pair of tiles (ta, tb) read from (pa, lda) / (pb, ldb).
+//   bf16:  tile t is computed from buffer t&1 while tile t+1 is written to the other buffer and tile t+2 is loading.
+#define ATTN_STREAM_BEGIN(pa, lda_, pb, ldb_)                                                              \
+    AStage<T, NT> sa_, sb_;                                                                                \
+    sa_.load(pa, lda_, 0, P.T);                                                                            \
+    sb_.load(pb, ldb_, 0, P.T);                                                                            \
+    if constexpr (NBUF == 2) {                                                                             \
+        sa_.store(lds);                                                                                    \
+        sb_.store(lds + TB);                                                                               \
+        if (ntiles > 1) { sa_.load(pa, lda_, BT, P.T); sb_.load(pb, ldb_, BT, P.T); }                      \
+        __syncthreads();                                                                                   \
+    }
+#define ATTN_STREAM_TILE(t, pa, lda_, pb, ldb_, ta, tb)                                                    \
+    const char *ta, *tb;                                                                                   \
+    if constexpr (NBUF == 2) {                                                                             \
+        ta = lds + ((t) & 1) * 2 * TB;                                                                     \
+        tb = ta + TB;                                                                                      \
+        if ((t) + 1 < ntiles) {                                                                            \
+            char* nx = lds + (((t) + 1) & 1) * 2 * TB;                                                     \
+            sa_.store(nx);                                                                                 \
+            sb_.store(nx + TB);                                                                            \
+            if ((t) + 2 < ntiles) { sa_.load(pa, lda_, ((t) + 2) * BT, P.T); sb_.load(pb, ldb_, ((t) + 2) * BT, P.T); } \
+        }                                                                                                  \
+    } else {                                                                                               \
+        ta = lds;                                                                                          \
+        tb = lds + TB;                                                                                     \
+        __syncthreads();                                                                                   \
+        sa_.store(lds);                                                                                    \
+        sb_.store(lds + TB);                                                                               \
+        __syncthreads();                                                                                   \
+        if ((t) + 1 < ntiles) { sa_.load(pa, lda_, ((t) + 1) * BT, P.T); sb_.load(pb, ldb_, ((t) + 1) * BT, P.T); } \
+    }
+#define ATTN_STREAM_END() if constexpr (NBUF == 2) __syncthreads();
+
 // ================================================================== forward
-template <typename T>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP P) {
-    __shared__ __attribute__((aligned(16))) char lds[2 * ATile<T>::BYTES];
-    char* kt = lds;
-    char* vt = lds + ATile<T>::BYTES;
+// block = NW waves, each wave owns G groups of 16 queries (query = 16*group + lane&15)
+template <typename T, int NW, int G>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnP P) {
+    constexpr int NT = NW * 64, BQ = NW * G * 16, TB = ATile<T>::BYTES, NBUF = attn_nbuf<T>();
+    __shared__ __attribute__((aligned(16))) char lds[NBUF * 2 * TB];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
     int blk, bh;
-    block_coords((P.T + BT - 1) / BT, P.B * P.H, blk, bh);
+    block_coords((P.T + BQ - 1) / BQ, P.B * P.H, blk, bh);
     const int b = bh / P.H, h = bh % P.H;
-    const int q0 = blk * BT + wv * 16, qi = q0 + li;
     const T* qb = reinterpret_cast<const T*>(P.q) + (long long)b * P.T * P.ld_qkv + h * DH;
     const T* kb = reinterpret_cast<const T*>(P.k) + (long long)b * P.T * P.ld_qkv + h * DH;
     const T* vb = reinterpret_cast<const T*>(P.v) + (long long)b * P.T * P.ld_qkv + h * DH;
-    RowFrags<T> qf;
-    qf.load(qb + (long long)qi * P.ld_qkv, qi < P.T, lane);
     const uint8_t* km = P.keymask ? P.keymask + (long long)b * P.T : nullptr;
-
-    f32x4 oacc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) oacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m = -INFINITY, l = 0.f;                     // m: the max the probabilities are referred to (log2 domain)
     const int ntiles = (P.T + BT - 1) / BT;
-    uint32_t hb = (pair_base(bh, P.T, P.Th, qi) + (uint32_t)(2 * g) + P.seed) * HC1;    // dropout word base of this tile
-    AStage<T> sk, sv;
-    sk.load(kb, P.ld_qkv, 0, P.T);
-    sv.load(vb, P.ld_qkv, 0, P.T);
-    for (int kt_i = 0; kt_i < ntiles; ++kt_i) {
-        __syncthreads();
-        sk.store(kt);
-        sv.store(vt);
-        __syncthreads();
-        if (kt_i + 1 < ntiles) {
-            sk.load(kb, P.ld_qkv, (kt_i + 1) * BT, P.T);
-            sv.load(vb, P.ld_qkv, (kt_i + 1) * BT, P.T);
-        }
-        f32x4 s[4];
-        tile_times_rows<T>(kt, qf, s, lane);          // s[i][r] = raw S^T[key 16i+4g+r][query li]
-        const bool edge = km != nullptr || (kt_i + 1) * BT > P.T;      // wave-uniform: masks / tail only here
-        float mt;
-        if (!edge) {
-            mt = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
+
+    RowFrags<T> qf[G];
+    f32x4 oacc[G][4];
+    float m[G], l[G];                                 // m: the max the probabilities are referred to (log2 domain)
+    uint32_t hb[G];                                   // dropout word base of the current tile
+    int qi[G];
 #pragma unroll
-            for (int i = 1; i < 4; ++i) mt = fmaxf(fmaxf(mt, s[i][0]), fmaxf(fmaxf(s[i][1], s[i][2]), s[i][3]));
-            mt *= P.scale;
-        } else {
-            const int key0 = kt_i * BT + 4 * g;
-            mt = -INFINITY;
+    for (int j = 0; j < G; ++j) {
+        qi[j] = blk * BQ + (wv * G + j) * 16 + li;
+        qf[j].load(qb + (long long)qi[j] * P.ld_qkv, qi[j] < P.T, lane);
+        m[j] = -INFINITY; l[j] = 0.f;
+        hb[j] = (pair_base(bh, P.T, P.Th, qi[j]) + (uint32_t)(2 * g) + P.seed) * HC1;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = key0 + 16 * i + r;
-                    float x = s[i][r] * P.scale;
-                    if (km && key < P.T && !km[key]) x = MASKED_LOG2;
-                    if (key >= P.T) x = -INFINITY;
-                    s[i][r] = x;                     // already scaled on this path
-                    mt = fmaxf(mt, x);
-                }
-        }
-        mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        if (__any(mt > m + P.lazy)) {                 // first tile: m = -inf -> always taken, alpha = 0
-            const float mn = fmaxf(m, mt);
-            const float alpha = fast_exp2(m - mn);
-            m = mn;
-            l *= alpha;
-#pragma unroll
-            for (int db = 0; db < 4; ++db) oacc[db] *= alpha;
-        }
-        float ls = 0.f;
-        if (!edge) {
-            const float nb = -m;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { s[i][r] = fast_exp2(__builtin_fmaf(s[i][r], P.scale, nb)); ls += s[i][r]; }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { s[i][r] = fast_exp2(s[i][r] - m); ls += s[i][r]; }
-        }
-        l += ls;
-        if (P.thr) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t h0 = hfin(hb + (uint32_t)(8 * i) * HC1), h1 = hfin(hb + (uint32_t)(8 * i + 1) * HC1);
-                s[i][0] = (h0 & 0xFFFFu) >= P.thr ? s[i][0] : 0.f;
-                s[i][1] = (h0 >> 16) >= P.thr ? s[i][1] : 0.f;
-                s[i][2] = (h1 & 0xFFFFu) >= P.thr ? s[i][2] : 0.f;
-                s[i][3] = (h1 >> 16) >= P.thr ? s[i][3] : 0.f;
-            }
-            hb += (uint32_t)(BT / 2) * HC1;
-        }
-#pragma unroll
-        for (int db = 0; db < 4; ++db) {
-            oacc[db] = ATile<T>::mma_xt_p(vt, 0, 16 * db, s[0], s[1], oacc[db], lane);
-            oacc[db] = ATile<T>::mma_xt_p(vt, 32, 16 * db, s[2], s[3], oacc[db], lane);
-        }
+        for (int i = 0; i < 4; ++i) oacc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-    if (qi < P.T) {
-        const float inv = P.pscale / l;               // 1/(1-p) of the dropout is applied here, once
-        T* op = reinterpret_cast<T*>(P.out) + ((long long)b * P.T + qi) * P.ld_o + h * DH + 4 * g;
+    ATTN_STREAM_BEGIN(kb, P.ld_qkv, vb, P.ld_qkv)
+    for (int kt_i = 0; kt_i < ntiles; ++kt_i) {
+        ATTN_STREAM_TILE(kt_i, kb, P.ld_qkv, vb, P.ld_qkv, kt, vt)
+        f32x4 s[G][4];
+        tile_times_rows<T, G>(kt, qf, s, lane);       // s[j][i][r] = raw S^T[key 16i+4g+r][query group j, li]
+        const bool edge = km != nullptr || (kt_i + 1) * BT > P.T;      // wave-uniform: masks / tail only here
+        typename ATile<T>::PF pf[G][2];
 #pragma unroll
-        for (int db = 0; db < 4; ++db) store4<T>(op + 16 * db, oacc[db][0] * inv, oacc[db][1] * inv, oacc[db][2] * inv, oacc[db][3] * inv);
-        if (g == 0) P.lse[((long long)bh) * P.T + qi] = m + log2f(l);     // log2-domain log-sum-exp
+        for (int j = 0; j < G; ++j) {
+            float mt;
+            if (!edge) {
+                mt = fmaxf(fmaxf(s[j][0][0], s[j][0][1]), fmaxf(s[j][0][2], s[j][0][3]));
+#pragma unroll
+                for (int i = 1; i < 4; ++i) mt = fmaxf(fmaxf(mt, s[j][i][0]), fmaxf(fmaxf(s[j][i][1], s[j][i][2]), s[j][i][3]));
+                mt *= P.scale;
+            } else {
+                const int key0 = kt_i * BT + 4 * g;
+                mt = -INFINITY;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = key0 + 16 * i + r;
+                        float x = s[j][i][r] * P.scale;
+                        if (km && key < P.T && !km[key]) x = MASKED_LOG2;
+                        if (key >= P.T) x = -INFINITY;
+                        s[j][i][r] = x;              // already scaled on this path
+                        mt = fmaxf(mt, x);
+                    }
+            }
+            mt = rows_max(mt);
+            if (__any(mt > m[j] + P.lazy)) {          // first tile: m = -inf -> always taken, alpha = 0
+                const float mn = fmaxf(m[j], mt);
+                const float alpha = fast_exp2(m[j] - mn);
+                m[j] = mn;
+                l[j] *= alpha;
+#pragma unroll
+                for (int db = 0; db < 4; ++db) oacc[j][db] *= alpha;
+            }
+            float ls = 0.f;
+            if (!edge) {
+                const float nb = -m[j];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { s[j][i][r] = fast_exp2(__builtin_fmaf(s[j][i][r], P.scale, nb)); ls += s[j][i][r]; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { s[j][i][r] = fast_exp2(s[j][i][r] - m[j]); ls += s[j][i][r]; }
+            }
+            l[j] += ls;
+            if (P.thr) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t h0 = hfin(hb[j] + (uint32_t)(8 * i) * HC1), h1 = hfin(hb[j] + (uint32_t)(8 * i + 1) * HC1);
+                    s[j][i][0] = (h0 & 0xFFFFu) >= P.thr ? s[j][i][0] : 0.f;
+                    s[j][i][1] = (h0 >> 16) >= P.thr ? s[j][i][1] : 0.f;
+                    s[j][i][2] = (h1 & 0xFFFFu) >= P.thr ? s[j][i][2] : 0.f;
+                    s[j][i][3] = (h1 >> 16) >= P.thr ? s[j][i][3] : 0.f;
+                }
+                hb[j] += (uint32_t)(BT / 2) * HC1;
+            }
+            pf[j][0] = ATile<T>::pfrag(s[j][0], s[j][1]);
+            pf[j][1] = ATile<T>::pfrag(s[j][2], s[j][3]);
+        }
+        xt_times_p<T, G>(vt, pf, oacc, lane);
+        ATTN_STREAM_END()
+    }
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+        const float lj = rows_sum(l[j]);
+        if (qi[j] < P.T) {
+            const float inv = P.pscale / lj;          // 1/(1-p) of the dropout is applied here, once
+            T* op = reinterpret_cast<T*>(P.out) + ((long long)b * P.T + qi[j]) * P.ld_o + h * DH + 4 * g;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) store4<T>(op + 16 * db, oacc[j][db][0] * inv, oacc[j][db][1] * inv, oacc[j][db][2] * inv, oacc[j][db][3] * inv);
+            if (g == 0) P.lse[((long long)bh) * P.T + qi[j]] = m[j] + log2f(lj);     // log2-domain log-sum-exp
+        }
     }
 }
 
@@ -318,172 +380,195 @@ __global__ void attn_delta_kernel(const AttnP P) {
 }
 
 // ================================================================== backward A: dK, dV (key block stationary)
-template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnP P) {
-    __shared__ __attribute__((aligned(16))) char lds[2 * ATile<T>::BYTES];
-    __shared__ __attribute__((aligned(16))) float s_lse[BT], s_delta[BT];
-    char* qt = lds;
-    char* dot = lds + ATile<T>::BYTES;
+// block = NW waves, each wave owns G groups of 16 keys; streams Q / dO tiles (+ lse, delta of the tile's queries)
+template <typename T, int NW, int G>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_kv_kernel(const AttnP P) {
+    constexpr int NT = NW * 64, BK = NW * G * 16, TB = ATile<T>::BYTES, NBUF = attn_nbuf<T>();
+    __shared__ __attribute__((aligned(16))) char lds[NBUF * 2 * TB];
+    __shared__ __attribute__((aligned(16))) float s_stat[NBUF][2][BT];     // [buffer][lse | delta][query in tile]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
     int blk, bh;
-    block_coords((P.T + BT - 1) / BT, P.B * P.H, blk, bh);
+    block_coords((P.T + BK - 1) / BK, P.B * P.H, blk, bh);
     const int b = bh / P.H, h = bh % P.H;
-    const int key = blk * BT + wv * 16 + li;
     const T* qb = reinterpret_cast<const T*>(P.q) + (long long)b * P.T * P.ld_qkv + h * DH;
     const T* kb = reinterpret_cast<const T*>(P.k) + (long long)b * P.T * P.ld_qkv + h * DH;
     const T* vb = reinterpret_cast<const T*>(P.v) + (long long)b * P.T * P.ld_qkv + h * DH;
     const T* dob = reinterpret_cast<const T*>(P.dout) + (long long)b * P.T * P.ld_o + h * DH;
-    RowFrags<T> kf, vf;
-    kf.load(kb + (long long)key * P.ld_qkv, key < P.T, lane);
-    vf.load(vb + (long long)key * P.ld_qkv, key < P.T, lane);
-    const bool key_ok = key < P.T;
-    const bool key_masked = P.keymask && key_ok && !P.keymask[(long long)b * P.T + key];
-
-    f32x4 dk[4], dv[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { dk[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     const int ntiles = (P.T + BT - 1) / BT;
-    // dropout word of (query qq, this lane's key): fin(hk + (qq - tile base - 4g) * ThC); field (key & 1)
     const uint32_t ThC = (uint32_t)P.Th * HC1;
-    uint32_t hk = (pair_base(bh, P.T, P.Th, 4 * g) + (uint32_t)(key >> 1) + P.seed) * HC1;
-    const uint32_t fsh = (key & 1) << 4;
-    AStage<T> sq, sd;
-    sq.load(qb, P.ld_qkv, 0, P.T);
-    sd.load(dob, P.ld_o, 0, P.T);
+
+    RowFrags<T> kf[G], vf[G];
+    f32x4 dk[G][4], dv[G][4];
+    int key[G];
+    bool key_masked[G];
+    uint32_t hk[G], fsh[G];       // dropout word of (query qq, key): fin(hk + (qq - tile base - 4g) * ThC), field (key & 1)
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+        key[j] = blk * BK + (wv * G + j) * 16 + li;
+        const bool ok = key[j] < P.T;
+        kf[j].load(kb + (long long)key[j] * P.ld_qkv, ok, lane);
+        vf[j].load(vb + (long long)key[j] * P.ld_qkv, ok, lane);
+        key_masked[j] = P.keymask && ok && !P.keymask[(long long)b * P.T + key[j]];
+        hk[j] = (pair_base(bh, P.T, P.Th, 4 * g) + (uint32_t)(key[j] >> 1) + P.seed) * HC1;
+        fsh[j] = (key[j] & 1) << 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { dk[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    }
+    // per-tile softmax statistics ride along with the tiles: rows beyond T get Q = dO = 0 (staged zero) and
+    // lse = delta = 0, which makes dS = 0 and P^T dO = 0 without any per-element test
+    auto load_stat = [&](int t) -> float {
+        const int qq = t * BT + (threadIdx.x & (BT - 1));
+        if (threadIdx.x >= 2 * BT || qq >= P.T) return 0.f;
+        return (threadIdx.x < BT ? P.lse : P.delta)[(long long)bh * P.T + qq];
+    };
+    auto store_stat = [&](int buf, float v) {
+        if (threadIdx.x < 2 * BT) s_stat[buf][threadIdx.x >> 6][threadIdx.x & (BT - 1)] = v;
+    };
+    static_assert(NT >= 2 * BT, "statistics staging needs 128 threads");
+    float st = load_stat(0);
+    if constexpr (NBUF == 2) { store_stat(0, st); if (ntiles > 1) st = load_stat(1); }
+    ATTN_STREAM_BEGIN(qb, P.ld_qkv, dob, P.ld_o)
     for (int qt_i = 0; qt_i < ntiles; ++qt_i) {
-        __syncthreads();
-        sq.store(qt);
-        sd.store(dot);
-        if (threadIdx.x < BT) {                        // rows beyond T: Q = dO = 0 (staged zero), lse = delta = 0 -> dS = 0, P^T dO = 0
-            const int qq = qt_i * BT + threadIdx.x;
-            s_lse[threadIdx.x] = qq < P.T ? P.lse[(long long)bh * P.T + qq] : 0.f;
-            s_delta[threadIdx.x] = qq < P.T ? P.delta[(long long)bh * P.T + qq] : 0.f;
+        const float* stat;
+        if constexpr (NBUF == 2) {
+            stat = &s_stat[qt_i & 1][0][0];
+            if (qt_i + 1 < ntiles) { store_stat((qt_i + 1) & 1, st); if (qt_i + 2 < ntiles) st = load_stat(qt_i + 2); }
+        } else {
+            stat = &s_stat[0][0][0];
         }
-        __syncthreads();
-        if (qt_i + 1 < ntiles) {
-            sq.load(qb, P.ld_qkv, (qt_i + 1) * BT, P.T);
-            sd.load(dob, P.ld_o, (qt_i + 1) * BT, P.T);
+        ATTN_STREAM_TILE(qt_i, qb, P.ld_qkv, dob, P.ld_o, qt, dot)
+        if constexpr (NBUF == 1) {                     // single buffer: the tile macro has just passed its two barriers
+            __syncthreads();
+            store_stat(0, st);
+            __syncthreads();
+            if (qt_i + 1 < ntiles) st = load_stat(qt_i + 1);
         }
-        f32x4 s[4], dp[4];
-        rows_times_tile<T>(qt, kf, s, lane);           // s[i][r]  = raw S[q 16i+4g+r][key li]
-        rows_times_tile<T>(dot, vf, dp, lane);         // dp[i][r] = (dO V^T)[q][key]
+        f32x4 s[G][4], dp[G][4];
+        tile_times_rows<T, G>(qt, kf, s, lane);        // s[j][i][r]  = raw S[q 16i+4g+r][key group j, li]
+        tile_times_rows<T, G>(dot, vf, dp, lane);      // dp[j][i][r] = (dO V^T)[q][key]
+        typename ATile<T>::PF pp[G][2], pd[G][2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const f32x4 lse4 = *reinterpret_cast<const f32x4*>(&s_lse[16 * i + 4 * g]);
-            const f32x4 del4 = *reinterpret_cast<const f32x4*>(&s_delta[16 * i + 4 * g]);
+        for (int j = 0; j < G; ++j) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float x = __builtin_fmaf(s[i][r], P.scale, -lse4[r]);
-                if (P.keymask && key_masked) x = MASKED_LOG2 - lse4[r];
-                const float p = fast_exp2(x);          // keys beyond T: harmless garbage in rows that are never stored
-                float pd = p, dpv = dp[i][r];
-                if (P.thr) {
-                    const uint32_t hh = hfin(hk + (uint32_t)(16 * i + r) * ThC);
-                    const bool keep = ((hh >> fsh) & 0xFFFFu) >= P.thr;
-                    pd = keep ? p : 0.f;
-                    dpv = keep ? dpv : 0.f;
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 lse4 = *reinterpret_cast<const f32x4*>(stat + 16 * i + 4 * g);
+                const f32x4 del4 = *reinterpret_cast<const f32x4*>(stat + BT + 16 * i + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = __builtin_fmaf(s[j][i][r], P.scale, -lse4[r]);
+                    if (P.keymask && key_masked[j]) x = MASKED_LOG2 - lse4[r];
+                    const float p = fast_exp2(x);      // keys beyond T: harmless garbage in rows that are never stored
+                    float pdrop = p, dpv = dp[j][i][r];
+                    if (P.thr) {
+                        const uint32_t hh = hfin(hk[j] + (uint32_t)(16 * i + r) * ThC);
+                        const bool keep = ((hh >> fsh[j]) & 0xFFFFu) >= P.thr;
+                        pdrop = keep ? p : 0.f;
+                        dpv = keep ? dpv : 0.f;
+                    }
+                    s[j][i][r] = pdrop;                                                  // P (dropped, unscaled) for dV
+                    dp[j][i][r] = p * __builtin_fmaf(dpv, P.pscale, -del4[r]);           // dS / softmax scale for dK
                 }
-                s[i][r] = pd;                                                     // P (dropped, unscaled) for dV
-                dp[i][r] = p * __builtin_fmaf(dpv, P.pscale, -del4[r]);          // dS / softmax scale for dK
+            }
+            hk[j] += (uint32_t)BT * ThC;
+            pp[j][0] = ATile<T>::pfrag(s[j][0], s[j][1]);
+            pp[j][1] = ATile<T>::pfrag(s[j][2], s[j][3]);
+            pd[j][0] = ATile<T>::pfrag(dp[j][0], dp[j][1]);
+            pd[j][1] = ATile<T>::pfrag(dp[j][2], dp[j][3]);
+        }
+        xt_times_p<T, G>(dot, pp, dv, lane);
+        xt_times_p<T, G>(qt, pd, dk, lane);
+        ATTN_STREAM_END()
+    }
+#pragma unroll
+    for (int j = 0; j < G; ++j)
+        if (key[j] < P.T) {
+            T* dkp = reinterpret_cast<T*>(P.dk) + ((long long)b * P.T + key[j]) * P.ld_d + h * DH + 4 * g;
+            T* dvp = reinterpret_cast<T*>(P.dv) + ((long long)b * P.T + key[j]) * P.ld_d + h * DH + 4 * g;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                store4<T>(dkp + 16 * db, dk[j][db][0] * P.dscale, dk[j][db][1] * P.dscale, dk[j][db][2] * P.dscale, dk[j][db][3] * P.dscale);
+                store4<T>(dvp + 16 * db, dv[j][db][0] * P.pscale, dv[j][db][1] * P.pscale, dv[j][db][2] * P.pscale, dv[j][db][3] * P.pscale);
             }
         }
-        hk += (uint32_t)BT * ThC;
-#pragma unroll
-        for (int db = 0; db < 4; ++db) {
-            dv[db] = ATile<T>::mma_xt_p(dot, 0, 16 * db, s[0], s[1], dv[db], lane);
-            dv[db] = ATile<T>::mma_xt_p(dot, 32, 16 * db, s[2], s[3], dv[db], lane);
-            dk[db] = ATile<T>::mma_xt_p(qt, 0, 16 * db, dp[0], dp[1], dk[db], lane);
-            dk[db] = ATile<T>::mma_xt_p(qt, 32, 16 * db, dp[2], dp[3], dk[db], lane);
-        }
-    }
-    if (key_ok) {
-        T* dkp = reinterpret_cast<T*>(P.dk) + ((long long)b * P.T + key) * P.ld_d + h * DH + 4 * g;
-        T* dvp = reinterpret_cast<T*>(P.dv) + ((long long)b * P.T + key) * P.ld_d + h * DH + 4 * g;
-#pragma unroll
-        for (int db = 0; db < 4; ++db) {
-            store4<T>(dkp + 16 * db, dk[db][0] * P.dscale, dk[db][1] * P.dscale, dk[db][2] * P.dscale, dk[db][3] * P.dscale);
-            store4<T>(dvp + 16 * db, dv[db][0] * P.pscale, dv[db][1] * P.pscale, dv[db][2] * P.pscale, dv[db][3] * P.pscale);
-        }
-    }
 }
 
 // ================================================================== backward B: dQ (query block stationary)
-template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnP P) {
-    __shared__ __attribute__((aligned(16))) char lds[2 * ATile<T>::BYTES];
-    char* kt = lds;
-    char* vt = lds + ATile<T>::BYTES;
+template <typename T, int NW, int G>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_q_kernel(const AttnP P) {
+    constexpr int NT = NW * 64, BQ = NW * G * 16, TB = ATile<T>::BYTES, NBUF = attn_nbuf<T>();
+    __shared__ __attribute__((aligned(16))) char lds[NBUF * 2 * TB];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
     int blk, bh;
-    block_coords((P.T + BT - 1) / BT, P.B * P.H, blk, bh);
+    block_coords((P.T + BQ - 1) / BQ, P.B * P.H, blk, bh);
     const int b = bh / P.H, h = bh % P.H;
-    const int qi = blk * BT + wv * 16 + li;
-    const bool q_ok = qi < P.T;
     const T* qb = reinterpret_cast<const T*>(P.q) + (long long)b * P.T * P.ld_qkv + h * DH;
     const T* kb = reinterpret_cast<const T*>(P.k) + (long long)b * P.T * P.ld_qkv + h * DH;
     const T* vb = reinterpret_cast<const T*>(P.v) + (long long)b * P.T * P.ld_qkv + h * DH;
     const T* dob = reinterpret_cast<const T*>(P.dout) + (long long)b * P.T * P.ld_o + h * DH;
-    RowFrags<T> qf, dof;
-    qf.load(qb + (long long)qi * P.ld_qkv, q_ok, lane);
-    dof.load(dob + (long long)qi * P.ld_o, q_ok, lane);
-    const float lse = q_ok ? P.lse[(long long)bh * P.T + qi] : 0.f;
-    const float delta = q_ok ? P.delta[(long long)bh * P.T + qi] : 0.f;
     const uint8_t* km = P.keymask ? P.keymask + (long long)b * P.T : nullptr;
-
-    f32x4 dq[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int ntiles = (P.T + BT - 1) / BT;
-    uint32_t hb = (pair_base(bh, P.T, P.Th, qi) + (uint32_t)(2 * g) + P.seed) * HC1;
-    const float nlse = -lse, ndelta = -delta;
-    AStage<T> sk, sv;
-    sk.load(kb, P.ld_qkv, 0, P.T);
-    sv.load(vb, P.ld_qkv, 0, P.T);
+
+    RowFrags<T> qf[G], dof[G];
+    f32x4 dq[G][4];
+    float nlse[G], ndelta[G];
+    uint32_t hb[G];
+    int qi[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+        qi[j] = blk * BQ + (wv * G + j) * 16 + li;
+        const bool ok = qi[j] < P.T;
+        qf[j].load(qb + (long long)qi[j] * P.ld_qkv, ok, lane);
+        dof[j].load(dob + (long long)qi[j] * P.ld_o, ok, lane);
+        nlse[j] = ok ? -P.lse[(long long)bh * P.T + qi[j]] : 0.f;
+        ndelta[j] = ok ? -P.delta[(long long)bh * P.T + qi[j]] : 0.f;
+        hb[j] = (pair_base(bh, P.T, P.Th, qi[j]) + (uint32_t)(2 * g) + P.seed) * HC1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dq[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    ATTN_STREAM_BEGIN(kb, P.ld_qkv, vb, P.ld_qkv)
     for (int kt_i = 0; kt_i < ntiles; ++kt_i) {
-        __syncthreads();
-        sk.store(kt);
-        sv.store(vt);
-        __syncthreads();
-        if (kt_i + 1 < ntiles) {
-            sk.load(kb, P.ld_qkv, (kt_i + 1) * BT, P.T);
-            sv.load(vb, P.ld_qkv, (kt_i + 1) * BT, P.T);
-        }
-        f32x4 s[4], dp[4];
-        tile_times_rows<T>(kt, qf, s, lane);           // raw S^T[key][q]
-        tile_times_rows<T>(vt, dof, dp, lane);         // (V dO^T)[key][q]
+        ATTN_STREAM_TILE(kt_i, kb, P.ld_qkv, vb, P.ld_qkv, kt, vt)
+        f32x4 s[G][4], dp[G][4];
+        tile_times_rows<T, G>(kt, qf, s, lane);        // raw S^T[key][q]
+        tile_times_rows<T, G>(vt, dof, dp, lane);      // (V dO^T)[key][q]
         // keys beyond T: staged K = V = 0, so dS is finite garbage that multiplies zero K rows -- no tail test needed
+        typename ATile<T>::PF pf[G][2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            uint32_t h0 = 0, h1 = 0;
-            if (P.thr) { h0 = hfin(hb + (uint32_t)(8 * i) * HC1); h1 = hfin(hb + (uint32_t)(8 * i + 1) * HC1); }
+        for (int j = 0; j < G; ++j) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float x = __builtin_fmaf(s[i][r], P.scale, nlse);
-                if (km) {                                                  // wave-uniform
-                    const int key = kt_i * BT + 4 * g + 16 * i + r;
-                    if (key < P.T && !km[key]) x = MASKED_LOG2 + nlse;
+            for (int i = 0; i < 4; ++i) {
+                uint32_t h0 = 0, h1 = 0;
+                if (P.thr) { h0 = hfin(hb[j] + (uint32_t)(8 * i) * HC1); h1 = hfin(hb[j] + (uint32_t)(8 * i + 1) * HC1); }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = __builtin_fmaf(s[j][i][r], P.scale, nlse[j]);
+                    if (km) {                                                  // wave-uniform
+                        const int key = kt_i * BT + 4 * g + 16 * i + r;
+                        if (key < P.T && !km[key]) x = MASKED_LOG2 + nlse[j];
+                    }
+                    const float p = fast_exp2(x);
+                    float dpv = dp[j][i][r];
+                    if (P.thr) {
+                        const uint32_t hh = (r < 2) ? h0 : h1;
+                        dpv = (((r & 1) ? (hh >> 16) : (hh & 0xFFFFu)) >= P.thr) ? dpv : 0.f;
+                    }
+                    s[j][i][r] = p * __builtin_fmaf(dpv, P.pscale, ndelta[j]);      // dS^T[key][q] / softmax scale
                 }
-                const float p = fast_exp2(x);
-                float dpv = dp[i][r];
-                if (P.thr) {
-                    const uint32_t hh = (r < 2) ? h0 : h1;
-                    dpv = (((r & 1) ? (hh >> 16) : (hh & 0xFFFFu)) >= P.thr) ? dpv : 0.f;
-                }
-                s[i][r] = p * __builtin_fmaf(dpv, P.pscale, ndelta);      // dS^T[key][q] / softmax scale
             }
+            hb[j] += (uint32_t)(BT / 2) * HC1;
+            pf[j][0] = ATile<T>::pfrag(s[j][0], s[j][1]);
+            pf[j][1] = ATile<T>::pfrag(s[j][2], s[j][3]);
         }
-        hb += (uint32_t)(BT / 2) * HC1;
+        xt_times_p<T, G>(kt, pf, dq, lane);
+        ATTN_STREAM_END()
+    }
 #pragma unroll
-        for (int db = 0; db < 4; ++db) {
-            dq[db] = ATile<T>::mma_xt_p(kt, 0, 16 * db, s[0], s[1], dq[db], lane);
-            dq[db] = ATile<T>::mma_xt_p(kt, 32, 16 * db, s[2], s[3], dq[db], lane);
+    for (int j = 0; j < G; ++j)
+        if (qi[j] < P.T) {
+            T* dqp = reinterpret_cast<T*>(P.dq) + ((long long)b * P.T + qi[j]) * P.ld_d + h * DH + 4 * g;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) store4<T>(dqp + 16 * db, dq[j][db][0] * P.dscale, dq[j][db][1] * P.dscale, dq[j][db][2] * P.dscale, dq[j][db][3] * P.dscale);
         }
-    }
-    if (q_ok) {
-        T* dqp = reinterpret_cast<T*>(P.dq) + ((long long)b * P.T + qi) * P.ld_d + h * DH + 4 * g;
-#pragma unroll
-        for (int db = 0; db < 4; ++db) store4<T>(dqp + 16 * db, dq[db][0] * P.dscale, dq[db][1] * P.dscale, dq[db][2] * P.dscale, dq[db][3] * P.dscale);
-    }
 }
 
 void set_softmax_params(AttnP& P, float scale, float p, uint32_t seed) {
@@ -508,6 +593,22 @@ int check_common(const char* what, int dtype, int B, int T_, int H, long long ld
     return A8_OK;
 }
 
+// launch geometry (a8_set_tuning keys 2 = forward, 3 = dK/dV, 4 = dQ): value = waves_per_block * 10 + row groups per wave
+#define A8_ATTN_LAUNCH(KERN, key, what)                                                                                       \
+    {                                                                                                                          \
+        const int geo = g_a8_tuning[key], nw = geo / 10, grp = geo % 10, rows = nw * grp * 16;                                 \
+        const dim3 grid(cdiv(T_, rows) * B * H), blk(nw * 64);                                                                 \
+        if (dtype == A8_BF16) {                                                                                                \
+            if (geo == 41) hipLaunchKernelGGL((KERN<bf16, 4, 1>), grid, blk, 0, s, P);                                        \
+            else if (geo == 22) hipLaunchKernelGGL((KERN<bf16, 2, 2>), grid, blk, 0, s, P);                                   \
+            else if (geo == 42) hipLaunchKernelGGL((KERN<bf16, 4, 2>), grid, blk, 0, s, P);                                   \
+            else return a8_set_error(A8_ERR_ARG, "%s: bad tuning %d", what, geo);                                             \
+        } else {                                                                                                               \
+            const dim3 grid1(cdiv(T_, 64) * B * H);                                                                            \
+            hipLaunchKernelGGL((KERN<float, 4, 1>), grid1, dim3(256), 0, s, P);                                               \
+        }                                                                                                                      \
+    }
+
 }  // namespace
 
 extern "C" int a8_attn_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* keymask,
@@ -517,9 +618,8 @@ extern "C" int a8_attn_fwd(int dtype, const void* q, const void* k, const void* 
     P.q = (const char*)q; P.k = (const char*)k; P.v = (const char*)v; P.out = (char*)o; P.lse = lse; P.keymask = keymask;
     P.B = B; P.T = T_; P.H = H; P.ld_qkv = ld_qkv; P.ld_o = ld_o;
     set_softmax_params(P, scale, p, seed);
-    const dim3 grid(cdiv(T_, BT) * B * H);
-    if (dtype == A8_BF16) hipLaunchKernelGGL(attn_fwd_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, P);
-    else hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, P);
+    hipStream_t s = (hipStream_t)stream;
+    A8_ATTN_LAUNCH(attn_fwd_kernel, 2, "a8_attn_fwd")
     return a8_check_launch("a8_attn_fwd");
 }
 
@@ -535,15 +635,9 @@ extern "C" int a8_attn_bwd(int dtype, const void* q, const void* k, const void* 
     set_softmax_params(P, scale, p, seed);
     hipStream_t s = (hipStream_t)stream;
     const long long nrow = (long long)B * T_ * H;
-    const dim3 grid(cdiv(T_, BT) * B * H);
-    if (dtype == A8_BF16) {
-        hipLaunchKernelGGL(attn_delta_kernel<bf16>, dim3(cdiv(nrow * 8, 256)), dim3(256), 0, s, P);
-        hipLaunchKernelGGL(attn_bwd_kv_kernel<bf16>, grid, dim3(256), 0, s, P);
-        hipLaunchKernelGGL(attn_bwd_q_kernel<bf16>, grid, dim3(256), 0, s, P);
-    } else {
-        hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(cdiv(nrow * 8, 256)), dim3(256), 0, s, P);
-        hipLaunchKernelGGL(attn_bwd_kv_kernel<float>, grid, dim3(256), 0, s, P);
-        hipLaunchKernelGGL(attn_bwd_q_kernel<float>, grid, dim3(256), 0, s, P);
-    }
+    if (dtype == A8_BF16) hipLaunchKernelGGL(attn_delta_kernel<bf16>, dim3(cdiv(nrow * 8, 256)), dim3(256), 0, s, P);
+    else hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(cdiv(nrow * 8, 256)), dim3(256), 0, s, P);
+    A8_ATTN_LAUNCH(attn_bwd_kv_kernel, 3, "a8_attn_bwd")
+    A8_ATTN_LAUNCH(attn_bwd_q_kernel, 4, "a8_attn_bwd")
     return a8_check_launch("a8_attn_bwd");
 }

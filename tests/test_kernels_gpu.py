@@ -224,9 +224,23 @@ def _attn_ref(q, k, v, keymask, scale, drop_keep=None, p=0.0):
     return torch.matmul(a, v)
 
 
+@pytest.fixture(params=[41, 22, 42])
+def attn_geometry(request):
+    """Launch geometry of the three attention kernels (waves per block * 10 + 16-row groups per wave)."""
+    from audio8_amd import _lib as L
+    for key in (2, 3, 4):
+        L.check(L.lib().a8_set_tuning(key, request.param), "a8_set_tuning")
+    yield request.param
+    for key, v in ((2, ATTN_DEFAULT[0]), (3, ATTN_DEFAULT[1]), (4, ATTN_DEFAULT[2])):
+        L.check(L.lib().a8_set_tuning(key, v), "a8_set_tuning")
+
+
+ATTN_DEFAULT = (41, 41, 41)
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("T,use_mask", [(64, False), (100, True), (333, False)])
-def test_attention_fwd_bwd(dtype, T, use_mask):
+def test_attention_fwd_bwd(dtype, T, use_mask, attn_geometry):
     from audio8_amd import kernels as K
     B, H = 2, 3
     d = H * 64
@@ -299,7 +313,7 @@ def _extract_keep(K, B, H, T, p, seed, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
-def test_attention_dropout_multi_tile(dtype):
+def test_attention_dropout_multi_tile(dtype, attn_geometry):
     """Several key/query tiles with a tail (T = 200): forward and both backward kernels must regenerate the same
     keep-mask from the running hash sums."""
     from audio8_amd import kernels as K
@@ -327,7 +341,7 @@ def test_attention_dropout_multi_tile(dtype):
     close(dv.reshape(B, T, H, 64), v.grad.permute(0, 2, 1, 3), tolb, "attn dv (dropout)")
 
 
-def test_attention_running_max_rescale():
+def test_attention_running_max_rescale(attn_geometry):
     """Scores that grow from key tile to key tile by far more than the lazy-rescale margin (and, for other rows,
     by less than it): the deferred max update must give the exact softmax."""
     from audio8_amd import kernels as K

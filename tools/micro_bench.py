@@ -43,22 +43,44 @@ def main():
 
 
 def attention():
+    from audio8_amd import _lib as L
     d = "cuda"
     B, T, H = 8, 781, 12
     dm = H * 64
     bf = torch.bfloat16
     qkv = (torch.randn(B * T, 3 * dm, device=d) * 0.5).to(bf)
     dout = torch.randn(B * T, dm, device=d).to(bf)
-    for p in (0.0, 0.1):
-        o, lse = K.attn_fwd(qkv[:, :dm], qkv[:, dm:2 * dm], qkv[:, 2 * dm:], B, T, H, 3 * dm, 0.125, None, p=p, seed=3)
-        tf = timeit(lambda: K.attn_fwd(qkv[:, :dm], qkv[:, dm:2 * dm], qkv[:, 2 * dm:], B, T, H, 3 * dm, 0.125, None, p=p, seed=3))
-        dq = torch.empty(B * T, 3 * dm, device=d, dtype=bf)
-        tb = timeit(lambda: K.attn_bwd(qkv[:, :dm], qkv[:, dm:2 * dm], qkv[:, 2 * dm:], o, dout, lse, B, T, H, 3 * dm, 0.125, None, p=p, seed=3, dqkv=dq))
-        gf = 4.0 * B * H * T * T * 64 / 1e9
-        print(f"attention p={p}: fwd {tf:.1f} us ({gf / tf * 1e3:.0f} TFLOP/s)  bwd (delta+kv+q) {tb:.1f} us ({2.5 * gf / tb * 1e3:.0f} TFLOP/s algorithmic)")
+    gf = 4.0 * B * H * T * T * 64 / 1e9
+    p = 0.1
+    o, lse = K.attn_fwd(qkv[:, :dm], qkv[:, dm:2 * dm], qkv[:, 2 * dm:], B, T, H, 3 * dm, 0.125, None, p=p, seed=3)
+    dq = torch.empty(B * T, 3 * dm, device=d, dtype=bf)
+    for rnd in range(2):
+        for geo in (41, 22, 42):
+            L.check(L.lib().a8_set_tuning(2, geo), "tune")
+            tf = timeit(lambda: K.attn_fwd(qkv[:, :dm], qkv[:, dm:2 * dm], qkv[:, 2 * dm:], B, T, H, 3 * dm, 0.125, None, p=p, seed=3))
+            res = [f"fwd {tf:.1f} us ({gf / tf * 1e3:.0f} TF/s)"]
+            for key, name in ((3, "dkv"), (4, "dq")):
+                other = 4 if key == 3 else 3
+                L.check(L.lib().a8_set_tuning(key, geo), "tune")
+                L.check(L.lib().a8_set_tuning(other, 41), "tune")
+                tb = timeit(lambda: K.attn_bwd(qkv[:, :dm], qkv[:, dm:2 * dm], qkv[:, 2 * dm:], o, dout, lse, B, T, H, 3 * dm, 0.125, None, p=p, seed=3, dqkv=dq))
+                res.append(f"bwd with {name}={geo}, other=41: {tb:.1f} us")
+            print(f"round {rnd} geometry {geo}: " + "; ".join(res))
+    for key in (2, 3, 4):
+        L.check(L.lib().a8_set_tuning(key, 41), "tune")
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "attn1":        # a few launches for counter collection
+        B, T, H = 8, 781, 12
+        dm = H * 64
+        qkv = (torch.randn(B * T, 3 * dm, device="cuda") * 0.5).to(torch.bfloat16)
+        dout = torch.randn(B * T, dm, device="cuda").to(torch.bfloat16)
+        for _ in range(3):
+            o, lse = K.attn_fwd(qkv[:, :dm], qkv[:, dm:2 * dm], qkv[:, 2 * dm:], B, T, H, 3 * dm, 0.125, None, p=0.1, seed=3)
+            K.attn_bwd(qkv[:, :dm], qkv[:, dm:2 * dm], qkv[:, 2 * dm:], o, dout, lse, B, T, H, 3 * dm, 0.125, None, p=0.1, seed=3)
+        torch.cuda.synchronize()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "attn":
         attention()
         sys.exit(0)
