@@ -26,12 +26,26 @@ int a8_check_launch(const char* what);
 #define A8_REQUIRE(cond, ...) do { if (!(cond)) return a8_set_error(A8_ERR_ARG, __VA_ARGS__); } while (0)
 
 // ---------------------------------------------------------------- small math
-A8_DEV float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// Exact (erf) GELU without erff: Phi(x) = 0.5 erfc(-x / sqrt 2), with log2 erfc(|x| / sqrt 2) as a degree-7
+// polynomial (weighted least-squares fit on [0, 5.75], exact 0 at 0) -- branch-free, one v_exp_f32.
+// Max abs error vs float64 over [-8, 8]: Phi 1.2e-7, gelu 7.7e-7 (torch's own f32 GELU: 1.4e-6), gelu' 1.7e-7.
+A8_DEV float norm_cdf_f(float x) {
+    const float t = fminf(fabsf(x), 5.75f);
+    float r = 8.510881681e-06f;
+    r = fmaf(r, t, -5.449422293e-05f);
+    r = fmaf(r, t, -4.180608761e-04f);
+    r = fmaf(r, t, 7.381212995e-03f);
+    r = fmaf(r, t, -5.268092407e-02f);
+    r = fmaf(r, t, -4.591593132e-01f);
+    r = fmaf(r, t, -1.151109407e+00f);
+    const float e = __builtin_amdgcn_exp2f(r * t);       // erfc(|x| / sqrt 2) in (8e-9, 1]
+    return 0.5f + copysignf(fmaf(-0.5f, e, 0.5f), x);
+}
+A8_DEV float gelu_f(float x) { return x * norm_cdf_f(x); }
 A8_DEV float gelu_grad_f(float x) {
     // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
+    const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);
+    return fmaf(x, pdf, norm_cdf_f(x));
 }
 
 template <typename T> A8_DEV float to_f(T v) { return (float)v; }

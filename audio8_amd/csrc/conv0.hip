@@ -6,7 +6,8 @@
 // the waveform (1 MB per utterance, LDS-staged, coalesced along the sample axis):
 //   forward  : stats pass (no output)  ->  finalize (mean, rstd per (b,c), f64)  ->  apply pass writes
 //              gelu(gn(conv(x))) once, channels-last [B, L0, 512], 16 B per lane.
-//   backward : reduce pass (sum dU, sum dU*xhat per (b,c))  ->  weight-grad pass; both read only dout.
+//   backward : ONE pass over dout accumulating per-(b,c) sums from which a tiny finalize kernel assembles
+//              dw / dgamma / dbeta (the GroupNorm mean terms factor through channel-free waveform moments).
 // Lane = 8 consecutive channels, wave = a stripe of frames; the frame's 10 samples are a wave-uniform
 // (broadcast) LDS read; per-(b,c) sums are kept in registers and combined across the 4 waves in LDS.
 #include "a8_common.h"
@@ -138,18 +139,33 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restric
     }
 }
 
-// ---- backward pass 1: red[b][c] = (sum_t dU, sum_t dU * xhat), dU = dout * gelu'(u)
-constexpr int CHB = 1024;
+// ---- backward: ONE pass over dout.
+// With u = gamma*xh + beta, xh = (conv - mean)*rstd, dU = dout*gelu'(u), the GroupNorm backward is
+//   dV = rstd*gamma*(dU - m1 - xh*m2),  m1 = mean_t dU, m2 = mean_t dU*xh,      dw[c][k] = sum_t dV[t] x[5t+k]
+// and the sum splits into pieces that do not need m1, m2 in advance:
+//   dw[c][k] = rstd*gamma*( A[c][k] - m1*S[k] - m2*C[c][k] ),
+//   A[c][k] = sum_t dU x[5t+k]                      (accumulated here, per (b,c))
+//   S[k]    = sum_t x[5t+k],  R[j][k] = sum_t x[5t+j] x[5t+k]     (waveform only, channel-free, f64)
+//   C[c][k] = sum_t xh x[5t+k] = rstd*( sum_j w[c][j] R[j][k] - mean*S[k] )
+// so dout (the 0.4 GB tensor) is read once; a finalize kernel over [B,512,10] assembles dw, dgamma, dbeta.
+constexpr int CHB = 784;          // frames per block: 8 x 64 blocks x 4 waves = 2 waves per SIMD at 8 x 250k samples
+constexpr int NACC = 2 + KW;      // per (b,c): s1, s2, A[0..9]
+constexpr int NXR = KW + KW * (KW + 1) / 2;     // per b: S[10], then the upper triangle of R row by row (f64)
+A8_DEV int tri(int j, int k) { return KW + j * KW - j * (j - 1) / 2 + (k - j); }     // j <= k
+
 template <typename T>
-__global__ __launch_bounds__(256) void conv0_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ wg,
-                                                               const float* __restrict__ gn_w, const float* __restrict__ gn_b,
-                                                               const float* __restrict__ stats, const T* __restrict__ dout,
-                                                               float* __restrict__ red, int L, int L0) {
+__global__ __launch_bounds__(256) void conv0_bwd_main_kernel(const float* __restrict__ x, const float* __restrict__ wg,
+                                                             const float* __restrict__ gn_w, const float* __restrict__ gn_b,
+                                                             const float* __restrict__ stats, const T* __restrict__ dout,
+                                                             float* __restrict__ acc, double* __restrict__ xr, int L, int L0) {
     __shared__ float xs[ST * CHB + 8];
-    __shared__ float rr[4][CC][2];
+    __shared__ float acc_s[CC * NACC];
+    __shared__ float xr_s[NXR];
     const int b = blockIdx.y, t0 = blockIdx.x * CHB;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c0 = lane * 8;
     stage_x<CHB>(xs, x + (long long)b * L, t0, L);
+    for (int i = threadIdx.x; i < CC * NACC; i += 256) acc_s[i] = 0.f;
+    if (threadIdx.x < NXR) xr_s[threadIdx.x] = 0.f;
     float w[8][KW], mu[8], rs[8], gw[8], gb[8];
     load_w(w, wg, c0);
 #pragma unroll
@@ -160,10 +176,38 @@ __global__ __launch_bounds__(256) void conv0_bwd_reduce_kernel(const float* __re
         gb[j] = gn_b[c0 + j];
     }
     __syncthreads();
-    float s1[8], s2[8];
+    const int nfr = min(CHB, L0 - t0);
+    {   // waveform moments of this chunk: thread-strided frames, LDS atomics (65 values)
+        float sx[KW], rx[KW * (KW + 1) / 2];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-    for (int tl = wv; tl < CHB && t0 + tl < L0; tl += 4) {
+        for (int k = 0; k < KW; ++k) sx[k] = 0.f;
+#pragma unroll
+        for (int i = 0; i < KW * (KW + 1) / 2; ++i) rx[i] = 0.f;
+        for (int tl = threadIdx.x; tl < nfr; tl += 256) {
+            float xv[KW];
+#pragma unroll
+            for (int k = 0; k < KW; ++k) xv[k] = xs[ST * tl + k];
+            int n = 0;
+#pragma unroll
+            for (int j = 0; j < KW; ++j) {
+                sx[j] += xv[j];
+#pragma unroll
+                for (int k = j; k < KW; ++k) { rx[n] = fmaf(xv[j], xv[k], rx[n]); ++n; }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KW; ++k) { const float t = wave_sum(sx[k]); if (lane == 0) atomicAdd(&xr_s[k], t); }
+#pragma unroll
+        for (int i = 0; i < KW * (KW + 1) / 2; ++i) { const float t = wave_sum(rx[i]); if (lane == 0) atomicAdd(&xr_s[KW + i], t); }
+    }
+    float s1[8], s2[8], a[8][KW];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        s1[j] = 0.f; s2[j] = 0.f;
+#pragma unroll
+        for (int k = 0; k < KW; ++k) a[j][k] = 0.f;
+    }
+    for (int tl = wv; tl < nfr; tl += 4) {
         float v[8], xv[KW], g[8];
         conv_frame(xs, tl, w, v, xv);
         ld8(dout + ((long long)b * L0 + t0 + tl) * CC + c0, g);
@@ -173,80 +217,59 @@ __global__ __launch_bounds__(256) void conv0_bwd_reduce_kernel(const float* __re
             const float du = g[j] * gelu_grad_f(fmaf(xh, gw[j], gb[j]));
             s1[j] += du;
             s2[j] = fmaf(du, xh, s2[j]);
+#pragma unroll
+            for (int k = 0; k < KW; ++k) a[j][k] = fmaf(du, xv[k], a[j][k]);
         }
     }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { rr[wv][c0 + j][0] = s1[j]; rr[wv][c0 + j][1] = s2[j]; }
-    __syncthreads();
-    for (int i = threadIdx.x; i < CC * 2; i += 256) {
-        const int c = i >> 1, h = i & 1;
-        atomicAdd(red + ((long long)b * CC + c) * 2 + h, rr[0][c][h] + rr[1][c][h] + rr[2][c][h] + rr[3][c][h]);
-    }
-}
-
-// ---- backward pass 1.5: dgn_b[c] += sum_b s1, dgn_w[c] += sum_b s2
-__global__ void conv0_bwd_affine_kernel(const float* __restrict__ red, float* __restrict__ dgn_w, float* __restrict__ dgn_b, int B) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= CC) return;
-    float a = 0.f, bsum = 0.f;
-    for (int b = 0; b < B; ++b) { bsum += red[((long long)b * CC + c) * 2]; a += red[((long long)b * CC + c) * 2 + 1]; }
-    dgn_w[c] += a;
-    dgn_b[c] += bsum;
-}
-
-// ---- backward pass 2: dV = rstd*gamma*(dU - mean(dU) - xhat*mean(dU*xhat)); dw[c][k] += sum_t dV x[5t+k]
-template <typename T>
-__global__ __launch_bounds__(256) void conv0_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ wg,
-                                                           const float* __restrict__ gn_w, const float* __restrict__ gn_b,
-                                                           const float* __restrict__ stats, const T* __restrict__ dout,
-                                                           const float* __restrict__ red, float* __restrict__ dw, int L, int L0) {
-    __shared__ float xs[ST * CHB + 8];
-    __shared__ float acc_s[CC * KW];
-    const int b = blockIdx.y, t0 = blockIdx.x * CHB;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c0 = lane * 8;
-    stage_x<CHB>(xs, x + (long long)b * L, t0, L);
-    for (int i = threadIdx.x; i < CC * KW; i += 256) acc_s[i] = 0.f;
-    float w[8][KW], mu[8], rs[8], gw[8], gb[8], m1[8], m2[8];
-    load_w(w, wg, c0);
-    const float invL = 1.0f / (float)L0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        mu[j] = stats[((long long)b * CC + c0 + j) * 2];
-        rs[j] = stats[((long long)b * CC + c0 + j) * 2 + 1];
-        gw[j] = gn_w[c0 + j];
-        gb[j] = gn_b[c0 + j];
-        m1[j] = red[((long long)b * CC + c0 + j) * 2] * invL;
-        m2[j] = red[((long long)b * CC + c0 + j) * 2 + 1] * invL;
+        float* p = acc_s + (c0 + j) * NACC;
+        atomicAdd(p, s1[j]);
+        atomicAdd(p + 1, s2[j]);
+#pragma unroll
+        for (int k = 0; k < KW; ++k) atomicAdd(p + 2 + k, a[j][k]);
     }
     __syncthreads();
-    float a[8][KW];
+    float* ga = acc + (long long)b * CC * NACC;
+    for (int i = threadIdx.x; i < CC * NACC; i += 256) atomicAdd(ga + i, acc_s[i]);
+    if (threadIdx.x < NXR) atomicAdd(xr + (long long)b * NXR + threadIdx.x, (double)xr_s[threadIdx.x]);
+}
+
+// ---- finalize: dw[c][k] += sum_b rstd*gamma*(A - m1*S - m2*C); dgn_w[c] += sum_b s2; dgn_b[c] += sum_b s1
+__global__ void conv0_bwd_finalize_kernel(const float* __restrict__ wg, const float* __restrict__ gn_w, const float* __restrict__ stats,
+                                          const float* __restrict__ acc, const double* __restrict__ xr,
+                                          float* __restrict__ dw, float* __restrict__ dgn_w, float* __restrict__ dgn_b, int B, int L0) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= CC) return;
+    float wc[KW];
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
+    for (int k = 0; k < KW; ++k) wc[k] = wg[c * KW + k];
+    const double invL = 1.0 / (double)L0;
+    double dwk[KW];
 #pragma unroll
-        for (int k = 0; k < KW; ++k) a[j][k] = 0.f;
-    for (int tl = wv; tl < CHB && t0 + tl < L0; tl += 4) {
-        float v[8], xv[KW], g[8];
-        conv_frame(xs, tl, w, v, xv);
-        ld8(dout + ((long long)b * L0 + t0 + tl) * CC + c0, g);
+    for (int k = 0; k < KW; ++k) dwk[k] = 0.0;
+    double dgw = 0.0, dgb = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const float* ab = acc + ((long long)b * CC + c) * NACC;
+        const double* xb = xr + (long long)b * NXR;
+        const double mu = stats[((long long)b * CC + c) * 2], rs = stats[((long long)b * CC + c) * 2 + 1];
+        const double s1 = ab[0], s2 = ab[1], m1 = s1 * invL, m2 = s2 * invL;
+        dgb += s1;
+        dgw += s2;
+        const double f = rs * (double)gn_w[c];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float xh = (v[j] - mu[j]) * rs[j];
-            const float du = g[j] * gelu_grad_f(fmaf(xh, gw[j], gb[j]));
-            const float dv = rs[j] * gw[j] * (du - m1[j] - xh * m2[j]);
+        for (int k = 0; k < KW; ++k) {
+            double wr = 0.0;
 #pragma unroll
-            for (int k = 0; k < KW; ++k) a[j][k] = fmaf(dv, xv[k], a[j][k]);
+            for (int j = 0; j < KW; ++j) wr += (double)wc[j] * xb[j <= k ? tri(j, k) : tri(k, j)];
+            const double ck = rs * (wr - mu * xb[k]);
+            dwk[k] += f * ((double)ab[2 + k] - m1 * xb[k] - m2 * ck);
         }
     }
-    for (int ww = 0; ww < 4; ++ww) {
-        if (wv == ww) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-#pragma unroll
-                for (int k = 0; k < KW; ++k) acc_s[(c0 + j) * KW + k] += a[j][k];
-        }
-        __syncthreads();
-    }
-    for (int i = threadIdx.x; i < CC * KW; i += 256) atomicAdd(dw + i, acc_s[i]);
+    for (int k = 0; k < KW; ++k) dw[c * KW + k] += (float)dwk[k];
+    dgn_w[c] += (float)dgw;
+    dgn_b[c] += (float)dgb;
 }
 
 }  // namespace
@@ -275,17 +298,19 @@ extern "C" int a8_conv0_gn_gelu_bwd(int dtype, const float* x, const float* w, c
     A8_REQUIRE(C_ == CC, "a8_conv0_gn_gelu_bwd: C must be %d (got %d)", CC, C_);
     A8_REQUIRE(L >= KW && B >= 1, "a8_conv0_gn_gelu_bwd: bad B=%d L=%d", B, L);
     A8_REQUIRE(dtype == A8_F32 || dtype == A8_BF16, "a8_conv0_gn_gelu_bwd: bad dtype");
+    A8_REQUIRE(((uintptr_t)red % 8) == 0, "a8_conv0_gn_gelu_bwd: scratch must be 8-byte aligned");
     const int L0 = conv0_out_len(L), nchunk = cdiv(L0, CHB);
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(red, 0, sizeof(float) * 2 * B * CC, s) != hipSuccess) return a8_set_error(A8_ERR_LAUNCH, "a8_conv0_gn_gelu_bwd: memset failed");
-    if (dtype == A8_BF16) {
-        hipLaunchKernelGGL(conv0_bwd_reduce_kernel<bf16>, dim3(nchunk, B), dim3(256), 0, s, x, w, gn_w, gn_b, stats, (const bf16*)dout, red, L, L0);
-        hipLaunchKernelGGL(conv0_bwd_affine_kernel, dim3(2), dim3(256), 0, s, red, dgn_w, dgn_b, B);
-        hipLaunchKernelGGL(conv0_bwd_dw_kernel<bf16>, dim3(nchunk, B), dim3(256), 0, s, x, w, gn_w, gn_b, stats, (const bf16*)dout, red, dw, L, L0);
-    } else {
-        hipLaunchKernelGGL(conv0_bwd_reduce_kernel<float>, dim3(nchunk, B), dim3(256), 0, s, x, w, gn_w, gn_b, stats, (const float*)dout, red, L, L0);
-        hipLaunchKernelGGL(conv0_bwd_affine_kernel, dim3(2), dim3(256), 0, s, red, dgn_w, dgn_b, B);
-        hipLaunchKernelGGL(conv0_bwd_dw_kernel<float>, dim3(nchunk, B), dim3(256), 0, s, x, w, gn_w, gn_b, stats, (const float*)dout, red, dw, L, L0);
-    }
+    // scratch layout: f64 xr[B][NXR] | f32 acc[B][C][NACC]   (A8_CONV0_BWD_SCRATCH_FLOATS(B) floats in all)
+    double* xr = reinterpret_cast<double*>(red);
+    float* acc = red + 2 * (size_t)B * NXR;
+    static_assert(NXR == 65 && NACC == 12, "keep A8_CONV0_BWD_SCRATCH_FLOATS in a8hip.h in sync");
+    if (hipMemsetAsync(red, 0, sizeof(float) * A8_CONV0_BWD_SCRATCH_FLOATS(B), s) != hipSuccess)
+        return a8_set_error(A8_ERR_LAUNCH, "a8_conv0_gn_gelu_bwd: memset failed");
+    if (dtype == A8_BF16)
+        hipLaunchKernelGGL(conv0_bwd_main_kernel<bf16>, dim3(nchunk, B), dim3(256), 0, s, x, w, gn_w, gn_b, stats, (const bf16*)dout, acc, xr, L, L0);
+    else
+        hipLaunchKernelGGL(conv0_bwd_main_kernel<float>, dim3(nchunk, B), dim3(256), 0, s, x, w, gn_w, gn_b, stats, (const float*)dout, acc, xr, L, L0);
+    hipLaunchKernelGGL(conv0_bwd_finalize_kernel, dim3(cdiv(CC, 64)), dim3(64), 0, s, w, gn_w, stats, acc, xr, dw, dgn_w, dgn_b, B, L0);
     return a8_check_launch("a8_conv0_gn_gelu_bwd");
 }

@@ -104,7 +104,7 @@ def conv0_gn_gelu_bwd(x, w, gn_w, gn_b, stats, dout, dw, dgn_w, dgn_b):
     L.require_cuda(x, dout, dw)
     B, Ls = x.shape
     Cn = w.shape[0]
-    red = torch.empty((B, Cn, 2), device=x.device, dtype=torch.float32)
+    red = torch.empty((B * (2 * 65 + 512 * 12),), device=x.device, dtype=torch.float32)     # A8_CONV0_BWD_SCRATCH_FLOATS(B)
     L.check(L.lib().a8_conv0_gn_gelu_bwd(L.dt(dout), L.ptr(_c(x)), L.ptr(_c(w)), L.ptr(gn_w), L.ptr(gn_b), L.ptr(stats), L.ptr(_c(dout)),
                                          L.ptr(dw), L.ptr(dgn_w), L.ptr(dgn_b), L.ptr(red), B, Ls, Cn, L.stream()), "a8_conv0_gn_gelu_bwd")
 

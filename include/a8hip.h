@@ -70,7 +70,8 @@ int a8_prepare_weights_device(int dtype, const a8_wprep_desc* descs_dev, const i
 int a8_conv0_gn_gelu_fwd(int dtype, const float* x, const float* w, const float* gn_w, const float* gn_b,
                          void* out, float* stats, float* part, int B, int L, int C, float eps, void* stream);
 /* backward: dout dtype [B,L0,C] -> dw f32 [C,10], dgn_w, dgn_b f32 [C] (all accumulated, +=).
- * red is scratch f32 [B,C,2] (zeroed by the call). */
+ * red is scratch of A8_CONV0_BWD_SCRATCH_FLOATS(B) floats, 8-byte aligned (zeroed by the call). */
+#define A8_CONV0_BWD_SCRATCH_FLOATS(B) ((size_t)(B) * (2 * 65 + 512 * 12))
 int a8_conv0_gn_gelu_bwd(int dtype, const float* x, const float* w, const float* gn_w, const float* gn_b,
                          const float* stats, const void* dout, float* dw, float* dgn_w, float* dgn_b,
                          float* red, int B, int L, int C, void* stream);
