@@ -23,6 +23,7 @@ _dev_index = None
 ARGTYPES = {
     "a8_version": [],
     "a8_gemm": [C.c_void_p, C.c_void_p],
+    "a8_gemm_grouped": [C.c_void_p, C.c_int, C.c_void_p],
     "a8_set_tuning": [C.c_int, C.c_int],
     "a8_prepare_weights": [C.c_int, C.c_void_p, C.c_int, C.c_void_p],
     "a8_prepare_weights_device": [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p],
@@ -30,7 +31,7 @@ ARGTYPES = {
     "a8_conv0_gn_gelu_bwd": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "a8_col2im_gelu_grad": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "a8_layernorm_fwd": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_void_p],
-    "a8_layernorm_bwd": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_uint32, C.c_uint32, C.c_void_p],
+    "a8_layernorm_bwd": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_uint32, C.c_uint32, C.c_void_p],
     "a8_cast": [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
     "a8_dropout": [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_uint32, C.c_uint32, C.c_void_p],
     "a8_mask_fill_rows": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p],
@@ -71,6 +72,7 @@ class GemmDesc(C.Structure):
         ("zin", C.c_void_p), ("zout", C.c_void_p), ("ldz", C.c_int64), ("z_rpb", C.c_int64), ("z_bs", C.c_int64),
         ("out_f32", C.c_int), ("accumulate", C.c_int), ("splitk", C.c_int),
         ("alpha", C.c_float),
+        ("colsum", C.c_void_p),
     ]
 
 
@@ -130,7 +132,7 @@ def require_cuda(*ts):
 
 
 EXPORTS = [
-    "a8_version", "a8_last_error", "a8_gemm", "a8_set_tuning", "a8_prepare_weights", "a8_prepare_weights_device",
+    "a8_version", "a8_last_error", "a8_gemm", "a8_gemm_grouped", "a8_set_tuning", "a8_prepare_weights", "a8_prepare_weights_device",
     "a8_conv0_gn_gelu_fwd", "a8_conv0_gn_gelu_bwd", "a8_col2im_gelu_grad",
     "a8_layernorm_fwd", "a8_layernorm_bwd",
     "a8_cast", "a8_dropout", "a8_mask_fill_rows", "a8_mask_fill_rows_bwd", "a8_mask_zero_cols", "a8_zero_rows",

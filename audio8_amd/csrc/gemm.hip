@@ -7,9 +7,12 @@
 // An operand that is K-strided in memory ("KS") is staged [k][row] in LDS and read with
 // ds_read_b64_tr_b16 (bf16) so no operand is ever transposed through HBM.
 //
-// Block = 256 threads = 4 waves (2x2), tile 128x128, k-tile = 64 bytes of K per row (32 bf16 / 16 f32), staged
-// by LDS-DMA (global_load_lds) into a 4-deep LDS ring: three k-tiles are in flight per block behind a counted
-// s_waitcnt vmcnt and one raw s_barrier per k-tile (the K = 768 projections are latency-bound otherwise).
+// Block = 512 threads = 8 waves (4 along M x 2 along N, each 32x64 of the 128x128 tile; 4 waves per SIMD at two
+// blocks per CU hide the LDS / DMA latencies).  A k-tile = 128 bytes of K per row (64 bf16), staged by LDS-DMA
+// (global_load_lds, 16 B per lane) into a 2-deep LDS ring behind a counted s_waitcnt vmcnt and ONE raw s_barrier
+// per k-tile; every fragment read of a k-tile is issued ahead of its MFMAs.  (f32: 64-byte rows, 4-deep ring, 4 waves.)
+// a8_gemm_grouped runs several independent problems of one layout in ONE launch (the four weight-gradient GEMMs
+// of an encoder layer: 432 tiles fill the chip without split-K, where each alone needs 3-12 way split-K + atomics).
 // "Row remap": an operand's outer index o maps to (o / rpb) * bs + (o % rpb) * ld, which lets the
 // strided conv layers run as plain GEMMs over overlapping rows of a channels-last activation
 // (row t of utterance b starts at b*Lin*C + t*stride*C and is k*C long).
@@ -24,6 +27,7 @@ struct GemmArgs {
     char* C; long long ldc, c_rpb, c_bs;
     const char* zin; char* zout; long long ldz, z_rpb, z_bs;
     const float* bias;
+    float* colsum;
     int M, N, K, kchunk, nsplit, tiles_m, tiles_n;
     int act, out_f32, atomic, bias_rows;
     float alpha;
@@ -94,7 +98,7 @@ template <int KB> struct StageTile<float, KB> {
 // Main loop: NST-deep ring of LDS stages filled by LDS-DMA (global_load_lds, 16 B per lane), NST-1 k-tiles in
 // flight per block; one raw s_barrier and one counted s_waitcnt vmcnt per k-tile; no register staging.
 template <typename T, bool AKS, bool BKS, int KB, int NST, int NWM>
-__global__ __launch_bounds__(128 * NWM, (NST * 2 * 8192 * KB <= 65536) ? NWM : NWM / 2) void gemm_kernel(const GemmArgs g) {
+A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
     typedef StageTile<T, KB> ST;
     typedef KcGeom<KB> G;
     typedef Mma<T> MM;
@@ -107,8 +111,6 @@ __global__ __launch_bounds__(128 * NWM, (NST * 2 * 8192 * KB <= 65536) ? NWM : N
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = w >> 1, wn = w & 1;            // wm in [0, NWM)
-    const int nblk = g.tiles_m * g.tiles_n * g.nsplit;
-    const int bid = xcd_remap(blockIdx.x, nblk);
     const int split = bid / (g.tiles_m * g.tiles_n);
     const int tile = bid - split * (g.tiles_m * g.tiles_n);
     // grouped tile order: consecutive ids (= one XCD's co-resident blocks) cover GROUP_M m-tiles x several n-tiles, so
@@ -282,6 +284,7 @@ __global__ __launch_bounds__(128 * NWM, (NST * 2 * 8192 * KB <= 65536) ? NWM : N
         const int n = nw + lane;
         const bool n_ok = n < g.N;
         const float bn = (g.bias && !g.bias_rows && n_ok) ? g.bias[n] : 0.f;
+        float csum = 0.f;
         for (int rr = 0; rr < WROWS; ++rr) {
             const int m = mw + rr;
             if (m >= g.M) break;
@@ -295,7 +298,9 @@ __global__ __launch_bounds__(128 * NWM, (NST * 2 * 8192 * KB <= 65536) ? NWM : N
             float* cp = reinterpret_cast<float*>(g.C) + crow + n;
             if (g.atomic) atomicAdd(cp, v);
             else *cp = v;
+            csum += v;
         }
+        if (g.colsum && n_ok) atomicAdd(g.colsum + n, csum);
     } else {
         // 16-bit output: lane owns 8 consecutive columns (16 B), a wave-instruction covers 8 rows x 128 B
         const int c8 = (lane & 7) << 3;                 // first column within the wave's 64
@@ -305,6 +310,7 @@ __global__ __launch_bounds__(128 * NWM, (NST * 2 * 8192 * KB <= 65536) ? NWM : N
 #pragma unroll
         for (int e = 0; e < 8; ++e) bn[e] = (g.bias && !g.bias_rows && n_ok) ? g.bias[n + e] : 0.f;
         typedef T T8 __attribute__((ext_vector_type(8)));
+        float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (int it = 0; it < WROWS / 8; ++it) {
             if (mw + 8 * it >= g.M) break;
             const int rr = 8 * it + (lane >> 3);
@@ -334,10 +340,41 @@ __global__ __launch_bounds__(128 * NWM, (NST * 2 * 8192 * KB <= 65536) ? NWM : N
             const long long crow = g.c_rpb ? (m / g.c_rpb) * g.c_bs + (m % g.c_rpb) * g.ldc : (long long)m * g.ldc;
             T8 ov;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) ov[e] = from_f<T>(v[e]);
+            for (int e = 0; e < 8; ++e) { ov[e] = from_f<T>(v[e]); csum[e] += v[e]; }
             *reinterpret_cast<T8*>(reinterpret_cast<T*>(g.C) + crow + n) = ov;
         }
+        if (g.colsum) {                                  // block-uniform; lanes l, l+8, .. l+56 hold the same 8 columns
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t = csum[e];
+                t += __shfl_xor(t, 8, 64);
+                t += __shfl_xor(t, 16, 64);
+                t += __shfl_xor(t, 32, 64);
+                csum[e] = t;
+            }
+            if (lane < 8 && n_ok) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) atomicAdd(g.colsum + n + e, csum[e]);
+            }
+        }
     }
+}
+
+template <typename T, bool AKS, bool BKS, int KB, int NST, int NWM>
+__global__ __launch_bounds__(128 * NWM, (NST * 2 * 8192 * KB <= 65536) ? NWM : NWM / 2) void gemm_kernel(const GemmArgs g) {
+    gemm_body<T, AKS, BKS, KB, NST, NWM>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n * g.nsplit));
+}
+
+// several problems, one grid: block ids [start[i], start[i+1]) belong to problem i
+constexpr int MAXGROUP = 8;
+struct GemmGroup { int n; int start[MAXGROUP + 1]; GemmArgs g[MAXGROUP]; };
+template <typename T, bool AKS, bool BKS, int KB, int NST, int NWM>
+__global__ __launch_bounds__(128 * NWM, (NST * 2 * 8192 * KB <= 65536) ? NWM : NWM / 2) void gemm_grouped_kernel(const GemmGroup grp) {
+    const int bid = xcd_remap(blockIdx.x, grp.start[grp.n]);
+    int i = 0;
+    while (i + 1 < grp.n && bid >= grp.start[i + 1]) ++i;
+    const GemmArgs g = grp.g[i];                       // block-uniform: lives in SGPRs
+    gemm_body<T, AKS, BKS, KB, NST, NWM>(g, bid - grp.start[i]);
 }
 
 #define g_variant g_a8_tuning[0]
@@ -354,6 +391,16 @@ template <typename T, int KB, int NST, int NWM> int launch2(const a8_gemm_desc* 
     }
     return a8_check_launch("a8_gemm");
 }
+template <typename T, int KB, int NST, int NWM> int launch2g(int layout, const GemmGroup& g, int grid, hipStream_t s) {
+    const dim3 blk(128 * NWM);
+    switch (layout) {
+        case A8_GEMM_NT: hipLaunchKernelGGL((gemm_grouped_kernel<T, false, false, KB, NST, NWM>), dim3(grid), blk, 0, s, g); break;
+        case A8_GEMM_NN: hipLaunchKernelGGL((gemm_grouped_kernel<T, false, true, KB, NST, NWM>), dim3(grid), blk, 0, s, g); break;
+        case A8_GEMM_TN: hipLaunchKernelGGL((gemm_grouped_kernel<T, true, true, KB, NST, NWM>), dim3(grid), blk, 0, s, g); break;
+        default: return a8_set_error(A8_ERR_ARG, "a8_gemm_grouped: bad layout %d", layout);
+    }
+    return a8_check_launch("a8_gemm_grouped");
+}
 template <typename T> int launch(const a8_gemm_desc* d, const GemmArgs& g, int grid, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
         switch (g_variant) {
@@ -369,11 +416,11 @@ template <typename T> int launch(const a8_gemm_desc* d, const GemmArgs& g, int g
 
 }  // namespace
 
-extern "C" int a8_gemm(const a8_gemm_desc* d, void* stream) {
+// validates one descriptor and fills the kernel arguments; *grid = blocks it needs
+static int build_args(const a8_gemm_desc* d, GemmArgs& g, long long* grid) {
     A8_REQUIRE(d != nullptr, "a8_gemm: null descriptor");
     A8_REQUIRE(d->dtype == A8_F32 || d->dtype == A8_BF16, "a8_gemm: bad dtype %d", d->dtype);
     A8_REQUIRE(d->M >= 0 && d->N > 0 && d->K >= 0, "a8_gemm: bad sizes M=%d N=%d K=%d", d->M, d->N, d->K);
-    if (d->M == 0) return A8_OK;
     const int esz = d->dtype == A8_BF16 ? 2 : 4, epc = 16 / esz;
     const bool aks = d->layout == A8_GEMM_TN, bks = d->layout != A8_GEMM_NT;
     A8_REQUIRE(d->N % 8 == 0 || (d->N % 4 == 0 && (d->out_f32 || d->dtype == A8_F32)), "a8_gemm: N=%d must be a multiple of 8 (4 for f32 output)", d->N);
@@ -385,12 +432,11 @@ extern "C" int a8_gemm(const a8_gemm_desc* d, void* stream) {
     A8_REQUIRE(((uintptr_t)d->A % 16) == 0 && ((uintptr_t)d->B % 16) == 0 && ((uintptr_t)d->C % 16) == 0, "a8_gemm: pointers must be 16-byte aligned");
     A8_REQUIRE(d->a_bs % epc == 0 && d->b_bs % epc == 0, "a8_gemm: batch strides must keep 16-byte alignment");
     const int bk = d->dtype == A8_BF16 ? ((g_variant == 1 || g_variant == 6) ? 32 : 64) : 16;
-    GemmArgs g;
     g.A = Op{(const char*)d->A, d->lda, d->a_rpb, d->a_bs};
     g.B = Op{(const char*)d->B, d->ldb, d->b_rpb, d->b_bs};
     g.C = (char*)d->C; g.ldc = d->ldc; g.c_rpb = d->c_rpb; g.c_bs = d->c_bs;
     g.zin = (const char*)d->zin; g.zout = (char*)d->zout; g.ldz = d->ldz; g.z_rpb = d->z_rpb; g.z_bs = d->z_bs;
-    g.bias = d->bias; g.bias_rows = d->bias_rows;
+    g.bias = d->bias; g.bias_rows = d->bias_rows; g.colsum = d->colsum;
     g.M = d->M; g.N = d->N; g.K = d->K;
     g.tiles_m = cdiv(d->M, 128); g.tiles_n = cdiv(d->N, 128);
     int nsplit = d->splitk > 0 ? d->splitk : 1;
@@ -401,10 +447,46 @@ extern "C" int a8_gemm(const a8_gemm_desc* d, void* stream) {
     g.act = d->act; g.out_f32 = d->out_f32; g.alpha = d->alpha;
     g.atomic = (nsplit > 1 || d->accumulate) ? 1 : 0;
     A8_REQUIRE(!(g.atomic && !d->out_f32), "a8_gemm: split-K / accumulate needs an f32 output");
-    A8_REQUIRE(!(nsplit > 1 && (d->bias || d->act || d->zout)), "a8_gemm: split-K cannot carry a bias/activation epilogue");
+    A8_REQUIRE(!(nsplit > 1 && (d->bias || d->act || d->zout || d->colsum)), "a8_gemm: split-K cannot carry a bias/activation/colsum epilogue");
     A8_REQUIRE(d->act != A8_ACT_MUL_GELU_GRAD || d->zin, "a8_gemm: MUL_GELU_GRAD needs zin");
-    const long long grid = (long long)g.tiles_m * g.tiles_n * nsplit;
-    A8_REQUIRE(grid < (1ll << 30), "a8_gemm: grid too large");
+    *grid = (long long)g.tiles_m * g.tiles_n * nsplit;
+    A8_REQUIRE(*grid < (1ll << 30), "a8_gemm: grid too large");
+    return A8_OK;
+}
+
+extern "C" int a8_gemm(const a8_gemm_desc* d, void* stream) {
+    GemmArgs g;
+    long long grid = 0;
+    if (int e = build_args(d, g, &grid)) return e;
+    if (d->M == 0) return A8_OK;
     hipStream_t s = (hipStream_t)stream;
     return d->dtype == A8_BF16 ? launch<bf16>(d, g, (int)grid, s) : launch<float>(d, g, (int)grid, s);
+}
+
+extern "C" int a8_gemm_grouped(const a8_gemm_desc* descs, int n, void* stream) {
+    A8_REQUIRE(descs != nullptr && n >= 1 && n <= MAXGROUP, "a8_gemm_grouped: need 1..%d descriptors (got %d)", MAXGROUP, n);
+    GemmGroup grp;
+    grp.n = 0;
+    grp.start[0] = 0;
+    long long total = 0;
+    for (int i = 0; i < n; ++i) {
+        A8_REQUIRE(descs[i].dtype == descs[0].dtype && descs[i].layout == descs[0].layout, "a8_gemm_grouped: all problems must share dtype and layout");
+        long long grid = 0;
+        if (int e = build_args(&descs[i], grp.g[grp.n], &grid)) return e;
+        if (descs[i].M == 0) continue;
+        total += grid;
+        A8_REQUIRE(total < (1ll << 30), "a8_gemm_grouped: grid too large");
+        grp.start[++grp.n] = (int)total;
+    }
+    if (grp.n == 0) return A8_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (descs[0].dtype == A8_BF16) {
+        switch (g_variant) {
+            case 1: return launch2g<bf16, 1, 4, 2>(descs[0].layout, grp, (int)total, s);
+            case 5: return launch2g<bf16, 2, 2, 4>(descs[0].layout, grp, (int)total, s);
+            case 6: return launch2g<bf16, 1, 4, 4>(descs[0].layout, grp, (int)total, s);
+            default: return launch2g<bf16, 2, 2, 2>(descs[0].layout, grp, (int)total, s);
+        }
+    }
+    return launch2g<float, 1, 4, 2>(descs[0].layout, grp, (int)total, s);
 }

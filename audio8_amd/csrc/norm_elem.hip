@@ -101,14 +101,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 // Column sums held per wave in registers -> LDS [NS][cols] (one slab per wave; with more than NS waves the upper
 // waves add into the lower waves' slabs in a second pass) -> one atomic per column per block.
 // acc[c][i] belongs to column (lane + 64c)*8 + i.  lds: float[NS * cols], NS = min(NW, 8).
-template <int NW>
-A8_DEV void flush_colsum(float (&acc)[MAXC][8], float* lds, float* __restrict__ out, int cols) {
+template <int NW, int MC>
+A8_DEV void flush_colsum(float (&acc)[MC][8], float* lds, float* __restrict__ out, int cols) {
     constexpr int NS = NW < 8 ? NW : 8;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nch = cols >> 3;
     __syncthreads();
     if (w < NS) {
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c)
+        for (int c = 0; c < MC; ++c)
             if (lane + 64 * c < nch) {
                 float* p = lds + w * cols + (lane + 64 * c) * 8;
                 *reinterpret_cast<f32x4*>(p) = (f32x4){acc[c][0], acc[c][1], acc[c][2], acc[c][3]};
@@ -119,7 +119,7 @@ A8_DEV void flush_colsum(float (&acc)[MAXC][8], float* lds, float* __restrict__ 
     if constexpr (NW > NS) {
         if (w >= NS) {
 #pragma unroll
-            for (int c = 0; c < MAXC; ++c)
+            for (int c = 0; c < MC; ++c)
                 if (lane + 64 * c < nch) {
                     float* p = lds + (w - NS) * cols + (lane + 64 * c) * 8;
                     const f32x4 a = *reinterpret_cast<f32x4*>(p), b = *reinterpret_cast<f32x4*>(p + 4);
@@ -138,27 +138,29 @@ A8_DEV void flush_colsum(float (&acc)[MAXC][8], float* lds, float* __restrict__ 
 }
 
 // ------------------------------------------------------------------ LayerNorm backward
-template <typename T, int NW>
+// MC = 16-byte chunks per lane (cols <= 512 * MC).  dbias (optional) += column sums of the dx output, i.e. the bias
+// gradient of the Linear whose output fed this LayerNorm through dropout (saves a separate column-sum pass).
+template <typename T, int NW, int MC>
 __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ dy2,
-                                                     const T* __restrict__ x, const T* __restrict__ res,
-                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                     const float* __restrict__ rstd, T* __restrict__ dx, T* __restrict__ dres,
-                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                     int rows, int cols, Drop dr) {
-    __shared__ __attribute__((aligned(16))) float lds[(NW < 8 ? NW : 8) * MAXC * 512];
+                                                         const T* __restrict__ x, const T* __restrict__ res,
+                                                         const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, T* __restrict__ dx, T* __restrict__ dres,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dbias,
+                                                         int rows, int cols, Drop dr) {
+    __shared__ __attribute__((aligned(16))) float lds[(NW < 8 ? NW : 8) * MC * 512];
     const int lane = threadIdx.x & 63, nch = cols >> 3;
     const float inv = 1.0f / (float)cols;
-    float ag[MAXC][8], ab[MAXC][8];
+    float ag[MC][8], ab[MC][8], ad[MC][8];
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c)
+    for (int c = 0; c < MC; ++c)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { ag[c][i] = 0.f; ab[c][i] = 0.f; }
+        for (int i = 0; i < 8; ++i) { ag[c][i] = 0.f; ab[c][i] = 0.f; ad[c][i] = 0.f; }
     for (int row = blockIdx.x * NW + (threadIdx.x >> 6); row < rows; row += gridDim.x * NW) {
         const float mu = mean[row], rs = rstd[row];
-        float xh[MAXC][8], g[MAXC][8];
+        float xh[MC][8], g[MC][8];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
+        for (int c = 0; c < MC; ++c) {
             const int ch = lane + 64 * c;
             if (ch < nch) {
                 const long long off = (long long)row * cols + ch * 8;
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const T* __restrict__ d
         }
         const float a = wave_sum(s1) * inv, b = wave_sum(s2) * inv;
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
+        for (int c = 0; c < MC; ++c) {
             const int ch = lane + 64 * c;
             if (ch < nch) {
                 const long long off = (long long)row * cols + ch * 8;
@@ -203,19 +205,23 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const T* __restrict__ d
 #pragma unroll
                 for (int i = 0; i < 8; ++i) o[i] = rs * (g[c][i] - a - xh[c][i] * b);
                 if (dres) store8(dres + off, o);
-                if (dx) {
-                    if (dr.thr) {
+                if (dr.thr) {
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) o[i] = a8_keep(dr.seed, dr.stream, (uint32_t)(off + i), dr.thr) ? o[i] * dr.scale : 0.f;
-                    }
-                    store8(dx + off, o);
+                    for (int i = 0; i < 8; ++i) o[i] = a8_keep(dr.seed, dr.stream, (uint32_t)(off + i), dr.thr) ? o[i] * dr.scale : 0.f;
+                }
+                if (dx) store8(dx + off, o);
+                if (dbias) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) ad[c][i] += o[i];
                 }
             }
         }
     }
-    if (!dgamma) return;
-    flush_colsum<NW>(ag, lds, dgamma, cols);
-    flush_colsum<NW>(ab, lds, dbeta, cols);
+    if (dgamma) {
+        flush_colsum<NW, MC>(ag, lds, dgamma, cols);
+        flush_colsum<NW, MC>(ab, lds, dbeta, cols);
+    }
+    if (dbias) flush_colsum<NW, MC>(ad, lds, dbias, cols);
 }
 
 // ------------------------------------------------------------------ dz = dy * gelu'(z); dbias += colsum(dz)
@@ -292,7 +298,7 @@ __global__ __launch_bounds__(256) void mask_fill_rows_bwd_kernel(T* __restrict__
             }
         }
     }
-    flush_colsum<4>(ab, lds, demb, cols);
+    flush_colsum<4, MAXC>(ab, lds, demb, cols);
 }
 
 template <typename T>
@@ -481,21 +487,24 @@ extern "C" int a8_layernorm_fwd(int dtype, const void* x, const void* res, const
 }
 
 extern "C" int a8_layernorm_bwd(int dtype, const void* dy, const void* dy2, const void* x, const void* res, const float* gamma,
-                                const float* mean, const float* rstd, void* dx, void* dres, float* dgamma, float* dbeta,
+                                const float* mean, const float* rstd, void* dx, void* dres, float* dgamma, float* dbeta, float* dbias,
                                 int rows, int cols, float p, uint32_t seed, uint32_t rng_stream, void* stream) {
     A8_REQUIRE(cols % 8 == 0 && cols <= MAXC * 512, "a8_layernorm_bwd: cols=%d must be a multiple of 8 and <= %d", cols, MAXC * 512);
+    A8_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "a8_layernorm_bwd: dgamma and dbeta go together");
     if (rows == 0) return A8_OK;
     const Drop dr = make_drop(p, seed, rng_stream);
     // rows per wave R and waves per block NW (a8_set_tuning key 1 = NW*100 + R): fewer, fatter blocks mean fewer
-    // same-address atomics on dgamma/dbeta
+    // same-address atomics on the column sums
     const int nw = g_a8_tuning[1] / 100, rpw = g_a8_tuning[1] % 100;
     const int grid = cdiv(rows, nw * rpw);
-#define LN_BWD(NW) DISPATCH_T(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T, NW>), dim3(grid), dim3(NW * 64), 0, (hipStream_t)stream, \
+#define LN_BWD2(NW, MC) DISPATCH_T(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T, NW, MC>), dim3(grid), dim3(NW * 64), 0, (hipStream_t)stream, \
                                          (const T*)dy, (const T*)dy2, (const T*)x, (const T*)res, gamma, mean, rstd, (T*)dx, (T*)dres, \
-                                         dgamma, dbeta, rows, cols, dr))
+                                         dgamma, dbeta, dbias, rows, cols, dr))
+#define LN_BWD(NW) do { if (cols <= 1024) LN_BWD2(NW, 2); else LN_BWD2(NW, MAXC); } while (0)
     if (nw == 4) LN_BWD(4); else if (nw == 8) LN_BWD(8); else if (nw == 16) LN_BWD(16);
     else return a8_set_error(A8_ERR_ARG, "a8_layernorm_bwd: bad tuning %d", g_a8_tuning[1]);
 #undef LN_BWD
+#undef LN_BWD2
     return a8_check_launch("a8_layernorm_bwd");
 }
 

@@ -21,12 +21,10 @@ def _c(t):
     return t
 
 
-def gemm(layout, A, B, M, N, K, *, out=None, out_dtype=None, lda=None, ldb=None, ldc=None, bias=None, bias_rows=False,
-         act=L.ACT_NONE, zin=None, zout=None, ldz=None, accumulate=False, splitk=1, alpha=1.0,
-         a_rpb=0, a_bs=0, b_rpb=0, b_bs=0, c_rpb=0, c_bs=0, z_rpb=0, z_bs=0, a_off=0, c_off=0, z_off=0):
-    """C[M,N] = epi(alpha * A.B^T + bias).  A/B are CUDA tensors of the activation dtype; the logical
-    shapes and leading dimensions are given explicitly so strided views (conv-as-GEMM) need no copy."""
-    L.require_cuda(A, B, out, bias, zin, zout)
+def _gemm_desc(layout, A, B, M, N, K, *, out=None, out_dtype=None, lda=None, ldb=None, ldc=None, bias=None, bias_rows=False,
+               act=L.ACT_NONE, zin=None, zout=None, ldz=None, accumulate=False, splitk=1, alpha=1.0,
+               a_rpb=0, a_bs=0, b_rpb=0, b_bs=0, c_rpb=0, c_bs=0, z_rpb=0, z_bs=0, a_off=0, c_off=0, z_off=0, colsum=None):
+    L.require_cuda(A, B, out, bias, zin, zout, colsum)
     dtype = L.dt(A)
     assert B.dtype == A.dtype
     if layout == L.NT:
@@ -58,17 +56,44 @@ def gemm(layout, A, B, M, N, K, *, out=None, out_dtype=None, lda=None, ldb=None,
     d.accumulate = 1 if accumulate else 0
     d.splitk = splitk
     d.alpha = alpha
+    d.colsum = colsum.data_ptr() if colsum is not None else None
+    alg_bytes = (M * K + N * K) * esz + M * N * out.element_size() * (2 if zout is not None else 1) + (M * N * esz if zin is not None else 0)
+    return d, out, alg_bytes
+
+
+def gemm(layout, A, B, M, N, K, **kw):
+    """C[M,N] = epi(alpha * A.B^T + bias).  A/B are CUDA tensors of the activation dtype; the logical
+    shapes and leading dimensions are given explicitly so strided views (conv-as-GEMM) need no copy."""
+    d, out, alg_bytes = _gemm_desc(layout, A, B, M, N, K, **kw)
     if GEMM_PROFILE is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
         L.check(L.lib().a8_gemm(C.byref(d), L.stream()), "a8_gemm")
         ev1.record()
-        esz = A.element_size()
-        alg_bytes = (M * K + N * K) * esz + M * N * out.element_size() * (2 if zout is not None else 1) + (M * N * esz if zin is not None else 0)
-        GEMM_PROFILE.append((ev0, ev1, 2.0 * M * N * K, layout, alg_bytes, (M, N, K, splitk)))
+        GEMM_PROFILE.append((ev0, ev1, 2.0 * M * N * K, layout, alg_bytes, (M, N, K, kw.get("splitk", 1))))
     else:
         L.check(L.lib().a8_gemm(C.byref(d), L.stream()), "a8_gemm")
     return out
+
+
+def gemm_grouped(layout, problems):
+    """Several independent GEMMs of one layout and dtype in one launch.  problems: list of (A, B, M, N, K, kwargs)."""
+    arr = (L.GemmDesc * len(problems))()
+    flops, nbytes, outs = 0.0, 0, []
+    for i, (A, B, M, N, K, kw) in enumerate(problems):
+        arr[i], out, ab = _gemm_desc(layout, A, B, M, N, K, **kw)
+        outs.append(out)
+        flops += 2.0 * M * N * K
+        nbytes += ab
+    if GEMM_PROFILE is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        L.check(L.lib().a8_gemm_grouped(arr, len(problems), L.stream()), "a8_gemm_grouped")
+        ev1.record()
+        GEMM_PROFILE.append((ev0, ev1, flops, layout, nbytes, (-len(problems), problems[0][3], problems[0][4], 1)))
+    else:
+        L.check(L.lib().a8_gemm_grouped(arr, len(problems), L.stream()), "a8_gemm_grouped")
+    return outs
 
 
 # ----------------------------------------------------------------------------- helpers
@@ -127,12 +152,13 @@ def layernorm_fwd(x, res, gamma, beta, eps, p=0.0, seed=0, rng_stream=0):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, dy2, x, res, gamma, mean, rstd, dgamma, dbeta, p=0.0, seed=0, rng_stream=0, want_dx=True, want_dres=True):
+def layernorm_bwd(dy, dy2, x, res, gamma, mean, rstd, dgamma, dbeta, p=0.0, seed=0, rng_stream=0, want_dx=True, want_dres=True, dbias=None):
+    """dbias (optional f32 [cols]) += column sums of dx: the bias gradient of the Linear that produced x."""
     rows, cols = x.numel() // x.shape[-1], x.shape[-1]
     dx = torch.empty_like(x) if want_dx else None
     dres = torch.empty_like(x) if want_dres else None
     L.check(L.lib().a8_layernorm_bwd(L.dt(x), L.ptr(_c(dy)), L.ptr(_c(dy2)), L.ptr(_c(x)), L.ptr(_c(res)), L.ptr(gamma), L.ptr(mean), L.ptr(rstd),
-                                     L.ptr(dx), L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), rows, cols, _f(p), _u32(seed), _u32(rng_stream),
+                                     L.ptr(dx), L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dbias), rows, cols, _f(p), _u32(seed), _u32(rng_stream),
                                      L.stream()), "a8_layernorm_bwd")
     return dx, dres
 

@@ -167,6 +167,41 @@ def acc_wgrad(p, dy, x, n_out, n_in, m, **kw):
     return None
 
 
+# The four weight-gradient products of an encoder layer as ONE grouped launch at the end of the layer's backward:
+# 432 output tiles fill the chip without split-K (each alone needs a 3-12 way split + f32 atomics to do so).
+GROUP_WGRAD = True
+
+
+class WgradGroup:
+    """Collects (params, target, dy, x, n_out, n_in, m) and issues them together on the side stream."""
+
+    def __init__(self):
+        self.items = []
+
+    def add(self, params, tgt, dy, x, n_out, n_in, m):
+        self.items.append((params, tgt, dy, x, n_out, n_in, m))
+
+    def flush(self):
+        if not self.items:
+            return
+        items, self.items = self.items, []
+
+        def run():
+            K.gemm_grouped(L.TN, [(dy, x, n_out, n_in, m, dict(out=tgt, accumulate=True)) for _, tgt, dy, x, n_out, n_in, m in items])
+            for params, *_ in items:
+                _ready(*params)
+        _on_side(run, *[t for it in items for t in (it[2], it[3])])
+
+
+def acc_wgrad_grouped(group, p, dy, x, n_out, n_in, m):
+    """acc_wgrad, deferred into `group` when the gradient goes straight into p.grad."""
+    tgt = _target(p)
+    if group is None or tgt is None:
+        return acc_wgrad(p, dy, x, n_out, n_in, m)
+    group.add((p,), tgt, dy, x, n_out, n_in, m)
+    return None
+
+
 def acc_colsum(p, x2d):
     tgt = _target(p)
     if tgt is None:
@@ -570,30 +605,45 @@ class EncoderLayerFn(torch.autograd.Function):
         dg1, dbe1, dir1 = ln_targets(pg1, pbe1)
         dg2, dbe2, dir2 = ln_targets(pg2, pbe2)
         # ln1: x2 = LN(x1 + drop(f))
-        df, dx1_res = K.layernorm_bwd(dx2, None, f, x1, g1.detach(), mean1, rstd1, dg1, dbe1, p, seed2, 4, want_dx=True, want_dres=p > 0)
+        tb2, tbo = _target(b2), _target(bo)      # bias gradients of w_2 / w_O ride on the LayerNorm backward passes
+        df, dx1_res = K.layernorm_bwd(dx2, None, f, x1, g1.detach(), mean1, rstd1, dg1, dbe1, p, seed2, 4, want_dx=True, want_dres=p > 0, dbias=tb2)
         if p == 0:
             dx1_res = df
         if dir1:
             _ready(pg1, pbe1)
             dg1 = dbe1 = None
         # FFN
-        db2 = acc_colsum(b2, df)
-        dw2 = acc_wgrad(w2, df, h, d, dff, M)
+        wg = WgradGroup() if GROUP_WGRAD else None
+        if tb2 is not None:
+            _ready(b2)
+            db2 = None
+        else:
+            db2 = acc_colsum(b2, df)
+        dw2 = acc_wgrad_grouped(wg, w2, df, h, d, dff, M)
         wqkv_t, wo_t, w1_t, w2_t = ctx.wts
-        dz1 = _dgrad(df, w2_c, w2_t, M, dff, d, act=L.ACT_MUL_GELU_GRAD, zin=z1, ldz=dff)
-        db1 = acc_colsum(b1, dz1)
-        dw1 = acc_wgrad(w1, dz1, x1, dff, d, M)
+        tb1 = _target(b1)                       # b_1's gradient = column sums of dz1: accumulated by the same epilogue
+        dz1 = _dgrad(df, w2_c, w2_t, M, dff, d, act=L.ACT_MUL_GELU_GRAD, zin=z1, ldz=dff, colsum=tb1)
+        if tb1 is not None:
+            _ready(b1)
+            db1 = None
+        else:
+            db1 = acc_colsum(b1, dz1)
+        dw1 = acc_wgrad_grouped(wg, w1, dz1, x1, dff, d, M)
         dx1_ffn = _dgrad(dz1, w1_c, w1_t, M, d, dff)
         # ln2: x1 = LN(x + drop(ao))
-        dao, dx_res = K.layernorm_bwd(dx1_res, dx1_ffn, ao, x, g2.detach(), mean2, rstd2, dg2, dbe2, p, seed1, 3, want_dx=True, want_dres=p > 0)
+        dao, dx_res = K.layernorm_bwd(dx1_res, dx1_ffn, ao, x, g2.detach(), mean2, rstd2, dg2, dbe2, p, seed1, 3, want_dx=True, want_dres=p > 0, dbias=tbo)
         if p == 0:
             dx_res = dao
         if dir2:
             _ready(pg2, pbe2)
             dg2 = dbe2 = None
         # output projection
-        dbo = acc_colsum(bo, dao)
-        dwo = acc_wgrad(wo, dao, o, d, d, M)
+        if tbo is not None:
+            _ready(bo)
+            dbo = None
+        else:
+            dbo = acc_colsum(bo, dao)
+        dwo = acc_wgrad_grouped(wg, wo, dao, o, d, d, M)
         do = _dgrad(dao, wo_c, wo_t, M, d, d)
         # attention core
         _, _, _, dqkv = K.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, do, lse, B, T, H, 3 * d, 1.0 / math.sqrt(d // H),
@@ -603,16 +653,20 @@ class EncoderLayerFn(torch.autograd.Function):
             colsum(dqkv, _span3(tb[0], (3 * d,)))
             _ready(bq, bk, bv)
             wspan = _span3(tw[0], (3 * d, d))
-
-            def run_qkv():
-                K.gemm(L.TN, dqkv, x, 3 * d, d, M, out=wspan, accumulate=True, splitk=_splitk(_tiles(3 * d, d), M))
-                _ready(wq, wk, wv)
-            _on_side(run_qkv, dqkv, x)
+            if wg is not None:
+                wg.add((wq, wk, wv), wspan, dqkv, x, 3 * d, d, M)
+            else:
+                def run_qkv():
+                    K.gemm(L.TN, dqkv, x, 3 * d, d, M, out=wspan, accumulate=True, splitk=_splitk(_tiles(3 * d, d), M))
+                    _ready(wq, wk, wv)
+                _on_side(run_qkv, dqkv, x)
             gq = (None,) * 6
         else:
             dbqkv = colsum(dqkv)
             dwqkv = wgrad(dqkv, x, 3 * d, d, M)
             gq = (dwqkv[:d], dbqkv[:d], dwqkv[d:2 * d], dbqkv[d:2 * d], dwqkv[2 * d:], dbqkv[2 * d:])
+        if wg is not None:
+            wg.flush()                 # all four operand pairs are enqueued; the side stream waits for exactly that
         dx_qkv = _dgrad(dqkv, wqkv_c, wqkv_t, M, d, 3 * d)
         dx = K.add(dx_res, dx_qkv)
         return (dx, None, None, None, None, None, None, *gq, dwo, dbo, dw1, db1, dw2, db2, dg1, dbe1, dg2, dbe2)

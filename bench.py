@@ -96,6 +96,7 @@ def main():
     loss_fn = W.create_loss(640, 100)
     stepper = Stepper(model, lr=2.0e-4, weight_decay=1.0e-2, clip=1.0, bucket_mb=args.bucket_mb,
                       wgrad_side_stream=os.environ.get("A8_SIDE_WGRAD", "1") != "0")
+    ops.GROUP_WGRAD = os.environ.get("A8_GROUP_WGRAD", "1") != "0"
     x = synth(args.batch, args.samples, rank).to(dev)
 
     def one_step():

@@ -47,8 +47,14 @@ typedef struct a8_gemm_desc {
     int accumulate;                       /* C += (f32 atomics) */
     int splitk;                           /* >1: split the K range over workgroups (f32 atomics) */
     float alpha;
+    float* colsum;                        /* optional f32 [N] += column sums of the final C values (a bias gradient riding on
+                                             the data-gradient GEMM that produces dz); not with split-K */
 } a8_gemm_desc;
 int a8_gemm(const a8_gemm_desc* d, void* stream);
+/* n (<= 8) independent problems of one dtype and layout in ONE launch (block ranges partition the grid): the four
+ * weight-gradient products of an encoder layer fill the chip together without split-K.  Replaces the same
+ * per-parameter autograd GEMMs as a8_gemm. */
+int a8_gemm_grouped(const a8_gemm_desc* descs, int n, void* stream);
 /* developer tuning knob (key 0: GEMM stage geometry variant); never needed for correctness */
 int a8_set_tuning(int key, int value);
 
@@ -90,9 +96,10 @@ int a8_layernorm_fwd(int dtype, const void* x, const void* res, const float* gam
                      float* mean, float* rstd, int rows, int cols, float eps, float p, uint32_t seed, uint32_t rng_stream,
                      void* stream);
 /* dy (+ dy2 if non-NULL) -> ds = d(res + dropout(x)); writes dres = ds (if dres) and dx = ds * keep/(1-p) (if dx);
- * dgamma/dbeta f32 [cols] accumulated (+=). */
+ * dgamma/dbeta f32 [cols] accumulated (+=; both NULL to skip); dbias (optional) f32 [cols] += column sums of dx, the
+ * bias gradient of the Linear that produced x (eight_mile Dense bias, audio8/wav2vec2.py:613-622 block). */
 int a8_layernorm_bwd(int dtype, const void* dy, const void* dy2, const void* x, const void* res, const float* gamma,
-                     const float* mean, const float* rstd, void* dx, void* dres, float* dgamma, float* dbeta,
+                     const float* mean, const float* rstd, void* dx, void* dres, float* dgamma, float* dbeta, float* dbias,
                      int rows, int cols, float p, uint32_t seed, uint32_t rng_stream, void* stream);
 
 /* ---- element-wise helpers ----------------------------------------------------------------------- */

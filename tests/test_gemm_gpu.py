@@ -127,3 +127,44 @@ def test_gemm_tuning_variants_are_exact(variant, layout):
     finally:
         L.check(L.lib().a8_set_tuning(0, 5))
     assert torch.equal(out.cpu().double(), ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("out_f32", [False, True])
+def test_gemm_colsum_epilogue(dtype, out_f32):
+    """Column sums of the final output values (bias gradient riding on a data-gradient GEMM), with the gelu' epilogue."""
+    from audio8_amd import kernels as Kn, _lib as L
+    M, N, K = 333, 264, 96
+    A, B = _mk((M, K), dtype, 11), _mk((N, K), dtype, 12)
+    z = _mk((M, N), dtype, 13)
+    dev = "cuda"
+    cs = torch.full((N,), 0.5, device=dev)
+    out = Kn.gemm(L.NT, A.to(dev), B.to(dev), M, N, K, act=L.ACT_MUL_GELU_GRAD, zin=z.to(dev), colsum=cs,
+                  out_dtype=torch.float32 if out_f32 else dtype)
+    zz = z.double()
+    gp = 0.5 * (1 + torch.erf(zz / math.sqrt(2))) + zz * torch.exp(-0.5 * zz * zz) / math.sqrt(2 * math.pi)
+    ref = (A.double() @ B.double().T) * gp
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    np.testing.assert_allclose(out.double().cpu().numpy(), ref.numpy(), rtol=tol, atol=tol * 10)
+    np.testing.assert_allclose(cs.double().cpu().numpy(), 0.5 + ref.sum(0).numpy(), rtol=tol, atol=tol * 30)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("layout", ["TN", "NT"])
+def test_gemm_grouped(dtype, layout):
+    """Several problems of different shapes in one launch == the same problems launched one by one."""
+    from audio8_amd import kernels as Kn, _lib as L
+    dev = "cuda"
+    shapes = [(768, 264, 1000), (128, 128, 72), (200, 512, 2056), (8, 8, 8)]
+    probs, refs = [], []
+    for i, (M, N, K) in enumerate(shapes):
+        A, B = _mk((M, K), dtype, 20 + i, integer=True), _mk((N, K), dtype, 40 + i, integer=True)
+        refs.append(A.double() @ B.double().T + 1.0)
+        out = torch.ones((M, N), device=dev, dtype=torch.float32)
+        if layout == "TN":
+            probs.append((A.T.contiguous().to(dev), B.T.contiguous().to(dev), M, N, K, dict(out=out, accumulate=True, splitk=1 + i % 2)))
+        else:
+            probs.append((A.to(dev), B.to(dev), M, N, K, dict(out=out, accumulate=True)))
+    outs = Kn.gemm_grouped(L.TN if layout == "TN" else L.NT, probs)
+    for o, r in zip(outs, refs):
+        np.testing.assert_array_equal(o.double().cpu().numpy(), r.numpy())

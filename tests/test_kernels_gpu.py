@@ -110,7 +110,9 @@ def test_layernorm_fused_dropout_consistency():
     close(y1, y2, 1e-6)
     dy = rnd((rows, cols), 3).to(d)
     dg, db = torch.zeros(cols, device=d), torch.zeros(cols, device=d)
-    dx1, dres1 = K.layernorm_bwd(dy, None, x, res, gm, m1, r1, dg, db, p=p, seed=77, rng_stream=5)
+    dbias = torch.zeros(x.shape[-1], device=x.device)
+    dx1, dres1 = K.layernorm_bwd(dy, None, x, res, gm, m1, r1, dg, db, p=p, seed=77, rng_stream=5, dbias=dbias)
+    close(dbias, dx1.float().sum(0), 2e-3 if x.dtype != torch.float32 else 1e-5, "ln fused bias column sum")
     dx2, dres2 = K.layernorm_bwd(dy, None, xd, res, gm, m2, r2, dg, db)
     close(dres1, dres2, 1e-5)
     close(dx1, dx2 * keep / (1 - p), 1e-5)

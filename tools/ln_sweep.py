@@ -41,7 +41,7 @@ def main():
         L.check(L.lib().a8_set_tuning(1, v), "tune")
         def f():
             L.check(L.lib().a8_layernorm_bwd(L.dt(x), L.ptr(dy), L.ptr(dy2), L.ptr(x), L.ptr(res), L.ptr(g), L.ptr(mean), L.ptr(rstd), L.ptr(dx), L.ptr(dres),
-                                             None, None, rows, cols, 0.1, 1, 1, L.stream()), "ln")
+                                             None, None, None, rows, cols, 0.1, 1, 1, L.stream()), "ln")
         print("no-colsum %d: %.1f us" % (v, timeit(f, iters=50)))
 
 
