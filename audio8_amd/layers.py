@@ -193,10 +193,9 @@ class TransformerEncoderStack(nn.Module):
         if mask is not None:
             mask_u8 = mask.reshape(B, T).to(torch.uint8).contiguous()
         h = x.reshape(B * T, d)
-        # one np.random.random() per layer per forward (eight_mile's layer-drop draw), taken up front: same count and
-        # order on the global numpy RNG, but whoever consumes the RNG next (negative sampling) can start right away
-        draws = [np.random.random() for _ in self.encoders] if self.layerdrop_rng_draws else [1.0] * len(self.encoders)
-        ops.run_post_rng_hooks()
+        # one np.random.random() per layer per forward (eight_mile's layer-drop draw), taken up front -- or handed over by
+        # wav2vec2.prefetch_host_draws, which took them in the same order while the GPU was busy with the previous step
+        draws = ops.take_layer_draws(len(self.encoders)) if self.layerdrop_rng_draws else [1.0] * len(self.encoders)
         for layer, pdrop in zip(self.encoders, draws):
             if self.training and pdrop < self.layer_drop:
                 continue

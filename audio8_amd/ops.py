@@ -18,16 +18,29 @@ _COMPUTE_DTYPE = torch.bfloat16
 _SEED_STATE = {"base": None, "ctr": 0}
 
 
-# One-shot callbacks run by TransformerEncoderStack right after its layer-drop draws, i.e. at the point of the forward
-# where the host RNG is next needed by the loss (negative sampling); LAST_MASK_INFO = (B, Tm) of the latest time mask.
-POST_RNG_HOOKS = []
-LAST_MASK_INFO = None
+# Layer-drop draws taken ahead of time by wav2vec2.prefetch_host_draws (None: TransformerEncoderStack draws them itself).
+PLANNED_LAYER_DRAWS = None
 
 
-def run_post_rng_hooks():
-    hooks, POST_RNG_HOOKS[:] = list(POST_RNG_HOOKS), []
-    for h in hooks:
-        h()
+def take_layer_draws(n):
+    """The n per-layer np.random.random() values of this forward: prefetched ones if a plan is active, else fresh draws."""
+    global PLANNED_LAYER_DRAWS
+    d, PLANNED_LAYER_DRAWS = PLANNED_LAYER_DRAWS, None
+    if d is not None:
+        if len(d) != n:
+            raise RuntimeError("a8hip: prefetched layer-drop draws (%d) do not match the encoder depth (%d)" % (len(d), n))
+        return d
+    return [np.random.random() for _ in range(n)]
+
+
+def host_to_device(a, dtype):
+    """numpy array -> device tensor through a pinned staging buffer (cached by torch's host allocator): the copy is
+    enqueued on the current stream and never blocks the host (a pageable .to(device) does)."""
+    a = np.ascontiguousarray(a, dtype=dtype)
+    pin = torch.empty(a.shape, dtype=torch.from_numpy(a[:0]).dtype, pin_memory=True)
+    pin.numpy()[...] = a
+    return pin.to("cuda", non_blocking=True)
+
 
 
 def set_compute_dtype(dtype):
@@ -780,4 +793,4 @@ class CTCFn(torch.autograd.Function):
 
 
 def host_i32(a, device):
-    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device, non_blocking=True)
+    return host_to_device(a, np.int32)

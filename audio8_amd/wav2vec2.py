@@ -10,6 +10,7 @@ Deliberate, documented differences from the reference implementation (not from i
 """
 import contextlib
 import math
+import collections
 import os
 from collections import namedtuple
 from typing import Dict, Optional, Tuple
@@ -34,7 +35,6 @@ DIVERSITY_WGT = 10
 
 CheckpointMapping = namedtuple('CheckpointMapping', ['nested', 'flat'])
 # optional: sample the negatives right after the encoder layer-drop draws (same RNG order, earlier on the host)
-EARLY_NEGATIVES = os.environ.get("A8_EARLY_NEG", "0") == "1"      # measured 1 ms slower: off by default
 
 
 def _nested_map(src_prefix: str, dst_prefix: str) -> Dict[str, str]:
@@ -185,37 +185,20 @@ class Wav2Vec2Loss(nn.Module):
         self.sample = Sampler(n_negatives)
         self.last_logits = None
 
-    def _prefetch_negatives(self):
-        """Runs (via ops.POST_RNG_HOOKS) right after the encoder's layer-drop draws.  The negatives are the next consumer
-        of the global numpy RNG, so sampling them here keeps the reference's draw order; at this point of the forward the
-        GPU still has the whole conv stack queued, so the ~2 ms of host sampling no longer leaves it idle (sampling after
-        the forward, as the reference does, hits an already drained queue)."""
-        info = ops.LAST_MASK_INFO
-        if info is None:
-            return
-        B, Tm = info
-        idx = self.sample.indices(B, Tm).reshape(B * Tm, self.sample.n_negatives)       # row (b,t): its N negatives
-        self._pending = (idx.astype(np.int32), B, Tm)
-
     def __call__(self, model, features):
-        self._pending = None
-        if EARLY_NEGATIVES:
-            ops.POST_RNG_HOOKS.append(self._prefetch_negatives)
-        try:
-            outputs, latents, gs_probs, time_mask = model(features)
-        finally:
-            if self._prefetch_negatives in ops.POST_RNG_HOOKS:
-                ops.POST_RNG_HOOKS.remove(self._prefetch_negatives)
+        outputs, latents, gs_probs, time_mask = model(features)
         B, T, C = outputs.shape
         Tm = latents.shape[1]
         rows = _mask_row_index(time_mask)
         ctx = ops.GatherRowsFn.apply(outputs.reshape(B * T, C), rows)
-        if self._pending is not None and self._pending[1:] == (B, Tm):
-            idx = self._pending[0]
+        plan = getattr(time_mask, "_a8_plan", None)
+        if plan is not None and plan.neg_idx is not None and plan.neg_shape == (B * Tm, self.sample.n_negatives):
+            neg_idx = plan.neg_idx                       # drawn ahead of time, in the reference's RNG order
         else:
-            idx = self.sample.indices(B, Tm).reshape(B * Tm, self.sample.n_negatives)
-        self._pending = None
-        neg_idx = ops.host_i32(idx, outputs.device)
+            if plan is not None and plan.neg_idx is not None:
+                raise RuntimeError("a8hip: prefetched negatives do not match this loss (shape %s vs %s)"
+                                   % (plan.neg_shape, (B * Tm, self.sample.n_negatives)))
+            neg_idx = ops.host_i32(self.sample.indices(B, Tm).reshape(B * Tm, self.sample.n_negatives), outputs.device)
         xe_loss, logits = ops.ContrastiveXEFn.apply(ctx, latents.reshape(B * Tm, C), neg_idx)
         self.last_logits = logits
         diversity = DIVERSITY_WGT * (self.n_vars - gs_probs) / self.n_vars
@@ -236,10 +219,62 @@ def _mask_row_index(time_mask: torch.Tensor) -> torch.Tensor:
 
 def _mask_to_device(mask_np: np.ndarray, device):
     """numpy bool [B,T] -> (bool tensor on device, uint8 flat view, int32 row indices); one H2D each."""
-    m = torch.from_numpy(mask_np).to(device)
+    m = ops.host_to_device(mask_np, np.bool_)
     rows = ops.host_i32(np.flatnonzero(mask_np.reshape(-1)), device)
     m._a8_rows = rows
     return m, m.reshape(-1).view(torch.uint8), rows
+
+
+class HostDraws:
+    """Every global-numpy-RNG draw of one pretrain step, already on the device: span mask, per-layer layer-drop draws,
+    negative indices -- taken in the reference's order (audio8/wav2vec2.py:937 -> eight_mile encoder stack -> :384)."""
+
+    def __init__(self, key, mask_dev, layer_draws, neg_idx, neg_shape):
+        self.key, self.mask_dev, self.layer_draws, self.neg_idx, self.neg_shape = key, mask_dev, layer_draws, neg_idx, neg_shape
+
+
+_PLANS = collections.deque()
+
+
+def conv_out_frames(conv_specs, n_samples: int) -> int:
+    for _, k, s in conv_specs:
+        n_samples = (n_samples - k) // s + 1
+    return n_samples
+
+
+def prefetch_host_draws(model, loss_fn, batch_shape, device="cuda"):
+    """Take the NEXT training step's host-RNG draws now and upload them asynchronously.
+
+    The reference draws mask / layer-drop / negatives inline during forward and loss (2-3 ms of numpy per step at
+    8 x 250k samples, with the GPU idle behind it).  None of them depends on device results, only on shapes, so a
+    training loop can call this right after `loss.backward()` -- while the host would otherwise just wait in
+    `loss.item()` -- and the next `loss_fn(model, x)` consumes the plan instead of drawing.  The order of calls on the
+    global numpy RNG is exactly the reference's (all of step n, then all of step n+1), so sampled indices stay
+    bit-identical to a run without prefetching.  Training mode only; a plan that does not match the next forward's
+    shape raises instead of silently re-drawing."""
+    if not isinstance(model, Wav2Vec2Model) or not model.training:
+        return None
+    B, L = int(batch_shape[0]), int(batch_shape[-1])
+    T = conv_out_frames(model.feature_extractor.conv_specs, L)
+    mask_np = create_mask((B, T), p_start=model.timestep_masking, mask_length=model.timestep_mask_len)
+    stack = model.encoder.transformer
+    draws = [np.random.random() for _ in stack.encoders] if stack.layerdrop_rng_draws else None
+    Tm = int(mask_np[0].sum())
+    n_neg = loss_fn.sample.n_negatives
+    idx = loss_fn.sample.indices(B, Tm).reshape(B * Tm, n_neg)
+    plan = HostDraws((id(model), B, T), _mask_to_device(mask_np, device), draws, ops.host_i32(idx, device), (B * Tm, n_neg))
+    _PLANS.append(plan)
+    return plan
+
+
+def _take_plan(model, B, T):
+    if not _PLANS:
+        return None
+    plan = _PLANS.popleft()
+    if plan.key != (id(model), B, T) or not model.training:
+        _PLANS.clear()
+        raise RuntimeError("a8hip: prefetched host draws %s do not match this forward %s" % (plan.key[1:], (B, T)))
+    return plan
 
 
 class ConvFeatureExtractionModel(nn.Module):
@@ -439,11 +474,16 @@ class Wav2Vec2Model(nn.Module):
         features = self.proj_to_input(unmasked)                                                   # :932
         features = ops.dropout(features, self.p_dropout_input, self.training)                    # :934
         unmasked_d = ops.dropout(unmasked, self.p_dropout_features, self.training)               # :935
-        time_mask_np = create_mask((B, T), p_start=self.timestep_masking, mask_length=self.timestep_mask_len)   # :937
-        time_mask, tm_u8, rows = _mask_to_device(time_mask_np, x.device)                          # :938
+        plan = _take_plan(self, B, T)
+        if plan is not None:                                                                      # draws taken by prefetch_host_draws
+            time_mask, tm_u8, rows = plan.mask_dev
+            time_mask._a8_plan = plan
+            ops.PLANNED_LAYER_DRAWS = plan.layer_draws
+        else:
+            time_mask_np = create_mask((B, T), p_start=self.timestep_masking, mask_length=self.timestep_mask_len)   # :937
+            time_mask, tm_u8, rows = _mask_to_device(time_mask_np, x.device)                      # :938
         features = ops.MaskFillRowsFn.apply(features, tm_u8, self.mask_emb)                      # :939
         Tm = rows.numel() // B
-        ops.LAST_MASK_INFO = (B, Tm)
         y = ops.GatherRowsFn.apply(unmasked_d, rows).view(B, Tm, C0)                              # :946
         ctx = self.encoder(features.view(B, T, -1))                                               # :947
         y, vq_probs = self.quantizer(y)                                                           # :948

@@ -97,12 +97,15 @@ def main():
     stepper = Stepper(model, lr=2.0e-4, weight_decay=1.0e-2, clip=1.0, bucket_mb=args.bucket_mb,
                       wgrad_side_stream=os.environ.get("A8_SIDE_WGRAD", "1") != "0")
     ops.GROUP_WGRAD = os.environ.get("A8_GROUP_WGRAD", "1") != "0"
+    prefetch = os.environ.get("A8_PREFETCH_DRAWS", "1") != "0"
     x = synth(args.batch, args.samples, rank).to(dev)
 
     def one_step():
         stepper.zero_grad()
         loss = loss_fn(model, x)
         loss.backward()
+        if prefetch:
+            W.prefetch_host_draws(model, loss_fn, x.shape, dev)   # next step's numpy draws, while the GPU runs this backward
         lv = loss.item()                       # audio8/pretrain.py:180
         stepper.step()
         return lv

@@ -131,6 +131,44 @@ def test_training_step_with_dropout_runs_and_is_deterministic(restore_dtype):
     np.testing.assert_allclose(vals[0][0], vals[1][0], rtol=1e-4)
 
 
+def test_prefetched_host_draws_are_bit_identical(restore_dtype):
+    """Two training steps with the next step's numpy draws taken ahead of time (prefetch_host_draws, right after
+    backward) sample exactly the masks / negatives of two steps that draw inline -- same global-RNG call order --
+    and give the same losses; a plan that does not fit the next forward raises."""
+    from audio8_amd import ops, wav2vec2 as W
+    ops.set_compute_dtype(torch.float32)
+    torch.manual_seed(0)
+    model = W.create_model(num_layers=2, dropout=0.0, dropout_input=0.0, dropout_features=0.0).cuda().train()
+    loss_fn = W.create_loss(640, 100)
+    x = synth(2, 16000).cuda()
+
+    def steps(prefetch):
+        np.random.seed(11)
+        vals, logits = [], []
+        for step in range(3):
+            torch.manual_seed(200 + step)              # Gumbel noise of the quantiser
+            ops.reset_seed_stream()
+            model.zero_grad()
+            loss = loss_fn(model, x)
+            loss.backward()
+            if prefetch and step < 2:
+                assert W.prefetch_host_draws(model, loss_fn, x.shape) is not None
+            vals.append(loss.item())
+            logits.append(loss_fn.last_logits.float().cpu().numpy().copy())   # depends on every mask row and negative index
+        return vals, logits, np.random.random()
+    v0, l0, r0 = steps(False)
+    v1, l1, r1 = steps(True)
+    np.testing.assert_allclose(v0, v1, rtol=1e-6)
+    for a, b in zip(l0, l1):
+        np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6)
+    assert r0 == r1                                    # the global numpy RNG ends in the same state
+    # a stale plan for another shape is refused
+    W.prefetch_host_draws(model, loss_fn, (2, 24000))
+    with pytest.raises(RuntimeError):
+        loss_fn(model, x)
+    assert not W._PLANS
+
+
 def test_ctc_finetune_parity_f32(restore_dtype):
     from audio8_amd import ops, wav2vec2 as W, ctc as Cc
     from oracle import ref_cpu as R
