@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--bucket-mb", type=float, default=32.0)
     args = ap.parse_args()
 
+    from audio8_amd import _lib as L
     from audio8_amd import ops, wav2vec2 as W, kernels as K
     from audio8_amd.trainer import Stepper, init_distributed_from_env
     import torch.distributed as dist
@@ -98,6 +99,9 @@ def main():
                       wgrad_side_stream=os.environ.get("A8_SIDE_WGRAD", "1") != "0")
     ops.GROUP_WGRAD = os.environ.get("A8_GROUP_WGRAD", "1") != "0"
     prefetch = os.environ.get("A8_PREFETCH_DRAWS", "1") != "0"
+    for kv in filter(None, os.environ.get("A8_TUNE", "").split(",")):       # developer knobs, e.g. A8_TUNE=5=0,1=403
+        k, v = kv.split("=")
+        L.check(L.lib().a8_set_tuning(int(k), int(v)), "a8_set_tuning")
     x = synth(args.batch, args.samples, rank).to(dev)
 
     def one_step():
