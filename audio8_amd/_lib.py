@@ -56,7 +56,7 @@ ARGTYPES = {
     "a8_log_softmax_fwd": [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p],
     "a8_log_softmax_bwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "a8_sumsq": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p],
-    "a8_adamw": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p],
+    "a8_adamw": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_void_p],
 }
 
 

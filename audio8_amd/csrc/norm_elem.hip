@@ -440,9 +440,9 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
     if (threadIdx.x == 0) atomicAdd(out, s);
 }
 
-__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+__global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                              long long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s,
-                             const float* __restrict__ gnorm_sq, float max_norm, float grad_scale) {
+                             const float* __restrict__ gnorm_sq, float max_norm, float grad_scale, int zero_grad) {
     float clip = grad_scale;
     if (gnorm_sq && max_norm > 0.f) {
         const float nrm = sqrtf(gnorm_sq[0]) * grad_scale;
@@ -451,6 +451,7 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     const float step = lr / bc1;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float gi = g[i] * clip;
+        if (zero_grad) g[i] = 0.f;                      // the next step accumulates into a clean buffer: no separate fill pass
         const float mi = b1 * m[i] + (1.f - b1) * gi;
         const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
         m[i] = mi; v[i] = vi;
@@ -614,13 +615,13 @@ extern "C" int a8_sumsq(const float* x, int64_t n, float* out, void* stream) {
     hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4 + 1, 1024)), dim3(256), 0, (hipStream_t)stream, x, (long long)n, out);
     return a8_check_launch("a8_sumsq");
 }
-extern "C" int a8_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                        float weight_decay, int step, const float* gnorm_sq, float max_norm, float grad_scale, void* stream) {
+extern "C" int a8_adamw(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int step, const float* gnorm_sq, float max_norm, float grad_scale, int zero_grad, void* stream) {
     A8_REQUIRE(step >= 1, "a8_adamw: step counts from 1");
     if (n == 0) return A8_OK;
     const float bc1 = 1.0f - powf(beta1, (float)step);
     const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n, lr, beta1, beta2, eps,
-                       weight_decay, bc1, bc2s, gnorm_sq, max_norm, grad_scale);
+                       weight_decay, bc1, bc2s, gnorm_sq, max_norm, grad_scale, zero_grad);
     return a8_check_launch("a8_adamw");
 }

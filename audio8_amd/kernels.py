@@ -348,9 +348,9 @@ def sumsq_(x, out):
     L.check(L.lib().a8_sumsq(L.ptr(x), int(x.numel()), L.ptr(out), L.stream()), "a8_sumsq")
 
 
-def adamw_(p, g, m, v, lr, beta1, beta2, eps, wd, step, gnorm_sq=None, max_norm=0.0, grad_scale=1.0):
+def adamw_(p, g, m, v, lr, beta1, beta2, eps, wd, step, gnorm_sq=None, max_norm=0.0, grad_scale=1.0, zero_grad=False):
     L.check(L.lib().a8_adamw(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), int(p.numel()), _f(lr), _f(beta1), _f(beta2), _f(eps), _f(wd),
-                             int(step), L.ptr(gnorm_sq), _f(max_norm), _f(grad_scale), L.stream()), "a8_adamw")
+                             int(step), L.ptr(gnorm_sq), _f(max_norm), _f(grad_scale), 1 if zero_grad else 0, L.stream()), "a8_adamw")
 
 
 # ----------------------------------------------------------------------------- weight preparation

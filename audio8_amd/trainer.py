@@ -62,8 +62,9 @@ class FlatState:
             done.add(id(p))
         return out
 
-    def zero_grad(self):
-        self.flat_g.zero_()
+    def zero_grad(self, already_clean=False):
+        if not already_clean:
+            self.flat_g.zero_()
         for p, o in zip(self.params, self.offsets):      # keep .grad bound to the flat views
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
                 p.grad = self.flat_g[o:o + p.numel()].view_as(p)
@@ -240,6 +241,7 @@ class Stepper:
         self.lr_function = lr_function
         self.global_step = 0
         self.gnorm_sq = torch.zeros(1, device=self.state.flat_p.device, dtype=torch.float32)
+        self._grads_clean = False
         ops.DIRECT_GRADS = True
         ops.GRAD_READY_HOOK = self.reducer.param_ready
         self.wgrad_stream = torch.cuda.Stream() if (wgrad_side_stream and self.state.flat_p.is_cuda) else None
@@ -268,7 +270,8 @@ class Stepper:
     def zero_grad(self):
         if self.wcache is not None and any(p._version != v for p, v in zip(self.state.params, self._versions)):
             self.refresh_weights()                        # someone wrote to a parameter through torch since the last step
-        self.state.zero_grad()
+        self.state.zero_grad(already_clean=self._grads_clean)     # step() cleared the buffer behind its read
+        self._grads_clean = False
         self.reducer.begin_step()
 
     def close(self):
@@ -289,7 +292,8 @@ class Stepper:
         self.gnorm_sq.zero_()
         K.sumsq_(self.state.flat_g, self.gnorm_sq)
         K.adamw_(self.state.flat_p, self.state.flat_g, self.state.flat_m, self.state.flat_v, self.current_lr, self.betas[0], self.betas[1],
-                 self.eps, self.wd, self.global_step, self.gnorm_sq, self.clip, scale)
+                 self.eps, self.wd, self.global_step, self.gnorm_sq, self.clip, scale, zero_grad=True)
+        self._grads_clean = True
         if self.wcache is not None:
             self.wcache.refresh()
 

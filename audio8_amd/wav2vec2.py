@@ -262,9 +262,20 @@ def prefetch_host_draws(model, loss_fn, batch_shape, device="cuda"):
     Tm = int(mask_np[0].sum())
     n_neg = loss_fn.sample.n_negatives
     idx = loss_fn.sample.indices(B, Tm).reshape(B * Tm, n_neg)
-    plan = HostDraws((id(model), B, T), _mask_to_device(mask_np, device), draws, ops.host_i32(idx, device), (B * Tm, n_neg))
+    # uploads go on their own stream: on the compute stream they would queue behind the whole backward and sit between
+    # it and the loss read-back / optimizer
+    global _UPLOAD_STREAM
+    if _UPLOAD_STREAM is None:
+        _UPLOAD_STREAM = torch.cuda.Stream()
+    with torch.cuda.stream(_UPLOAD_STREAM):
+        plan = HostDraws((id(model), B, T), _mask_to_device(mask_np, device), draws, ops.host_i32(idx, device), (B * Tm, n_neg))
+        plan.ready = torch.cuda.Event()
+        plan.ready.record(_UPLOAD_STREAM)
     _PLANS.append(plan)
     return plan
+
+
+_UPLOAD_STREAM = None
 
 
 def _take_plan(model, B, T):
@@ -274,6 +285,10 @@ def _take_plan(model, B, T):
     if plan.key != (id(model), B, T) or not model.training:
         _PLANS.clear()
         raise RuntimeError("a8hip: prefetched host draws %s do not match this forward %s" % (plan.key[1:], (B, T)))
+    cur = torch.cuda.current_stream()
+    cur.wait_event(plan.ready)
+    for t in (plan.mask_dev[0], plan.mask_dev[2], plan.neg_idx):     # allocated on the upload stream, consumed here
+        t.record_stream(cur)
     return plan
 
 

@@ -179,10 +179,11 @@ int a8_log_softmax_fwd(const void* x, int dtype, float* y, int rows, int cols, v
 int a8_log_softmax_bwd(const float* y, const float* dy, void* dx, int dtype, int rows, int cols, void* stream);
 
 /* ---- optimizer step either side of the path (clip_grad_norm_ + AdamW, audio8/pretrain.py:182-184) ----
- * a8_sumsq: out[0] += sum x^2 ;  a8_adamw: p,m,v updated in place with g * min(1, max_norm / (sqrt(gnorm_sq[0]) + 1e-6)). */
+ * a8_sumsq: out[0] += sum x^2 ;  a8_adamw: p,m,v updated in place with g * min(1, max_norm / (sqrt(gnorm_sq[0]) + 1e-6));
+ * zero_grad != 0 also clears g behind the read (optimizer.zero_grad() of the next step, audio8/pretrain.py:177, for free). */
 int a8_sumsq(const float* x, int64_t n, float* out, void* stream);
-int a8_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-             float weight_decay, int step, const float* gnorm_sq, float max_norm, float grad_scale, void* stream);
+int a8_adamw(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+             float weight_decay, int step, const float* gnorm_sq, float max_norm, float grad_scale, int zero_grad, void* stream);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,8 @@ import sys
 def per_kernel(d, counter, match):
     rows = [r for r in csv.DictReader(open(glob.glob(d + "/*/*counter_collection.csv")[0])) if r["Counter_Name"] == counter]
     # every gemm launch except the explicit f32 instantiations (the trace mixes mangled and demangled names)
-    sel = [r for r in rows if match in r["Kernel_Name"] and "<float" not in r["Kernel_Name"] and "gemm_kernelIfL" not in r["Kernel_Name"]]
+    sel = [r for r in rows if (match in r["Kernel_Name"] or "gemm_grouped_kernel" in r["Kernel_Name"]) and "<float" not in r["Kernel_Name"]
+           and "gemm_kernelIfL" not in r["Kernel_Name"] and "gemm_grouped_kernelIfL" not in r["Kernel_Name"]]
     return sum(float(r["Counter_Value"]) for r in sel), len(sel)
 
 
@@ -21,7 +22,7 @@ def main():
     w, nw = per_kernel(write_dir, "WRITE_SIZE", "gemm_kernel")
     fetch_bytes = f * 1024 * 2           # gfx950 correction
     write_bytes = w * 1024
-    res = {"kernel": "gemm_kernel<bf16>", "launches_profiled": nf, "steps_profiled": steps,
+    res = {"kernel": "gemm_kernel<bf16> + gemm_grouped_kernel<bf16>", "launches_profiled": nf, "steps_profiled": steps,
            "fetch_bytes_per_launch": fetch_bytes / max(1, nf), "write_bytes_per_launch": write_bytes / max(1, nw),
            "hbm_bytes_per_launch": fetch_bytes / max(1, nf) + write_bytes / max(1, nw),
            "hbm_bytes_per_step": (fetch_bytes + write_bytes) / steps,
