@@ -300,7 +300,16 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
             else *cp = v;
             csum += v;
         }
-        if (g.colsum && n_ok) atomicAdd(g.colsum + n, csum);
+        if (g.colsum) {                                  // block-uniform: combine the NWM row-waves in LDS, one atomic per column per block
+            cw[lane] = csum;                             // the wave is done with its staging area
+            __syncthreads();
+            if (wm == 0) {
+                float t = 0.f;
+#pragma unroll
+                for (int q = 0; q < NWM; ++q) t += reinterpret_cast<const float*>(lds)[(q * 2 + wn) * (WROWS * 64) + lane];
+                if (n_ok) atomicAdd(g.colsum + n, t);
+            }
+        }
     } else {
         // 16-bit output: lane owns 8 consecutive columns (16 B), a wave-instruction covers 8 rows x 128 B
         const int c8 = (lane & 7) << 3;                 // first column within the wave's 64
@@ -352,9 +361,16 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
                 t += __shfl_xor(t, 32, 64);
                 csum[e] = t;
             }
-            if (lane < 8 && n_ok) {
+            if (lane < 8) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) atomicAdd(g.colsum + n + e, csum[e]);
+                for (int e = 0; e < 8; ++e) cw[lane * 8 + e] = csum[e];      // the wave is done with its staging area
+            }
+            __syncthreads();
+            if (wm == 0) {                               // one atomic per column per block (128 per tile)
+                float t = 0.f;
+#pragma unroll
+                for (int q = 0; q < NWM; ++q) t += reinterpret_cast<const float*>(lds)[(q * 2 + wn) * (WROWS * 64) + lane];
+                if (nw + lane < g.N) atomicAdd(g.colsum + nw + lane, t);
             }
         }
     }
