@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "liba8hip.so")
 
 F32, BF16 = 0, 1
 NT, NN, TN = 0, 1, 2
-ACT_NONE, ACT_GELU, ACT_MUL_GELU_GRAD = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_MUL_GELU_GRAD, ACT_ADD = 0, 1, 2, 3
 
 _lib = None
 _dev_index = None

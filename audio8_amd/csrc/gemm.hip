@@ -294,6 +294,7 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
             if (g.zout) reinterpret_cast<T*>(g.zout)[zrow(m) + n] = from_f<T>(v);
             if (g.act == A8_ACT_GELU) v = gelu_f(v);
             else if (g.act == A8_ACT_MUL_GELU_GRAD) v *= gelu_grad_f(to_f(reinterpret_cast<const T*>(g.zin)[zrow(m) + n]));
+            else if (g.act == A8_ACT_ADD) v += to_f(reinterpret_cast<const T*>(g.zin)[zrow(m) + n]);
             const long long crow = g.c_rpb ? (m / g.c_rpb) * g.c_bs + (m % g.c_rpb) * g.ldc : (long long)m * g.ldc;
             float* cp = reinterpret_cast<float*>(g.C) + crow + n;
             if (g.atomic) atomicAdd(cp, v);
@@ -345,6 +346,10 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
                 const T8 zz = *reinterpret_cast<const T8*>(reinterpret_cast<const T*>(g.zin) + zrow(m) + n);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(to_f(zz[e]));
+            } else if (g.act == A8_ACT_ADD) {
+                const T8 zz = *reinterpret_cast<const T8*>(reinterpret_cast<const T*>(g.zin) + zrow(m) + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += to_f(zz[e]);
             }
             const long long crow = g.c_rpb ? (m / g.c_rpb) * g.c_bs + (m % g.c_rpb) * g.ldc : (long long)m * g.ldc;
             T8 ov;
@@ -464,7 +469,7 @@ static int build_args(const a8_gemm_desc* d, GemmArgs& g, long long* grid) {
     g.atomic = (nsplit > 1 || d->accumulate) ? 1 : 0;
     A8_REQUIRE(!(g.atomic && !d->out_f32), "a8_gemm: split-K / accumulate needs an f32 output");
     A8_REQUIRE(!(nsplit > 1 && (d->bias || d->act || d->zout || d->colsum)), "a8_gemm: split-K cannot carry a bias/activation/colsum epilogue");
-    A8_REQUIRE(d->act != A8_ACT_MUL_GELU_GRAD || d->zin, "a8_gemm: MUL_GELU_GRAD needs zin");
+    A8_REQUIRE((d->act != A8_ACT_MUL_GELU_GRAD && d->act != A8_ACT_ADD) || d->zin, "a8_gemm: MUL_GELU_GRAD / ADD need zin");
     *grid = (long long)g.tiles_m * g.tiles_n * nsplit;
     A8_REQUIRE(*grid < (1ll << 30), "a8_gemm: grid too large");
     return A8_OK;

@@ -680,8 +680,7 @@ class EncoderLayerFn(torch.autograd.Function):
             gq = (dwqkv[:d], dbqkv[:d], dwqkv[d:2 * d], dbqkv[d:2 * d], dwqkv[2 * d:], dbqkv[2 * d:])
         if wg is not None:
             wg.flush()                 # all four operand pairs are enqueued; the side stream waits for exactly that
-        dx_qkv = _dgrad(dqkv, wqkv_c, wqkv_t, M, d, 3 * d)
-        dx = K.add(dx_res, dx_qkv)
+        dx = _dgrad(dqkv, wqkv_c, wqkv_t, M, d, 3 * d, act=L.ACT_ADD, zin=dx_res, ldz=d)     # + the residual branch's gradient
         return (dx, None, None, None, None, None, None, *gq, dwo, dbo, dw1, db1, dw2, db2, dg1, dbe1, dg2, dbe2)
 
 

@@ -23,7 +23,7 @@ extern "C" {
 
 enum { A8_DT_F32 = 0, A8_DT_BF16 = 1 };
 enum { A8_GEMM_NT = 0, A8_GEMM_NN = 1, A8_GEMM_TN = 2 };
-enum { A8_ACT_NONE = 0, A8_ACT_GELU = 1, A8_ACT_MUL_GELU_GRAD = 2 };
+enum { A8_ACT_NONE = 0, A8_ACT_GELU = 1, A8_ACT_MUL_GELU_GRAD = 2, A8_ACT_ADD = 3 };
 
 int a8_version(void);
 const char* a8_last_error(void);      /* thread-local text of the last non-zero status */
@@ -41,7 +41,7 @@ typedef struct a8_gemm_desc {
     const void* B; int64_t ldb, b_rpb, b_bs;
     void* C;       int64_t ldc, c_rpb, c_bs;
     const float* bias;  int bias_rows;   /* bias[N] (or bias[M] when bias_rows) */
-    int act;                              /* A8_ACT_* ; MUL_GELU_GRAD multiplies by gelu'(zin) */
+    int act;                              /* A8_ACT_* ; MUL_GELU_GRAD multiplies by gelu'(zin); ADD adds zin (residual gradient) */
     const void* zin; void* zout; int64_t ldz, z_rpb, z_bs;   /* zout: pre-activation copy (dtype); z rows use their own remap */
     int out_f32;                          /* C is f32 regardless of dtype */
     int accumulate;                       /* C += (f32 atomics) */

@@ -168,3 +168,14 @@ def test_gemm_grouped(dtype, layout):
     outs = Kn.gemm_grouped(L.TN if layout == "TN" else L.NT, probs)
     for o, r in zip(outs, refs):
         np.testing.assert_array_equal(o.double().cpu().numpy(), r.numpy())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_add_epilogue(dtype):
+    from audio8_amd import kernels as Kn, _lib as L
+    M, N, K = 200, 136, 104
+    A, B, R = _mk((M, K), dtype, 31, integer=True), _mk((N, K), dtype, 32, integer=True), _mk((M, N), dtype, 33, integer=True)
+    out = Kn.gemm(L.NT, A.cuda(), B.cuda(), M, N, K, act=L.ACT_ADD, zin=R.cuda())
+    ref = A.double() @ B.double().T + R.double()
+    tol = 0 if dtype == torch.float32 else 1e-2
+    np.testing.assert_allclose(out.double().cpu().numpy(), ref.numpy(), rtol=tol, atol=tol)
