@@ -36,10 +36,14 @@ __global__ __launch_bounds__(256) void wprep_kernel(const float* __restrict__ sr
     }
 }
 
-// single-launch variant: blockIdx.x walks a prefix table of 32x32 tiles over all matrices
+// single-launch variant: blockIdx.x walks a prefix table of 64x64 tiles over all matrices.  Reads are 256-byte row
+// segments of the f32 master, the row-major copy leaves as 128-byte segments, and the transposed copy is written as
+// 16-byte (8 x bf16) pieces of 128-byte transposed rows out of a padded LDS tile (the 32x32 / 2-byte-store version ran
+// at 2.4 TB/s).
+constexpr int WT = 64;
 template <typename T>
 __global__ __launch_bounds__(256) void wprep_multi_kernel(const a8_wprep_desc* __restrict__ descs, const int* __restrict__ tile_start, int n) {
-    __shared__ float tile[32][33];
+    __shared__ float tile[WT][WT + 1];
     // binary search: largest i with tile_start[i] <= blockIdx.x
     int lo = 0, hi = n - 1;
     while (lo < hi) {
@@ -48,33 +52,66 @@ __global__ __launch_bounds__(256) void wprep_multi_kernel(const a8_wprep_desc* _
     }
     const a8_wprep_desc d = descs[lo];
     const int tl = blockIdx.x - tile_start[lo];
-    const int tcols = (d.cols + 31) >> 5;
-    const int c0 = (tl % tcols) * 32, r0 = (tl / tcols) * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int tcols = (d.cols + WT - 1) / WT;
+    const int c0 = (tl % tcols) * WT, r0 = (tl / tcols) * WT;
     const int cin = d.cols / d.kw;
     T* dst = reinterpret_cast<T*>(d.dst);
     T* dstT = reinterpret_cast<T*>(d.dstT);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = r0 + ty + 8 * j, c = c0 + tx;
-        float v = 0.f;
-        if (r < d.rows && c < d.cols) {
-            if (d.tap >= 0) {
-                v = d.src[((long long)r * d.cols + c) * d.kw + d.tap];
-            } else {
-                const int kk = c / cin, ci = c - kk * cin;
-                v = d.src[(long long)r * d.cols + (long long)ci * d.kw + kk];
-            }
-            if (dst) dst[(long long)r * (d.ld_dst ? d.ld_dst : d.cols) + c] = from_f<T>(v);
-        }
-        tile[ty + 8 * j][tx] = v;
-    }
-    __syncthreads();
-    if (dstT) {
+    const long long ldd = d.ld_dst ? d.ld_dst : d.cols, ldt = d.ld_dstT ? d.ld_dstT : d.rows;
+    const bool plain = d.kw == 1 && d.tap < 0 && (d.cols & 3) == 0;
+    {   // load (+ row-major copy): thread -> rows ty + 16 j, columns 4 tx .. 4 tx + 3
+        const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int c = c0 + ty + 8 * j, r = r0 + tx;
-            if (r < d.rows && c < d.cols) dstT[(long long)c * (d.ld_dstT ? d.ld_dstT : d.rows) + r] = from_f<T>(tile[tx][ty + 8 * j]);
+            const int rl = ty + 16 * j, r = r0 + rl, c = c0 + 4 * tx;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (r < d.rows) {
+                if (plain && c + 3 < d.cols) {
+                    const f32x4 q = *reinterpret_cast<const f32x4*>(d.src + (long long)r * d.cols + c);
+                    v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int cc = c + e;
+                        if (cc < d.cols) {
+                            if (d.tap >= 0) {
+                                v[e] = d.src[((long long)r * d.cols + cc) * d.kw + d.tap];
+                            } else {
+                                const int kk = cc / cin, ci = cc - kk * cin;        // logical column = kk*cin + ci
+                                v[e] = d.src[(long long)r * d.cols + (long long)ci * d.kw + kk];
+                            }
+                        }
+                    }
+                }
+                if (dst) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (c + e < d.cols) dst[(long long)r * ldd + c + e] = from_f<T>(v[e]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[rl][4 * tx + e] = v[e];
+        }
+    }
+    __syncthreads();
+    if (dstT) {   // transposed copy: thread -> transposed rows (columns) ty + 32 j, source rows 8 tx .. 8 tx + 7
+        const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int cl = ty + 32 * j, c = c0 + cl, r = r0 + 8 * tx;
+            if (c >= d.cols) continue;
+            T* o = dstT + (long long)c * ldt + r;
+            if (r + 7 < d.rows && ((ldt * (long long)sizeof(T)) & 15) == 0 && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
+                typedef T T8 __attribute__((ext_vector_type(8)));
+                T8 q;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) q[e] = from_f<T>(tile[8 * tx + e][cl]);
+                *reinterpret_cast<T8*>(o) = q;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (r + e < d.rows) o[e] = from_f<T>(tile[8 * tx + e][cl]);
+            }
         }
     }
 }
@@ -96,7 +133,7 @@ extern "C" int a8_prepare_weights(int dtype, const a8_wprep_desc* descs, int n, 
     return a8_check_launch("a8_prepare_weights");
 }
 
-// descs/tile_start live in DEVICE memory (built once by the host); tile_start[i] = first 32x32-tile index of matrix i,
+// descs/tile_start live in DEVICE memory (built once by the host); tile_start[i] = first 64x64-tile index of matrix i,
 // total_tiles = tile_start[n].  One launch prepares every weight of the model.
 extern "C" int a8_prepare_weights_device(int dtype, const a8_wprep_desc* descs_dev, const int* tile_start_dev, int n, int total_tiles, void* stream) {
     A8_REQUIRE(dtype == A8_F32 || dtype == A8_BF16, "a8_prepare_weights_device: bad dtype");

@@ -129,7 +129,7 @@ class WeightCache:
         for i, (src, r, c, kw, tap, dst, dst_t, ld, ld_t) in enumerate(jobs):
             self.descs[i] = L.WPrepDesc(src.data_ptr(), dst.data_ptr() if dst is not None else None,
                                         dst_t.data_ptr() if dst_t is not None else None, r, c, kw, tap, ld, ld_t)
-            starts.append(starts[-1] + ((r + 31) // 32) * ((c + 31) // 32))
+            starts.append(starts[-1] + ((r + 63) // 64) * ((c + 63) // 64))
         self.params = [j[0] for j in jobs]
         self._src_ptrs = [p.data_ptr() for p in self.params]
         raw = np.frombuffer(C.string_at(C.addressof(self.descs), C.sizeof(self.descs)), dtype=np.uint8).copy()

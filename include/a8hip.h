@@ -67,7 +67,7 @@ typedef struct a8_wprep_desc {
     int ld_dst, ld_dstT;     /* leading dimensions of dst / dstT (0: dense) */
 } a8_wprep_desc;
 int a8_prepare_weights(int dtype, const a8_wprep_desc* descs /* host array */, int n, void* stream);
-/* one-launch form: descs and tile_start (n+1 ints, prefix sums of ceil(rows/32)*ceil(cols/32)) in device memory */
+/* one-launch form: descs and tile_start (n+1 ints, prefix sums of ceil(rows/64)*ceil(cols/64)) in device memory */
 int a8_prepare_weights_device(int dtype, const a8_wprep_desc* descs_dev, const int* tile_start_dev, int n, int total_tiles, void* stream);
 
 /* ---- conv layer 0 + GroupNorm + GELU (audio8/wav2vec2.py:417-423, Cin=1, k=10, s=5) --------------

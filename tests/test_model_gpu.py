@@ -331,3 +331,40 @@ def test_stepper_bf16_weight_cache_matches_uncached(restore_dtype):
         assert torch.equal(after[0], w.detach().to(torch.bfloat16)) and torch.equal(after[1], w.detach().to(torch.bfloat16).t())
     finally:
         st.close()
+
+
+def test_weight_cache_contents_match_masters(restore_dtype):
+    """Every working copy the single-launch weight preparation writes: row-major bf16 copy, its transpose, the conv
+    [co][kk*cin+ci] re-layout and the even/odd tap matrices of the stride-2 conv data gradient."""
+    from audio8_amd import ops, wav2vec2 as W
+    from audio8_amd.trainer import Stepper
+    ops.set_compute_dtype(torch.bfloat16)
+    torch.manual_seed(3)
+    mdl = W.create_model(num_layers=1).cuda().train()
+    st = Stepper(mdl)
+    try:
+        torch.cuda.synchronize()
+        params = {id(p): (n, p) for n, p in mdl.named_parameters()}
+        checked = 0
+        for pid, (dst, dst_t) in ops.WEIGHT_CACHE.items():
+            n, p = params[pid]
+            w = p.detach()
+            if w.dim() == 3:
+                co, cin, kw = w.shape
+                w2 = w.permute(0, 2, 1).reshape(co, kw * cin)
+            else:
+                w2 = w
+                if dst.shape[0] == 3 * w.shape[0]:          # fused QKV span
+                    a = mdl.encoder.transformer.encoders[0].self_attn
+                    w2 = torch.cat([a.w_Q.layer.weight, a.w_K.layer.weight, a.w_V.layer.weight], 0).detach()
+            assert torch.equal(dst, w2.to(torch.bfloat16)), n
+            assert torch.equal(dst_t, w2.t().contiguous().to(torch.bfloat16)), n
+            checked += 1
+        assert checked > 10
+        for pid, (b_even, b_odd) in ops.CONV_DGRAD_CACHE.items():
+            n, p = params[pid]
+            w = p.detach()                                   # [co, cin, 3]
+            assert torch.equal(b_even, torch.cat([w[:, :, 2].t(), w[:, :, 0].t()], 1).contiguous().to(torch.bfloat16)), n
+            assert torch.equal(b_odd, w[:, :, 1].t().contiguous().to(torch.bfloat16)), n
+    finally:
+        st.close()
