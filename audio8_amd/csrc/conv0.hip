@@ -94,22 +94,27 @@ __global__ __launch_bounds__(256) void conv0_stats_kernel(const float* __restric
     }
 }
 
-// ---- forward pass 2: (mean, rstd) per (b,c) in f64
+// ---- forward pass 2: (mean, rstd) per (b,c) in f64; 16 lanes share one (b,c) and stride over its chunks
 __global__ void conv0_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats, int B, int nchunk, int L0, float eps) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * CC) return;
-    const int b = i / CC, c = i % CC;
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, sub = threadIdx.x & 15;
     double s = 0.0, q = 0.0;
-    for (int ch = 0; ch < nchunk; ++ch) {
-        const float* p = part + (((long long)b * nchunk + ch) * CC + c) * 2;
-        s += (double)p[0];
-        q += (double)p[1];
+    if (i < B * CC) {
+        const int b = i / CC, c = i % CC;
+        for (int ch = sub; ch < nchunk; ch += 16) {
+            const float* p = part + (((long long)b * nchunk + ch) * CC + c) * 2;
+            s += (double)p[0];
+            q += (double)p[1];
+        }
     }
-    const double mu = s / L0;
-    double var = q / L0 - mu * mu;
-    if (var < 0.0) var = 0.0;
-    stats[i * 2 + 0] = (float)mu;
-    stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    if (i < B * CC && sub == 0) {
+        const double mu = s / L0;
+        double var = q / L0 - mu * mu;
+        if (var < 0.0) var = 0.0;
+        stats[i * 2 + 0] = (float)mu;
+        stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
 }
 
 // ---- forward pass 3: out = gelu(gn(conv(x)))
@@ -284,7 +289,7 @@ extern "C" int a8_conv0_gn_gelu_fwd(int dtype, const float* x, const float* w, c
     const int L0 = conv0_out_len(L), nchunk = cdiv(L0, CHF);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(conv0_stats_kernel, dim3(nchunk, B), dim3(256), 0, s, x, w, part, L, L0, nchunk);
-    hipLaunchKernelGGL(conv0_finalize_kernel, dim3(cdiv(B * CC, 256)), dim3(256), 0, s, part, stats, B, nchunk, L0, eps);
+    hipLaunchKernelGGL(conv0_finalize_kernel, dim3(cdiv(B * CC * 16, 256)), dim3(256), 0, s, part, stats, B, nchunk, L0, eps);
     if (dtype == A8_BF16)
         hipLaunchKernelGGL(conv0_apply_kernel<bf16>, dim3(nchunk, B), dim3(256), 0, s, x, w, gn_w, gn_b, stats, (bf16*)out, L, L0);
     else

@@ -163,7 +163,10 @@ __global__ __launch_bounds__(256) void posconv_wgrad_kernel(const char* __restri
 #pragma unroll
             for (int j = 0; j < NB; ++j) acc[a][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nt = (Tn + WG_BT - 1) / WG_BT;
-    for (int it = 0; it < B * nt; ++it) {
+    // blockIdx.z splits the (utterance, 64-frame chunk) loop: 256 (group, tap-block) pairs alone leave one 4-wave block per CU
+    const int per = (B * nt + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int it_end = min(B * nt, ((int)blockIdx.z + 1) * per);
+    for (int it = blockIdx.z * per; it < it_end; ++it) {
         const int b = it / nt, t0 = (it % nt) * WG_BT;
         const T* xb = reinterpret_cast<const T*>(xp) + (long long)b * Tn * d + grp * DG;
         const T* zb = reinterpret_cast<const T*>(dzp) + (long long)b * Tn * d + grp * DG;
@@ -275,7 +278,7 @@ extern "C" int a8_posconv_wgrad(int dtype, const void* x, const void* dz, float*
     const int dg = d / groups;
     A8_REQUIRE(dg == 48 || dg == 64, "a8_posconv_wgrad: channels per group must be 48 or 64 (got %d)", dg);
     A8_REQUIRE(dtype == A8_F32 || dtype == A8_BF16, "a8_posconv_wgrad: bad dtype");
-    const dim3 grid(KW / WG_TAPS, groups);
+    const dim3 grid(KW / WG_TAPS, groups, g_a8_tuning[6] > 0 ? g_a8_tuning[6] : 1);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == A8_BF16) {
         if (dg == 48) hipLaunchKernelGGL((posconv_wgrad_kernel<bf16, 48>), grid, dim3(256), 0, s, (const char*)x, (const char*)dz, dw, B, T_, d, pad_left);

@@ -203,11 +203,21 @@ __global__ __launch_bounds__(256) void contrastive_fwd_kernel(const T* __restric
     if (threadIdx.x == 0) atomicAdd(loss_sum, lsum);
 }
 
-template <typename T>
+// Backward, two kernels.
+//  rows kernel (one wave per masked frame): softmax weights dl[n]; dctx = sum_n dl*(t_n*ic*it_n - cos_n*c*ic^2); stores the
+//  per-pair coefficients wA = dl*ic and wU = dl*cos.  The gradient of candidate row j is then
+//      dlat[j] = it_j * sum_{(row,n)->j} wA*c_row  -  t_j * it_j^2 * sum_{(row,n)->j} wU
+//  A frame's negatives come from its own utterance (rows_per_group consecutive rows), so the first sum is a small dense
+//  product per utterance: scatter wA into W_b[frame][candidate] (3e5 scalar atomics), then G_b = W_b^T C_b as an exact-f32
+//  grouped GEMM, then one combine pass -- instead of 7.6e7 global f32 atomics at 8 x 368 frames x 101 candidates.
+//  (Accumulating the rows in LDS with ds_add_f32 was tried first: ~0.3 atomics per clock per CU, 3x slower than the
+//  global scatter.)  Pairs that point outside the group (never produced by Sampler) are scattered directly.
+template <typename T, bool SCATTER>
 __global__ __launch_bounds__(256) void contrastive_bwd_kernel(const T* __restrict__ ctx, const T* __restrict__ lat, const int32_t* __restrict__ idx,
                                                               const float* __restrict__ inv_ctx, const float* __restrict__ inv_lat,
                                                               const float* __restrict__ logits, const float* __restrict__ gscale,
-                                                              float* __restrict__ dctx, float* __restrict__ dlat, int rows, int N) {
+                                                              float* __restrict__ dctx, float* __restrict__ dlat,
+                                                              float* __restrict__ wA, float* __restrict__ wU, int rows, int N) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const float gs = gscale[0];
     for (int row = blockIdx.x * 4 + wv; row < rows; row += gridDim.x * 4) {
@@ -221,6 +231,11 @@ __global__ __launch_bounds__(256) void contrastive_bwd_kernel(const T* __restric
 #pragma unroll
         for (int i = 0; i < CPL; ++i) dc[i] = 0.f;
         const float ic = inv_ctx[row];
+        if constexpr (!SCATTER) {
+            const float d0 = gs * (e0 * inv_s - (lane == 0 ? 1.f : 0.f)), d1 = gs * e1 * inv_s;
+            if (lane <= N) { wA[(long long)row * (N + 1) + lane] = d0 * ic; wU[(long long)row * (N + 1) + lane] = d0 * l0; }
+            if (lane + 64 <= N) { wA[(long long)row * (N + 1) + lane + 64] = d1 * ic; wU[(long long)row * (N + 1) + lane + 64] = d1 * l1; }
+        }
         for (int n = 0; n <= N; ++n) {
             const int tr = n == 0 ? row : idx[(long long)row * N + n - 1];
             const float lg = n < 64 ? __shfl(l0, n, 64) : __shfl(l1, n - 64, 64);
@@ -235,13 +250,46 @@ __global__ __launch_bounds__(256) void contrastive_bwd_kernel(const T* __restric
 #pragma unroll
             for (int i = 0; i < CPL; ++i) {
                 dc[i] += a * tv[i] - bc * c[i];
-                atomicAdd(dlp + lane + 64 * i, a * c[i] - bt * tv[i]);
+                if constexpr (SCATTER) atomicAdd(dlp + lane + 64 * i, a * c[i] - bt * tv[i]);
             }
         }
         float* dp = dctx + (long long)row * 256;
 #pragma unroll
         for (int i = 0; i < CPL; ++i) dp[lane + 64 * i] = dc[i];
     }
+}
+
+// dense per-group coefficient matrix W[grp][frame][candidate row in group] += wA, U[row] += wU  (one thread per pair;
+// ~3e5 scalar atomics instead of 7.6e7 row-element atomics); pairs outside the group are scattered directly.
+template <typename T>
+__global__ void contrastive_w_kernel(const T* __restrict__ ctx, const T* __restrict__ lat, const int32_t* __restrict__ idx,
+                                     const float* __restrict__ inv_lat, const float* __restrict__ wA, const float* __restrict__ wU,
+                                     float* __restrict__ W, float* __restrict__ U, float* __restrict__ dlat, int rows, int rpg, int ldw, int N) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= (long long)rows * (N + 1)) return;
+    const int row = (int)(i / (N + 1)), n = (int)(i % (N + 1));
+    const int tr = n == 0 ? row : idx[(long long)row * N + n - 1];
+    const int base = (row / rpg) * rpg, jl = tr - base;
+    const float a = wA[i], uu = wU[i];
+    if (jl >= 0 && jl < rpg) {
+        atomicAdd(W + (long long)row * ldw + jl, a);
+        atomicAdd(U + tr, uu);
+    } else {
+        const float it = inv_lat[tr];
+        for (int d = 0; d < 256; ++d)
+            atomicAdd(dlat + (long long)tr * 256 + d, it * a * to_f(ctx[(long long)row * 256 + d]) - to_f(lat[(long long)tr * 256 + d]) * it * it * uu);
+    }
+}
+// dlat[j] += it_j * G[j] - t_j * it_j^2 * U[j]   with G = W^T C from the GEMM
+template <typename T>
+__global__ void contrastive_combine_kernel(const T* __restrict__ lat, const float* __restrict__ inv_lat, const float* __restrict__ G,
+                                           const float* __restrict__ U, float* __restrict__ dlat, long long n, int rpg, int rpg4) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long j = i >> 8;
+    const float it = inv_lat[j];
+    const long long gi = ((j / rpg) * rpg4 + j % rpg) * 256 + (i & 255);       // G keeps rpg4 (padded) rows per group
+    dlat[i] += it * G[gi] - to_f(lat[i]) * it * it * U[j];
 }
 
 int gridw(int rows) { int b = (rows + 3) / 4; return b < 1 ? 1 : (b > 2048 ? 2048 : b); }
@@ -305,20 +353,69 @@ extern "C" int a8_contrastive_fwd(int dtype, const void* ctx, const void* lat, c
 }
 
 extern "C" int a8_contrastive_bwd(int dtype, const void* ctx, const void* lat, const int32_t* neg_idx, const float* logits,
-                                  const float* gscale, float* dctx, float* dlat, float* inv_norms, int rows, int N, int Cn, void* stream) {
+                                  const float* gscale, float* dctx, float* dlat, float* scratch, int rows, int N, int Cn,
+                                  int rows_per_group, void* stream) {
     A8_REQUIRE(Cn == 64 * CPL, "a8_contrastive_bwd: C must be %d (got %d)", 64 * CPL, Cn);
     A8_REQUIRE(N >= 1 && N + 1 <= 128, "a8_contrastive_bwd: N=%d must be in [1,127]", N);
+    A8_REQUIRE(dtype == A8_BF16 || dtype == A8_F32, "a8_contrastive_bwd: bad dtype");
     if (rows == 0) return A8_OK;
-    float* ic = inv_norms; float* il = inv_norms + rows;
+    const int rpg = rows_per_group;
+    const bool grouped = rpg > 0 && rows % rpg == 0;
+    const int rpg4 = (rpg + 3) & ~3;                     // the f32 TN GEMM wants M % 4 == 0: W rows are padded with zero columns
+    // scratch: ic[rows] il[rows] wA[rows*(N+1)] wU[rows*(N+1)] | U[rows] W[rows*rpg] Cf[rows*256] G[rows*256]
+    auto al4 = [](size_t n) { return (n + 3) & ~(size_t)3; };              // sub-buffers start 16-byte aligned (GEMM operands)
+    A8_REQUIRE(((uintptr_t)scratch & 15) == 0, "a8_contrastive_bwd: scratch must be 16-byte aligned");
+    float* ic = scratch; float* il = ic + al4(rows);
+    float* wA = il + al4(rows); float* wU = wA + al4((size_t)rows * (N + 1));
+    float* U = wU + al4((size_t)rows * (N + 1));
+    float* W = U + al4(rows);                           // U and W are cleared together
+    float* Cf = W + (size_t)rows * (grouped ? rpg4 : 0);
+    float* G = Cf + (size_t)rows * 256;                  // [groups][rpg4][256]
     hipStream_t s = (hipStream_t)stream;
+    if (grouped && hipMemsetAsync(U, 0, sizeof(float) * (al4(rows) + (size_t)rows * rpg4), s) != hipSuccess)
+        return a8_set_error(A8_ERR_LAUNCH, "a8_contrastive_bwd: memset failed");
+#define A8_CBWD(T)                                                                                                                     \
+    {                                                                                                                                  \
+        hipLaunchKernelGGL(rownorm_kernel<T>, dim3(gridw(rows)), dim3(256), 0, s, (const T*)ctx, ic, rows, Cn);                        \
+        hipLaunchKernelGGL(rownorm_kernel<T>, dim3(gridw(rows)), dim3(256), 0, s, (const T*)lat, il, rows, Cn);                        \
+        if (grouped) {                                                                                                                 \
+            hipLaunchKernelGGL((contrastive_bwd_kernel<T, false>), dim3(gridw(rows)), dim3(256), 0, s, (const T*)ctx, (const T*)lat, neg_idx, ic, il, \
+                               logits, gscale, dctx, dlat, wA, wU, rows, N);                                                           \
+            const long long np = (long long)rows * (N + 1);                                                                            \
+            hipLaunchKernelGGL(contrastive_w_kernel<T>, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, (const T*)ctx, (const T*)lat, neg_idx, \
+                               il, wA, wU, W, U, dlat, rows, rpg, rpg4, N);                                                                  \
+        } else {                                                                                                                       \
+            hipLaunchKernelGGL((contrastive_bwd_kernel<T, true>), dim3(gridw(rows)), dim3(256), 0, s, (const T*)ctx, (const T*)lat, neg_idx, ic, il, \
+                               logits, gscale, dctx, dlat, wA, wU, rows, N);                                                           \
+        }                                                                                                                              \
+    }
+    if (dtype == A8_BF16) A8_CBWD(bf16) else A8_CBWD(float)
+#undef A8_CBWD
+    if (int e = a8_check_launch("a8_contrastive_bwd")) return e;
+    if (!grouped) return A8_OK;
+    // G_b [rpg, 256] = W_b^T [rpg x rpg] . C_b [rpg x 256] in exact f32, 8 utterances per grouped launch
+    const float* cf = (const float*)ctx;
     if (dtype == A8_BF16) {
-        hipLaunchKernelGGL(rownorm_kernel<bf16>, dim3(gridw(rows)), dim3(256), 0, s, (const bf16*)ctx, ic, rows, Cn);
-        hipLaunchKernelGGL(rownorm_kernel<bf16>, dim3(gridw(rows)), dim3(256), 0, s, (const bf16*)lat, il, rows, Cn);
-        hipLaunchKernelGGL(contrastive_bwd_kernel<bf16>, dim3(gridw(rows)), dim3(256), 0, s, (const bf16*)ctx, (const bf16*)lat, neg_idx, ic, il, logits, gscale, dctx, dlat, rows, N);
-    } else if (dtype == A8_F32) {
-        hipLaunchKernelGGL(rownorm_kernel<float>, dim3(gridw(rows)), dim3(256), 0, s, (const float*)ctx, ic, rows, Cn);
-        hipLaunchKernelGGL(rownorm_kernel<float>, dim3(gridw(rows)), dim3(256), 0, s, (const float*)lat, il, rows, Cn);
-        hipLaunchKernelGGL(contrastive_bwd_kernel<float>, dim3(gridw(rows)), dim3(256), 0, s, (const float*)ctx, (const float*)lat, neg_idx, ic, il, logits, gscale, dctx, dlat, rows, N);
-    } else return a8_set_error(A8_ERR_ARG, "a8_contrastive_bwd: bad dtype");
+        if (int e = a8_cast(A8_BF16, A8_F32, ctx, Cf, (int64_t)rows * 256, stream)) return e;
+        cf = Cf;
+    }
+    const int ngrp = rows / rpg;
+    for (int g0 = 0; g0 < ngrp; g0 += 8) {
+        a8_gemm_desc d[8];
+        const int cnt = ngrp - g0 < 8 ? ngrp - g0 : 8;
+        for (int i = 0; i < cnt; ++i) {
+            const size_t off = (size_t)(g0 + i) * rpg;
+            d[i] = a8_gemm_desc{};
+            d[i].dtype = A8_F32; d[i].layout = A8_GEMM_TN; d[i].M = rpg4; d[i].N = 256; d[i].K = rpg;
+            d[i].A = W + off * rpg4; d[i].lda = rpg4;
+            d[i].B = cf + off * 256; d[i].ldb = 256;
+            d[i].C = G + (size_t)(g0 + i) * rpg4 * 256; d[i].ldc = 256;
+            d[i].out_f32 = 1; d[i].splitk = 1; d[i].alpha = 1.0f;
+        }
+        if (int e = a8_gemm_grouped(d, cnt, stream)) return e;
+    }
+    const long long n = (long long)rows * 256;
+    if (dtype == A8_BF16) hipLaunchKernelGGL(contrastive_combine_kernel<bf16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16*)lat, il, G, U, dlat, n, rpg, rpg4);
+    else hipLaunchKernelGGL(contrastive_combine_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)lat, il, G, U, dlat, n, rpg, rpg4);
     return a8_check_launch("a8_contrastive_bwd");
 }

@@ -742,9 +742,10 @@ class ContrastiveXEFn(torch.autograd.Function):
     """mean over masked frames of CE([cos(c, q+), cos(c, q-_1..N)], 0)  (audio8/wav2vec2.py:384-390)."""
 
     @staticmethod
-    def forward(ctx, ctx_rows, lat_rows, neg_idx):
+    def forward(ctx, ctx_rows, lat_rows, neg_idx, rows_per_group=0):
         logits, loss_sum = K.contrastive_fwd(ctx_rows.contiguous(), lat_rows.contiguous(), neg_idx)
         ctx.save_for_backward(ctx_rows, lat_rows, neg_idx, logits)
+        ctx.rows_per_group = rows_per_group
         rows = ctx_rows.shape[0]
         ctx.mark_non_differentiable(logits)
         return loss_sum[0] / rows, logits
@@ -754,10 +755,10 @@ class ContrastiveXEFn(torch.autograd.Function):
         c, q, neg_idx, logits = ctx.saved_tensors
         rows = c.shape[0]
         gscale = (dloss.float() / rows).reshape(1).contiguous()
-        dctx, dlat = K.contrastive_bwd(c.contiguous(), q.contiguous(), neg_idx, logits, gscale)
+        dctx, dlat = K.contrastive_bwd(c.contiguous(), q.contiguous(), neg_idx, logits, gscale, ctx.rows_per_group)
         if c.dtype != torch.float32:
             dctx, dlat = K.cast(dctx, c.dtype), K.cast(dlat, q.dtype)
-        return dctx, dlat, None
+        return dctx, dlat, None, None
 
 
 # ------------------------------------------------------------------ log-softmax head + CTC

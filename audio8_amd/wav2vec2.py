@@ -199,7 +199,7 @@ class Wav2Vec2Loss(nn.Module):
                 raise RuntimeError("a8hip: prefetched negatives do not match this loss (shape %s vs %s)"
                                    % (plan.neg_shape, (B * Tm, self.sample.n_negatives)))
             neg_idx = ops.host_i32(self.sample.indices(B, Tm).reshape(B * Tm, self.sample.n_negatives), outputs.device)
-        xe_loss, logits = ops.ContrastiveXEFn.apply(ctx, latents.reshape(B * Tm, C), neg_idx)
+        xe_loss, logits = ops.ContrastiveXEFn.apply(ctx, latents.reshape(B * Tm, C), neg_idx, Tm)   # negatives stay inside the utterance
         self.last_logits = logits
         diversity = DIVERSITY_WGT * (self.n_vars - gs_probs) / self.n_vars
         return (XE_WGT * xe_loss + diversity).reshape(())

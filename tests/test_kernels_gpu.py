@@ -424,7 +424,8 @@ def test_vq_against_golden(golden_dir):
 
 # ------------------------------------------------------------------ contrastive (golden G5)
 @pytest.mark.parametrize("dtype", DT)
-def test_contrastive_against_golden(golden_dir, dtype):
+@pytest.mark.parametrize("group_mode", ["scatter", "grouped", "grouped_wrong_size"])
+def test_contrastive_against_golden(golden_dir, dtype, group_mode):
     from audio8_amd import kernels as K
     g = np.load(os.path.join(golden_dir, "g5_loss.npz"))
     d = "cuda"
@@ -444,7 +445,10 @@ def test_contrastive_against_golden(golden_dir, dtype):
     loss = 0.1 * xe + 10 * (640 - float(g["gs"])) / 640
     np.testing.assert_allclose(loss, float(g["loss"]), rtol=1e-5 if dtype == torch.float32 else 5e-3)
     gscale = torch.full((1,), 0.1 / (B * Tm), device=d)
-    dctx, dlat = K.contrastive_bwd(ctx.to(dtype).to(d), lat.to(dtype).to(d), idx.to(d), logits, gscale)
+    # "grouped": the latent gradient is accumulated per utterance in LDS; a deliberately wrong group size (rows that
+    # point outside their group) must still give the right answer through the per-pair fallback
+    rpg = {"scatter": 0, "grouped": Tm, "grouped_wrong_size": max(1, Tm // 2) if (B * Tm) % max(1, Tm // 2) == 0 else 1}[group_mode]
+    dctx, dlat = K.contrastive_bwd(ctx.to(dtype).to(d), lat.to(dtype).to(d), idx.to(d), logits, gscale, rows_per_group=rpg)
     g_out = torch.from_numpy(g["g_outputs"])
     ref_dctx = g_out[mask.unsqueeze(-1).expand_as(g_out)].view(-1, C)
     tolb = 1e-4 if dtype == torch.float32 else 3e-2
