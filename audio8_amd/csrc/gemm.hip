@@ -95,6 +95,131 @@ template <int KB> struct StageTile<float, KB> {
     }
 };
 
+// ---- epilogue (shared by the main-loop variants).  Needs NWM*2 waves x (16*MI rows x 64 cols x 4 B) of free LDS.
+template <typename T, int MI, int NWM>
+A8_DEV void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MI][4], char* lds, const int w, const int m0, const int n0, const int lane) {
+    const int wm = w >> 1, wn = w & 1;
+    // ---- epilogue through LDS: each wave parks its 64x64 f32 sub-tile in its own 16 KB of the (now free) ring, then
+    // walks it row by row so that every global store / f32 atomic wave-instruction is ONE contiguous row segment
+    // (256 B of f32, 128 B of bf16) instead of 16 rows x 16 B -- the shape the memory-side atomic units need.
+    constexpr int WROWS = 16 * MI;                                    // rows of the tile owned by a wave
+    float* cw = reinterpret_cast<float*>(lds) + w * (WROWS * 64);
+    {
+        const int g4 = lane >> 4, li = lane & 15;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 v = acc[i][j];
+                v *= g.alpha;
+                *reinterpret_cast<f32x4*>(cw + (16 * i + li) * 64 + (((4 * j + g4) ^ li) << 2)) = v;
+            }
+    }
+    __builtin_amdgcn_wave_barrier();      // the tile is wave-private: program order of this wave's LDS ops suffices
+    const int mw = m0 + wm * WROWS, nw = n0 + wn * 64;
+    auto zrow = [&](int m) -> long long { return g.z_rpb ? (m / g.z_rpb) * g.z_bs + (m % g.z_rpb) * g.ldz : (long long)m * g.ldz; };
+    const bool f32_rows = g.out_f32 || sizeof(T) == 4;
+    if (f32_rows) {
+        const int n = nw + lane;
+        const bool n_ok = n < g.N;
+        const float bn = (g.bias && !g.bias_rows && n_ok) ? g.bias[n] : 0.f;
+        float csum = 0.f;
+        for (int rr = 0; rr < WROWS; ++rr) {
+            const int m = mw + rr;
+            if (m >= g.M) break;
+            float v = cw[rr * 64 + ((((lane >> 2) ^ (rr & 15))) << 2) + (lane & 3)] + bn;
+            if (g.bias && g.bias_rows) v += g.bias[m];
+            if (!n_ok) continue;
+            if (g.zout) reinterpret_cast<T*>(g.zout)[zrow(m) + n] = from_f<T>(v);
+            if (g.act == A8_ACT_GELU) v = gelu_f(v);
+            else if (g.act == A8_ACT_MUL_GELU_GRAD) v *= gelu_grad_f(to_f(reinterpret_cast<const T*>(g.zin)[zrow(m) + n]));
+            else if (g.act == A8_ACT_ADD) v += to_f(reinterpret_cast<const T*>(g.zin)[zrow(m) + n]);
+            const long long crow = g.c_rpb ? (m / g.c_rpb) * g.c_bs + (m % g.c_rpb) * g.ldc : (long long)m * g.ldc;
+            float* cp = reinterpret_cast<float*>(g.C) + crow + n;
+            if (g.atomic) atomicAdd(cp, v);
+            else *cp = v;
+            csum += v;
+        }
+        if (g.colsum) {                                  // block-uniform: combine the NWM row-waves in LDS, one atomic per column per block
+            cw[lane] = csum;                             // the wave is done with its staging area
+            __syncthreads();
+            if (wm == 0) {
+                float t = 0.f;
+#pragma unroll
+                for (int q = 0; q < NWM; ++q) t += reinterpret_cast<const float*>(lds)[(q * 2 + wn) * (WROWS * 64) + lane];
+                if (n_ok) atomicAdd(g.colsum + n, t);
+            }
+        }
+    } else {
+        // 16-bit output: lane owns 8 consecutive columns (16 B), a wave-instruction covers 8 rows x 128 B
+        const int c8 = (lane & 7) << 3;                 // first column within the wave's 64
+        const int n = nw + c8;
+        const bool n_ok = n < g.N;
+        float bn[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bn[e] = (g.bias && !g.bias_rows && n_ok) ? g.bias[n + e] : 0.f;
+        typedef T T8 __attribute__((ext_vector_type(8)));
+        float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int it = 0; it < WROWS / 8; ++it) {
+            if (mw + 8 * it >= g.M) break;
+            const int rr = 8 * it + (lane >> 3);
+            const int m = mw + rr;
+            const int ch = c8 >> 2;                      // even 16-byte chunk index; its partner is ch + 1
+            const f32x4 p0 = *reinterpret_cast<const f32x4*>(cw + rr * 64 + ((ch ^ (rr & 15)) << 2));
+            const f32x4 p1 = *reinterpret_cast<const f32x4*>(cw + rr * 64 + (((ch + 1) ^ (rr & 15)) << 2));
+            if (m >= g.M || !n_ok) continue;
+            float v[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+            const float bm = (g.bias && g.bias_rows) ? g.bias[m] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bn[e] + bm;
+            if (g.zout) {
+                T8 zv;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) zv[e] = from_f<T>(v[e]);
+                *reinterpret_cast<T8*>(reinterpret_cast<T*>(g.zout) + zrow(m) + n) = zv;
+            }
+            if (g.act == A8_ACT_GELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+            } else if (g.act == A8_ACT_MUL_GELU_GRAD) {
+                const T8 zz = *reinterpret_cast<const T8*>(reinterpret_cast<const T*>(g.zin) + zrow(m) + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(to_f(zz[e]));
+            } else if (g.act == A8_ACT_ADD) {
+                const T8 zz = *reinterpret_cast<const T8*>(reinterpret_cast<const T*>(g.zin) + zrow(m) + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += to_f(zz[e]);
+            }
+            const long long crow = g.c_rpb ? (m / g.c_rpb) * g.c_bs + (m % g.c_rpb) * g.ldc : (long long)m * g.ldc;
+            T8 ov;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ov[e] = from_f<T>(v[e]); csum[e] += v[e]; }
+            *reinterpret_cast<T8*>(reinterpret_cast<T*>(g.C) + crow + n) = ov;
+        }
+        if (g.colsum) {                                  // block-uniform; lanes l, l+8, .. l+56 hold the same 8 columns
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t = csum[e];
+                t += __shfl_xor(t, 8, 64);
+                t += __shfl_xor(t, 16, 64);
+                t += __shfl_xor(t, 32, 64);
+                csum[e] = t;
+            }
+            if (lane < 8) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) cw[lane * 8 + e] = csum[e];      // the wave is done with its staging area
+            }
+            __syncthreads();
+            if (wm == 0) {                               // one atomic per column per block (128 per tile)
+                float t = 0.f;
+#pragma unroll
+                for (int q = 0; q < NWM; ++q) t += reinterpret_cast<const float*>(lds)[(q * 2 + wn) * (WROWS * 64) + lane];
+                if (nw + lane < g.N) atomicAdd(g.colsum + nw + lane, t);
+            }
+        }
+    }
+}
+
 // Main loop: NST-deep ring of LDS stages filled by LDS-DMA (global_load_lds, 16 B per lane), NST-1 k-tiles in
 // flight per block; one raw s_barrier and one counted s_waitcnt vmcnt per k-tile; no register staging.
 template <typename T, bool AKS, bool BKS, int KB, int NST, int NWM>
@@ -259,126 +384,131 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // ---- epilogue through LDS: each wave parks its 64x64 f32 sub-tile in its own 16 KB of the (now free) ring, then
-    // walks it row by row so that every global store / f32 atomic wave-instruction is ONE contiguous row segment
-    // (256 B of f32, 128 B of bf16) instead of 16 rows x 16 B -- the shape the memory-side atomic units need.
-    static_assert(NST * 2 * TILE >= 65536, "epilogue staging needs 64 KB of LDS");
-    constexpr int WROWS = 16 * MI;                                    // rows of the tile owned by a wave
-    float* cw = reinterpret_cast<float*>(lds) + w * (WROWS * 64);
-    {
-        const int g4 = lane >> 4, li = lane & 15;
+    static_assert(NST * 2 * TILE >= NW * 16 * MI * 64 * 4, "epilogue staging needs a 64-column f32 slab per wave");
+    gemm_epilogue<T, MI, NWM>(g, acc, lds, w, m0, n0, lane);
+}
+
+// ---- register-pipelined main loop for large NT problems (both operands K-contiguous, 16-bit):
+// 256x128 tile, 8 waves of 64x64 (0.5 KB of LDS fragment reads per MFMA instead of 0.75 at 32x64), 3-stage LDS-DMA
+// ring (DMA two k-tiles ahead), one block per CU.  With only 2 waves per SIMD the LDS latency is hidden inside the wave:
+// the fragments of k-tile kb+1 are read into a second register set while the MFMAs of k-tile kb run from the first
+// (the k-loop is unrolled by two so the sets swap roles without moves).
+template <typename T>
+A8_DEV void gemm_body_pf(const GemmArgs& g, const int bid) {
+    static_assert(sizeof(T) == 2, "16-bit operands");
+    typedef StageTile<T, 2> ST;
+    typedef KcGeom<2> G;
+    typedef Mma<T> MM;
+    constexpr int BM = 256, BK = ST::BK, SZ = 2, EPC = 8, NWM = 4, NW = 8, MI = 4, NST = 3;
+    constexpr int TA = BM * G::KROW, TB = 128 * G::KROW, STAGE = TA + TB;
+    constexpr int PA = TA / 1024 / NW, PB = TB / 1024 / NW;
+    __shared__ __attribute__((aligned(1024))) char lds[NST * STAGE];
+    static_assert(NST * STAGE >= NW * 16 * MI * 64 * 4, "epilogue staging");
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    const int split = bid / (g.tiles_m * g.tiles_n);
+    const int tile = bid - split * (g.tiles_m * g.tiles_n);
+    constexpr int GROUP_M = 8;
+    const int tpg = GROUP_M * g.tiles_n;
+    const int grp = tile / tpg, first_m = grp * GROUP_M;
+    const int gsz = min(GROUP_M, g.tiles_m - first_m);
+    const int tin = tile - grp * tpg;
+    const int m0 = (first_m + tin % gsz) * BM, n0 = (tin / gsz) * 128;
+    const int kbeg = split * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+    const int nkb = (kend - kbeg + BK - 1) / BK;
+    const char* zero = reinterpret_cast<const char*>(g_zero16);
+
+    const char* a_ptr[PA]; int a_k[PA];
+    const char* b_ptr[PB]; int b_k[PB];
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                f32x4 v = acc[i][j];
-                v *= g.alpha;
-                *reinterpret_cast<f32x4*>(cw + (16 * i + li) * 64 + (((4 * j + g4) ^ li) << 2)) = v;
-            }
+    for (int j = 0; j < PA; ++j) {
+        const int p = w + NW * j, rl = G::RPP * p + lane / G::SPR, row = m0 + rl;
+        a_k[j] = (((lane % G::SPR) ^ G::swz(rl)) & (G::SPR - 1)) * EPC;
+        a_ptr[j] = row < g.M ? g.A.p + outer_off(g.A, row) * SZ : nullptr;
     }
-    __builtin_amdgcn_wave_barrier();      // the tile is wave-private: program order of this wave's LDS ops suffices
-    const int mw = m0 + wm * WROWS, nw = n0 + wn * 64;
-    auto zrow = [&](int m) -> long long { return g.z_rpb ? (m / g.z_rpb) * g.z_bs + (m % g.z_rpb) * g.ldz : (long long)m * g.ldz; };
-    const bool f32_rows = g.out_f32 || sizeof(T) == 4;
-    if (f32_rows) {
-        const int n = nw + lane;
-        const bool n_ok = n < g.N;
-        const float bn = (g.bias && !g.bias_rows && n_ok) ? g.bias[n] : 0.f;
-        float csum = 0.f;
-        for (int rr = 0; rr < WROWS; ++rr) {
-            const int m = mw + rr;
-            if (m >= g.M) break;
-            float v = cw[rr * 64 + ((((lane >> 2) ^ (rr & 15))) << 2) + (lane & 3)] + bn;
-            if (g.bias && g.bias_rows) v += g.bias[m];
-            if (!n_ok) continue;
-            if (g.zout) reinterpret_cast<T*>(g.zout)[zrow(m) + n] = from_f<T>(v);
-            if (g.act == A8_ACT_GELU) v = gelu_f(v);
-            else if (g.act == A8_ACT_MUL_GELU_GRAD) v *= gelu_grad_f(to_f(reinterpret_cast<const T*>(g.zin)[zrow(m) + n]));
-            else if (g.act == A8_ACT_ADD) v += to_f(reinterpret_cast<const T*>(g.zin)[zrow(m) + n]);
-            const long long crow = g.c_rpb ? (m / g.c_rpb) * g.c_bs + (m % g.c_rpb) * g.ldc : (long long)m * g.ldc;
-            float* cp = reinterpret_cast<float*>(g.C) + crow + n;
-            if (g.atomic) atomicAdd(cp, v);
-            else *cp = v;
-            csum += v;
-        }
-        if (g.colsum) {                                  // block-uniform: combine the NWM row-waves in LDS, one atomic per column per block
-            cw[lane] = csum;                             // the wave is done with its staging area
-            __syncthreads();
-            if (wm == 0) {
-                float t = 0.f;
 #pragma unroll
-                for (int q = 0; q < NWM; ++q) t += reinterpret_cast<const float*>(lds)[(q * 2 + wn) * (WROWS * 64) + lane];
-                if (n_ok) atomicAdd(g.colsum + n, t);
-            }
-        }
-    } else {
-        // 16-bit output: lane owns 8 consecutive columns (16 B), a wave-instruction covers 8 rows x 128 B
-        const int c8 = (lane & 7) << 3;                 // first column within the wave's 64
-        const int n = nw + c8;
-        const bool n_ok = n < g.N;
-        float bn[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bn[e] = (g.bias && !g.bias_rows && n_ok) ? g.bias[n + e] : 0.f;
-        typedef T T8 __attribute__((ext_vector_type(8)));
-        float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int it = 0; it < WROWS / 8; ++it) {
-            if (mw + 8 * it >= g.M) break;
-            const int rr = 8 * it + (lane >> 3);
-            const int m = mw + rr;
-            const int ch = c8 >> 2;                      // even 16-byte chunk index; its partner is ch + 1
-            const f32x4 p0 = *reinterpret_cast<const f32x4*>(cw + rr * 64 + ((ch ^ (rr & 15)) << 2));
-            const f32x4 p1 = *reinterpret_cast<const f32x4*>(cw + rr * 64 + (((ch + 1) ^ (rr & 15)) << 2));
-            if (m >= g.M || !n_ok) continue;
-            float v[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
-            const float bm = (g.bias && g.bias_rows) ? g.bias[m] : 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += bn[e] + bm;
-            if (g.zout) {
-                T8 zv;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) zv[e] = from_f<T>(v[e]);
-                *reinterpret_cast<T8*>(reinterpret_cast<T*>(g.zout) + zrow(m) + n) = zv;
-            }
-            if (g.act == A8_ACT_GELU) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
-            } else if (g.act == A8_ACT_MUL_GELU_GRAD) {
-                const T8 zz = *reinterpret_cast<const T8*>(reinterpret_cast<const T*>(g.zin) + zrow(m) + n);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(to_f(zz[e]));
-            } else if (g.act == A8_ACT_ADD) {
-                const T8 zz = *reinterpret_cast<const T8*>(reinterpret_cast<const T*>(g.zin) + zrow(m) + n);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += to_f(zz[e]);
-            }
-            const long long crow = g.c_rpb ? (m / g.c_rpb) * g.c_bs + (m % g.c_rpb) * g.ldc : (long long)m * g.ldc;
-            T8 ov;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { ov[e] = from_f<T>(v[e]); csum[e] += v[e]; }
-            *reinterpret_cast<T8*>(reinterpret_cast<T*>(g.C) + crow + n) = ov;
-        }
-        if (g.colsum) {                                  // block-uniform; lanes l, l+8, .. l+56 hold the same 8 columns
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float t = csum[e];
-                t += __shfl_xor(t, 8, 64);
-                t += __shfl_xor(t, 16, 64);
-                t += __shfl_xor(t, 32, 64);
-                csum[e] = t;
-            }
-            if (lane < 8) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) cw[lane * 8 + e] = csum[e];      // the wave is done with its staging area
-            }
-            __syncthreads();
-            if (wm == 0) {                               // one atomic per column per block (128 per tile)
-                float t = 0.f;
-#pragma unroll
-                for (int q = 0; q < NWM; ++q) t += reinterpret_cast<const float*>(lds)[(q * 2 + wn) * (WROWS * 64) + lane];
-                if (nw + lane < g.N) atomicAdd(g.colsum + nw + lane, t);
-            }
-        }
+    for (int j = 0; j < PB; ++j) {
+        const int p = w + NW * j, rl = G::RPP * p + lane / G::SPR, row = n0 + rl;
+        b_k[j] = (((lane % G::SPR) ^ G::swz(rl)) & (G::SPR - 1)) * EPC;
+        b_ptr[j] = row < g.N ? g.B.p + outer_off(g.B, row) * SZ : nullptr;
     }
+    auto issue = [&](int kb) {
+        char* ta = lds + (kb % NST) * STAGE;
+        char* tb = ta + TA;
+        const int k0 = kbeg + kb * BK;
+#pragma unroll
+        for (int j = 0; j < PA; ++j) {
+            const int k = k0 + a_k[j];
+            glds16((a_ptr[j] && k + EPC <= kend) ? a_ptr[j] + (long long)k * SZ : zero, ta + (w + NW * j) * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+            const int k = k0 + b_k[j];
+            glds16((b_ptr[j] && k + EPC <= kend) ? b_ptr[j] + (long long)k * SZ : zero, tb + (w + NW * j) * 1024);
+        }
+    };
+    struct Frags { typename MM::Frag a[ST::KSTEPS][MI], b[ST::KSTEPS][4]; };
+    auto read_frags = [&](int kb, Frags& f) {
+        const char* ta = lds + (kb % NST) * STAGE;
+        const char* tb = ta + TA;
+#pragma unroll
+        for (int ks = 0; ks < ST::KSTEPS; ++ks) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) f.a[ks][i] = ST::kc_frag(ta, wm * (16 * MI) + 16 * i, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) f.b[ks][i] = ST::kc_frag(tb, wn * 64 + 16 * i, ks, lane);
+        }
+    };
+
+    f32x4 acc[MI][4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    issue(0); issue(1); issue(2);
+    static_assert(PA + PB == 6, "the s_waitcnt immediates below encode 6 and 12 outstanding DMA pieces");
+    // (the builtin, not inline asm: the compiler's own wait-count bookkeeping must see these waits, or it re-inserts a
+    //  full lgkmcnt(0) in front of the MFMAs and serialises the fragment prefetch)
+    __builtin_amdgcn_s_waitcnt(0x0F7C);                  // vmcnt(12): k-tile 0 has landed
+    __builtin_amdgcn_s_barrier();
+    Frags f0, f1;
+    read_frags(0, f0);
+    __builtin_amdgcn_sched_barrier(0);
+    // one k-tile: MFMAs from `cur` while the next k-tile's fragments stream into `nxt`
+    auto step = [&](int kb, Frags& cur, Frags& nxt) {
+        // k-tile kb+1 has landed once at most one DMA round (k-tile kb+2) is outstanding; lgkmcnt(0): this wave's reads
+        // of the stage about to be refilled are complete before it signals the barrier
+        __builtin_amdgcn_s_waitcnt(0x0076);              // vmcnt(6) lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        issue(kb + 3);                                   // refills the stage read one iteration ago; beyond K: zero page
+        read_frags(kb + 1, nxt);
+        // pin the order: the compiler otherwise sinks these reads to their first use (the next step) and hoists that
+        // step's MFMAs over its barrier, which turns the pipeline back into read -> wait -> MFMA
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < ST::KSTEPS; ++ks)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = MM::mma(cur.b[ks][j], cur.a[ks][i], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int kb = 0; kb < nkb; kb += 2) {
+        step(kb, f0, f1);
+        if (kb + 1 < nkb) step(kb + 1, f1, f0);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    gemm_epilogue<T, MI, NWM>(g, acc, lds, w, m0, n0, lane);
+}
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void gemm_pf_kernel(const GemmArgs g) {
+    gemm_body_pf<T>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n * g.nsplit));
 }
 
 template <typename T, bool AKS, bool BKS, int KB, int NST, int NWM>
@@ -481,6 +611,15 @@ extern "C" int a8_gemm(const a8_gemm_desc* d, void* stream) {
     if (int e = build_args(d, g, &grid)) return e;
     if (d->M == 0) return A8_OK;
     hipStream_t s = (hipStream_t)stream;
+    // large NT problems: the register-pipelined 256x128 kernel (a8_set_tuning key 5 = minimum number of 256x128 tiles; 0 = off)
+    if (d->dtype == A8_BF16 && d->layout == A8_GEMM_NT && g_a8_tuning[5] > 0 && g_variant == 5) {
+        const int tm = cdiv(d->M, 256);
+        if ((long long)tm * g.tiles_n >= g_a8_tuning[5]) {
+            g.tiles_m = tm;
+            hipLaunchKernelGGL(gemm_pf_kernel<bf16>, dim3(tm * g.tiles_n * g.nsplit), dim3(512), 0, s, g);
+            return a8_check_launch("a8_gemm");
+        }
+    }
     return d->dtype == A8_BF16 ? launch<bf16>(d, g, (int)grid, s) : launch<float>(d, g, (int)grid, s);
 }
 

@@ -179,3 +179,51 @@ def test_gemm_add_epilogue(dtype):
     ref = A.double() @ B.double().T + R.double()
     tol = 0 if dtype == torch.float32 else 1e-2
     np.testing.assert_allclose(out.double().cpu().numpy(), ref.numpy(), rtol=tol, atol=tol)
+
+
+def test_gemm_register_pipelined_kernel_matches_default():
+    """The 256x128 register-pipelined NT kernel (a8_set_tuning key 5) walks K in the same order as the default kernel:
+    outputs must be bit-identical across shapes with M/N/K tails, the conv row remap and every epilogue."""
+    from audio8_amd import kernels as Kn, _lib as L
+    dev, bf = "cuda", torch.bfloat16
+
+    def both(fn):
+        L.check(L.lib().a8_set_tuning(5, 0), "tune")
+        ref = fn()
+        L.check(L.lib().a8_set_tuning(5, 1), "tune")
+        try:
+            got = fn()
+        finally:
+            L.check(L.lib().a8_set_tuning(5, 0), "tune")
+        return ref, got
+
+    def same(ref, got, what):
+        for r, g_ in zip(ref, got):
+            assert torch.equal(r, g_), what
+
+    for (M, N, K) in [(781, 768, 512), (1000, 264, 72), (256, 128, 64), (300, 136, 2056), (6248, 768, 768)]:
+        A, B = _mk((M, K), bf, 1).to(dev), _mk((N, K), bf, 2).to(dev)
+        same(*both(lambda: (Kn.gemm(L.NT, A, B, M, N, K),)), ("plain", M, N, K))
+    M, N, K = 6248, 3072, 768
+    A, B = _mk((M, K), bf, 3).to(dev), _mk((N, K), bf, 4).to(dev)
+    bias, z = torch.randn(N, device=dev), _mk((M, N), bf, 5).to(dev)
+
+    def gelu_zout():
+        zo = torch.empty(M, N, device=dev, dtype=bf)
+        return Kn.gemm(L.NT, A, B, M, N, K, bias=bias, act=L.ACT_GELU, zout=zo), zo
+    same(*both(gelu_zout), "gelu+zout")
+
+    def ggrad_colsum():
+        cs = torch.zeros(N, device=dev)
+        return Kn.gemm(L.NT, A, B, M, N, K, act=L.ACT_MUL_GELU_GRAD, zin=z, colsum=cs), cs
+    ref, got = both(ggrad_colsum)
+    assert torch.equal(ref[0], got[0])
+    np.testing.assert_allclose(got[1].cpu().numpy(), ref[1].cpu().numpy(), rtol=1e-4, atol=1e-2)       # atomic order differs
+    same(*both(lambda: (Kn.gemm(L.NT, A, B, M, N, K, act=L.ACT_ADD, zin=z),)), "add")
+    same(*both(lambda: (Kn.gemm(L.NT, A, B, M, N, K, out_dtype=torch.float32),)), "f32 out")
+    # conv-as-GEMM: overlapping rows of a channels-last activation (k = 3, stride 2), row remap on A and C
+    Bn, Lin, Cc = 2, 1001, 512
+    Lout = (Lin - 3) // 2 + 1
+    x = _mk((Bn * Lin * Cc,), bf, 6).to(dev)
+    Wc = _mk((512, 3 * Cc), bf, 7).to(dev)
+    same(*both(lambda: (Kn.gemm(L.NT, x, Wc, Bn * Lout, 512, 3 * Cc, lda=2 * Cc, a_rpb=Lout, a_bs=Lin * Cc),)), "conv remap")
