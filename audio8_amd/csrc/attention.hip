@@ -401,7 +401,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kv_kernel(const AttnP P) {
     f32x4 dk[G][4], dv[G][4];
     int key[G];
     bool key_masked[G];
-    uint32_t hk[G], fsh[G];       // dropout word of (query qq, key): fin(hk + (qq - tile base - 4g) * ThC), field (key & 1)
+    uint32_t hk[G], hc2[G];       // dropout word of (query qq, key): fin(hk + (qq - tile base - 4g) * ThC), field (key & 1);
+                                  // the final multiplier is HC2 << 16 for even keys, which moves their field to the top half
 #pragma unroll
     for (int j = 0; j < G; ++j) {
         key[j] = blk * BK + (wv * G + j) * 16 + li;
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kv_kernel(const AttnP P) {
         vf[j].load(vb + (long long)key[j] * P.ld_qkv, ok, lane);
         key_masked[j] = P.keymask && ok && !P.keymask[(long long)b * P.T + key[j]];
         hk[j] = (pair_base(bh, P.T, P.Th, 4 * g) + (uint32_t)(key[j] >> 1) + P.seed) * HC1;
-        fsh[j] = (key[j] & 1) << 4;
+        hc2[j] = (key[j] & 1) ? HC2 : (HC2 << 16);
 #pragma unroll
         for (int i = 0; i < 4; ++i) { dk[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     }
@@ -460,8 +461,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kv_kernel(const AttnP P) {
                     const float p = fast_exp2(x);      // keys beyond T: harmless garbage in rows that are never stored
                     float pdrop = p, dpv = dp[j][i][r];
                     if (P.thr) {
-                        const uint32_t hh = hfin(hk[j] + (uint32_t)(16 * i + r) * ThC);
-                        const bool keep = ((hh >> fsh[j]) & 0xFFFFu) >= P.thr;
+                        uint32_t hh = hk[j] + (uint32_t)(16 * i + r) * ThC;
+                        hh = (hh ^ (hh >> 15)) * hc2[j];                  // = hfin() with the key's 16-bit field in bits 31..16
+                        const bool keep = hh >= (P.thr << 16);
                         pdrop = keep ? p : 0.f;
                         dpv = keep ? dpv : 0.f;
                     }
@@ -578,6 +580,7 @@ void set_softmax_params(AttnP& P, float scale, float p, uint32_t seed) {
     P.Th = (P.T + 1) / 2;
     uint32_t thr = p > 0.f ? (uint32_t)(p * 65536.0f + 0.5f) : 0u;
     if (p > 0.f && thr == 0) thr = 1;
+    if (thr > 65535u) thr = 65535u;
     P.thr = thr;
     P.pscale = thr ? 65536.0f / (65536.0f - (float)thr) : 1.0f;      // unbiased for the realised keep probability
     P.seed = seed;
