@@ -37,7 +37,7 @@ def cfg4():
     x = synth(4, 320000).cuda()
 
     def step():
-        st.zero_grad(); loss = loss_fn(model, x); loss.backward(); v = loss.item(); st.step(); return v
+        st.zero_grad(); loss = loss_fn(model, x); loss.backward(); W.prefetch_host_draws(model, loss_fn, x.shape); v = loss.item(); st.step(); return v
     ms, v = timed(step)
     print(f"cfg4 wav2vec2-large 4x320k bf16: {ms:.2f} ms/step, {4 * 320000 / 16000 / ms * 1e3:.0f} audio-s/s, loss {v:.4f}, params {sum(p.numel() for p in model.parameters()):,}")
     st.close()
