@@ -171,13 +171,21 @@ class GradReducer:
             for i in bk["members"]:
                 self.bucket_of[i] = b
         self.handles = []
+        self.marked = [False] * len(state.params)
         self.extra_streams = []
+        self.compute_stream = None
         self.index_of = {id(p): i for i, p in enumerate(state.params)}
         if self.enabled:
             for i, p in enumerate(state.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(i))
 
     def _mark(self, i):
+        # idempotent per step: a parameter whose gradient a backward kernel wrote directly is reported through
+        # ops.GRAD_READY_HOOK, and autograd's post-accumulate hook fires for it as well (with an undefined gradient);
+        # counting both would release the bucket before its other members' gradients are enqueued
+        if self.marked[i]:
+            return
+        self.marked[i] = True
         bk = self.buckets[self.bucket_of[i]]
         bk["pending"] -= 1
         if bk["pending"] == 0 and not bk.get("launched"):
@@ -198,12 +206,19 @@ class GradReducer:
     def _launch(self, bk):
         view = self.state.flat_g[bk["lo"]:bk["hi"]]
         if self.on_gpu:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            self.side.wait_event(ev)
-            for s2 in self.extra_streams:              # gradients may have been produced on the wgrad side stream too
+            # the bucket's gradients were enqueued on the compute stream and/or the wgrad side stream, and this call may
+            # come from either context (the last parameter of a bucket decides): wait for all of them
+            cur = torch.cuda.current_stream()
+            streams = {id(cur): cur}
+            if self.compute_stream is not None:
+                streams[id(self.compute_stream)] = self.compute_stream
+            for s2 in self.extra_streams:
                 if s2 is not None:
-                    self.side.wait_stream(s2)
+                    streams[id(s2)] = s2
+            for st in streams.values():
+                ev = torch.cuda.Event()
+                ev.record(st)
+                self.side.wait_event(ev)
             with torch.cuda.stream(self.side):
                 h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         else:                                            # gloo on CPU (tests): same bucket schedule, no streams
@@ -212,9 +227,12 @@ class GradReducer:
         bk["launched"] = True
 
     def begin_step(self):
+        if self.on_gpu:
+            self.compute_stream = torch.cuda.current_stream()
         for bk in self.buckets:
             bk["pending"] = len(bk["members"])
             bk["launched"] = False
+        self.marked = [False] * len(self.state.params)
         self.handles = []
 
     def finish(self):

@@ -368,3 +368,68 @@ def test_weight_cache_contents_match_masters(restore_dtype):
             assert torch.equal(b_odd, w[:, :, 1].t().contiguous().to(torch.bfloat16)), n
     finally:
         st.close()
+
+
+def test_bucketed_reducer_on_gpu_streams_with_fake_collective(restore_dtype, monkeypatch):
+    """The GPU side of the DP reducer (bucket launches from compute- and side-stream contexts, event waits, 1/world
+    folded into AdamW) with the collective replaced by `x *= 2` -- what a SUM over two identical ranks gives."""
+    import torch.distributed as dist
+    from audio8_amd import ops, wav2vec2 as W
+    from audio8_amd.trainer import Stepper
+    ops.set_compute_dtype(torch.bfloat16)
+    x = synth(2, 16000, 5).cuda()
+
+    def run(fake_world):
+        torch.manual_seed(3)
+        np.random.seed(3)
+        ops.reset_seed_stream()
+        mdl = W.create_model(num_layers=2).cuda().train()
+        calls = []
+        if fake_world:
+            class Handle:
+                def wait(self):
+                    return True
+
+            def fake_all_reduce(t, op=None, group=None, async_op=False):
+                calls.append(t.numel())
+                t.mul_(2.0)                       # enqueued on the reducer's side stream, like the real collective
+                return Handle()
+            monkeypatch.setattr(dist, "is_initialized", lambda: True)
+            monkeypatch.setattr(dist, "get_world_size", lambda group=None: 2)
+            monkeypatch.setattr(dist, "all_reduce", fake_all_reduce)
+            monkeypatch.setattr(dist, "broadcast", lambda t, src=0, group=None, async_op=False: None)   # rank 0's parameters already
+        st = Stepper(mdl, lr=1e-3, bucket_mb=8.0)
+        try:
+            if fake_world:
+                assert st.reducer.enabled and len(st.reducer.buckets) > 3
+            st.zero_grad()
+            torch.manual_seed(4)
+            loss = W.create_loss(640, 100)(mdl, x)
+            loss.backward()
+            torch.cuda.current_stream().wait_stream(st.wgrad_stream)
+            st.reducer.finish()                       # all buckets exchanged; the compute stream waits for them
+            grads = st.state.flat_g.clone()
+            st.step()
+            torch.cuda.synchronize()
+            if fake_world:
+                assert sum(calls) == st.state.total and len(calls) == len(st.reducer.buckets)
+            names = [(k, st.state.offsets[i], p.numel()) for i, (k, p) in enumerate(mdl.named_parameters())]
+            return grads.cpu(), {k: p.detach().float().cpu().clone() for k, p in mdl.named_parameters()}, names
+        finally:
+            st.close()
+            monkeypatch.undo()
+
+    g1, single, names = run(False)
+    g2, double, _ = run(True)
+    for k, o, n in names:                              # per parameter: exchanged = 2 x local (a bucket released early shows 1 x)
+        a, b = g2[o:o + n].double(), g1[o:o + n].double()
+        if float(b.norm()) > 1e-6:
+            r = float((a * b).sum() / (b * b).sum())
+            assert abs(r - 2.0) < 0.1, (k, r)
+    # a missing stream wait would exchange half-written buckets: the "summed" gradient must be twice the local one up to
+    # the atomic-order noise of the bf16 backward
+    assert rel_err(g2, 2.0 * g1) < 2e-2
+    for k in single:
+        a, b = double[k].numpy(), single[k].numpy()
+        # one Adam step moves each element by ~lr = 1e-3; elements with rounding-level gradients may differ by a fraction of it
+        assert np.isfinite(a).all() and np.abs(a - b).max() < 2.5e-3, (k, float(np.abs(a - b).max()))
