@@ -137,16 +137,18 @@ def main():
     # ---- live roofline of the dominant kernel (a8_gemm, bf16 MFMA): one extra instrumented step,
     # HIP events on the launch stream around every a8_gemm launch
     roofline = None
+
+    def gemm_rate():                                           # EVERY rank runs these steps (they contain the gradient collectives);
+        K.GEMM_PROFILE = [] if rank == 0 else None             # only rank 0 brackets its launches with events
+        one_step()
+        torch.cuda.synchronize()
+        prof, K.GEMM_PROFILE = K.GEMM_PROFILE or [], None
+        return prof, sum(p[0].elapsed_time(p[1]) for p in prof), sum(p[2] for p in prof)
+    prof, tot_ms, tot_fl = gemm_rate()                         # as the step runs (weight-gradient GEMMs overlap on a side stream)
+    side, ops.WGRAD_SIDE_STREAM = ops.WGRAD_SIDE_STREAM, None
+    sprof, ser_ms, ser_fl = gemm_rate()                        # the same launches one after another (kernel's own rate)
+    ops.WGRAD_SIDE_STREAM = side
     if rank == 0:
-        def gemm_rate():
-            K.GEMM_PROFILE = []
-            one_step()
-            torch.cuda.synchronize()
-            prof, K.GEMM_PROFILE = K.GEMM_PROFILE, None
-            return prof, sum(p[0].elapsed_time(p[1]) for p in prof), sum(p[2] for p in prof)
-        prof, tot_ms, tot_fl = gemm_rate()                     # as the step runs (weight-gradient GEMMs overlap on a side stream)
-        side, ops.WGRAD_SIDE_STREAM = ops.WGRAD_SIDE_STREAM, None
-        sprof, ser_ms, ser_fl = gemm_rate()                    # the same launches one after another (kernel's own rate)
         if args.gemm_table:
             tab = {}
             for e0, e1, fl, lay, _, shp in sprof:
@@ -156,7 +158,6 @@ def main():
             for k, (n, ms, fl) in sorted(tab.items(), key=lambda kv: -kv[1][1]):
                 print("gemm %s M=%d N=%d K=%d splitk=%d  n=%3d  avg %7.1f us  total %6.3f ms  %6.1f TFLOP/s"
                       % (("NT", "NN", "TN")[k[0]], k[1], k[2], k[3], k[4], n, ms / n * 1e3, ms, fl * n / ms / 1e9), file=sys.stderr)
-        ops.WGRAD_SIDE_STREAM = side
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
         traffic, traffic_src = None, None
