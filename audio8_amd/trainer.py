@@ -322,8 +322,8 @@ def init_distributed_from_env():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if torch.cuda.is_available():
-        torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
+        torch.cuda.set_device(local % max(1, torch.cuda.device_count()))      # (more ranks than GPUs only in rehearsals)
     if world > 1 and not dist.is_initialized():
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        backend = os.environ.get("A8_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")   # nccl = RCCL on ROCm
         dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world)
     return rank, local, world
