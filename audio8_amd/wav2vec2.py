@@ -282,7 +282,7 @@ def _take_plan(model, B, T):
     if not _PLANS:
         return None
     plan = _PLANS.popleft()
-    if plan.key != (id(model), B, T) or not model.training:
+    if plan.key != (id(model), B, T):                   # (train / eval does not matter: the forward draws the same things in both)
         _PLANS.clear()
         raise RuntimeError("a8hip: prefetched host draws %s do not match this forward %s" % (plan.key[1:], (B, T)))
     cur = torch.cuda.current_stream()
