@@ -33,6 +33,7 @@ ARGTYPES = {
     "a8_layernorm_fwd": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_void_p],
     "a8_layernorm_bwd": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_uint32, C.c_uint32, C.c_void_p],
     "a8_cast": [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
+    "a8_ctc_greedy_decode": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_void_p],
     "a8_dropout": [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_uint32, C.c_uint32, C.c_void_p],
     "a8_mask_fill_rows": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p],
     "a8_mask_fill_rows_bwd": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p],
@@ -140,7 +141,7 @@ EXPORTS = [
     "a8_posconv_fwd", "a8_posconv_wgrad", "a8_gelu_bwd_bias",
     "a8_attn_fwd", "a8_attn_bwd",
     "a8_vq_select", "a8_vq_gather", "a8_vq_ppl", "a8_vq_bwd",
-    "a8_contrastive_fwd", "a8_contrastive_bwd",
+    "a8_contrastive_fwd", "a8_contrastive_bwd", "a8_ctc_greedy_decode",
     "a8_ctc_fwd_bwd", "a8_log_softmax_fwd", "a8_log_softmax_bwd",
     "a8_sumsq", "a8_adamw",
 ]

@@ -176,6 +176,39 @@ __global__ __launch_bounds__(64) void ctc_kernel(const float* __restrict__ lp, c
     }
 }
 
+// ---- greedy decode (audio8/ctc.py:156-159: argmax over labels, unique_consecutive, drop blanks), one wave per
+// utterance: lane = frame within a 64-frame chunk, neighbours by shuffle, survivors compacted with a ballot prefix.
+template <typename T>
+__global__ __launch_bounds__(64) void ctc_greedy_kernel(const T* __restrict__ lp, const int32_t* __restrict__ in_len,
+                                                        int32_t* __restrict__ tokens, int32_t* __restrict__ out_len,
+                                                        int Tn, int V, long long stride_b, long long stride_t, int blank) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int n = min(in_len[b], Tn);
+    const T* base = lp + (long long)b * stride_b;
+    int prev_last = -1, count = 0;
+    for (int t0 = 0; t0 < n; t0 += 64) {
+        const int t = t0 + lane;
+        int best = -1;
+        if (t < n) {
+            const T* row = base + (long long)t * stride_t;
+            float bv = to_f(row[0]);
+            best = 0;
+            for (int v = 1; v < V; ++v) {
+                const float x = to_f(row[v]);
+                if (x > bv) { bv = x; best = v; }          // first maximum wins, as torch.argmax
+            }
+        }
+        int prev = __shfl_up(best, 1, 64);
+        if (lane == 0) prev = prev_last;
+        const bool keep = t < n && best != prev && best != blank;
+        const unsigned long long m = __ballot(keep);
+        if (keep) tokens[(long long)b * Tn + count + __popcll(m & ((1ull << lane) - 1ull))] = best;
+        count += __popcll(m);
+        prev_last = __shfl(best, 63, 64);
+    }
+    if (lane == 0) out_len[b] = count;
+}
+
 }  // namespace
 
 extern "C" int a8_ctc_fwd_bwd(const float* lp, const int32_t* targets, const int32_t* tgt_off, const int32_t* in_len,
@@ -196,4 +229,15 @@ extern "C" int a8_ctc_fwd_bwd(const float* lp, const int32_t* targets, const int
     else A8_CTC_LAUNCH(16);
 #undef A8_CTC_LAUNCH
     return a8_check_launch("a8_ctc_fwd_bwd");
+}
+
+extern "C" int a8_ctc_greedy_decode(int dtype, const void* lp, const int32_t* in_len, int32_t* tokens, int32_t* out_len,
+                                    int B, int T_, int V, int64_t stride_b, int64_t stride_t, int blank, void* stream) {
+    A8_REQUIRE(T_ >= 1 && B >= 1 && V >= 1, "a8_ctc_greedy_decode: bad sizes T=%d B=%d V=%d", T_, B, V);
+    A8_REQUIRE(blank >= 0 && blank < V, "a8_ctc_greedy_decode: bad blank index");
+    A8_REQUIRE(dtype == A8_F32 || dtype == A8_BF16, "a8_ctc_greedy_decode: bad dtype");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == A8_F32) hipLaunchKernelGGL(ctc_greedy_kernel<float>, dim3(B), dim3(64), 0, s, (const float*)lp, in_len, tokens, out_len, T_, V, (long long)stride_b, (long long)stride_t, blank);
+    else hipLaunchKernelGGL(ctc_greedy_kernel<bf16>, dim3(B), dim3(64), 0, s, (const bf16*)lp, in_len, tokens, out_len, T_, V, (long long)stride_b, (long long)stride_t, blank);
+    return a8_check_launch("a8_ctc_greedy_decode");
 }

@@ -37,19 +37,35 @@ def edit_distance(a, b) -> int:
     return prev[-1]
 
 
+def _greedy_units(lprobs_t, input_lengths):
+    """Per utterance: argmax -> unique_consecutive -> drop blanks (audio8/ctc.py:156-159).  Device tensors go through the
+    a8_ctc_greedy_decode kernel (one D2H copy of the token table); host tensors are decoded on the host like the reference."""
+    BLANK_IDX = Offsets.GO
+    if lprobs_t.is_cuda:
+        from . import kernels as K
+        in_len = (input_lengths if torch.is_tensor(input_lengths) else torch.as_tensor(input_lengths)).to(device=lprobs_t.device, dtype=torch.int64)
+        in_len = in_len.clamp(max=lprobs_t.shape[1]).to(torch.int32).contiguous()
+        tokens, lens = K.ctc_greedy_decode(lprobs_t, in_len, BLANK_IDX)
+        tokens, lens = tokens.cpu().numpy(), lens.cpu().numpy()
+        return [tokens[b, :lens[b]].tolist() for b in range(tokens.shape[0])]
+    out = []
+    for lp, inp_l in zip(lprobs_t, input_lengths):
+        toks = lp[:inp_l].argmax(dim=-1).unique_consecutive()
+        out.append(toks[toks != BLANK_IDX].tolist())
+    return out
+
+
 def ctc_metrics(lprobs_t, target, input_lengths, index2vocab, postproc_fn=postproc_letters):
     """Greedy CTC decode + CER/WER counts.  Keeps the reference's quirk of slicing frames by the
     *sample* length (audio8/ctc.py:156 with audio8/train.py:47)."""
-    BLANK_IDX = Offsets.GO
     c_err = c_len = w_errs = w_len = wv_errs = 0
     with torch.no_grad():
-        for lp, t, inp_l in zip(lprobs_t, target, input_lengths):
-            lp = lp[:inp_l].unsqueeze(0)
+        preds = _greedy_units(lprobs_t, input_lengths)
+        target = target.cpu() if torch.is_tensor(target) and target.is_cuda else target
+        for pred_units_arr, t in zip(preds, target):
             p = (t != Offsets.PAD) & (t != Offsets.EOS)
             targ = t[p]
             targ_units_arr = targ.tolist()
-            toks = lp.argmax(dim=-1).unique_consecutive()
-            pred_units_arr = toks[toks != BLANK_IDX].tolist()
             c_err += edit_distance(pred_units_arr, targ_units_arr)
             c_len += len(targ_units_arr)
             targ_words = postproc_fn([index2vocab[x] for x in targ_units_arr]).split()

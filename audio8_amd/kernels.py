@@ -320,6 +320,20 @@ def contrastive_bwd(ctx, lat, neg_idx, logits, gscale, rows_per_group=0):
 
 
 # ----------------------------------------------------------------------------- CTC + log-softmax
+def ctc_greedy_decode(lprobs, in_len_i32, blank=0):
+    """lprobs [B,T,V] (any strides on B and T, V contiguous) -> (tokens i32 [B,T], lengths i32 [B]) on the device."""
+    L.require_cuda(lprobs, in_len_i32)
+    B, T, V = lprobs.shape
+    if lprobs.stride(2) != 1:
+        lprobs = lprobs.contiguous()
+    tokens = torch.empty((B, T), device=lprobs.device, dtype=torch.int32)
+    lens = torch.empty((B,), device=lprobs.device, dtype=torch.int32)
+    L.check(L.lib().a8_ctc_greedy_decode(L.dt(lprobs), L.ptr(lprobs), L.ptr(in_len_i32), L.ptr(tokens), L.ptr(lens), B, T, V,
+                                         int(lprobs.stride(0)), int(lprobs.stride(1)), int(blank), L.stream()), "a8_ctc_greedy_decode")
+    return tokens, lens
+
+
+
 def ctc_fwd_bwd(lp, targets_flat_i32, tgt_off_i32, in_len_i32, Smax, blank=0, zero_infinity=True):
     T, B, V = lp.shape
     nll = torch.empty((B,), device=lp.device, dtype=torch.float32)

@@ -181,6 +181,11 @@ int a8_contrastive_bwd(int dtype, const void* ctx, const void* lat, const int32_
 int a8_ctc_fwd_bwd(const float* lp, const int32_t* targets, const int32_t* tgt_off, const int32_t* in_len,
                    float* nll, float* grad, float* alpha, int T, int B, int V, int Smax, int blank, int zero_infinity,
                    void* stream);
+/* greedy decode for the metrics (audio8/ctc.py:156-159): per utterance argmax over labels of frames [0, min(in_len, T)),
+ * collapse repeats, drop blanks.  lp element (b,t,v) at b*stride_b + t*stride_t + v.  tokens i32 [B,T] (first out_len[b]
+ * entries of row b valid), out_len i32 [B]. */
+int a8_ctc_greedy_decode(int dtype, const void* lp, const int32_t* in_len, int32_t* tokens, int32_t* out_len,
+                         int B, int T, int V, int64_t stride_b, int64_t stride_t, int blank, void* stream);
 int a8_log_softmax_fwd(const void* x, int dtype, float* y, int rows, int cols, void* stream);
 int a8_log_softmax_bwd(const float* y, const float* dy, void* dx, int dtype, int rows, int cols, void* stream);
 

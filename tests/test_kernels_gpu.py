@@ -513,3 +513,36 @@ def test_sumsq_adamw_matches_torch():
         np.testing.assert_allclose(gsq.item(), (gr.double() ** 2).sum().item(), rtol=1e-5)
         K.adamw_(flat, gd, m, v, 2e-4, 0.9, 0.999, 1e-8, 1e-2, step, gsq, 1.0)
         close(flat, p.data, 2e-6)
+
+
+# ------------------------------------------------------------------ greedy CTC decode (metrics path)
+@pytest.mark.parametrize("dtype", DT)
+def test_ctc_greedy_decode_matches_host(dtype):
+    """a8_ctc_greedy_decode == argmax -> unique_consecutive -> drop blanks per utterance (audio8/ctc.py:156-159), incl.
+    runs that straddle the 64-frame chunks, all-blank rows, ragged lengths, ties, and ctc_metrics end to end."""
+    from audio8_amd import kernels as K, ctc as Cc
+    torch.manual_seed(5)
+    B, T, V = 6, 333, 32
+    # piecewise-constant label runs so that repeats and blanks are frequent
+    lab = torch.randint(0, V, (B, T // 3 + 1)).repeat_interleave(3, dim=1)[:, :T]
+    lab[lab % 3 == 0] = 0                                   # many blanks
+    lab[1] = 0                                              # an all-blank utterance
+    lp = torch.randn(B, T, V) * 0.1
+    lp.scatter_(2, lab.unsqueeze(-1), 3.0)
+    lp[2, 5, :] = 1.0                                        # a full tie: argmax must pick label 0 (first maximum)
+    lp = torch.log_softmax(lp, -1).to(dtype)
+    lens = torch.tensor([T, T, 200, 64, 65, 1])
+    tok, n = K.ctc_greedy_decode(lp.cuda(), lens.to(torch.int32).cuda(), 0)
+    tok, n = tok.cpu(), n.cpu()
+    for b in range(B):
+        ref = lp[b, :lens[b]].float().argmax(-1).unique_consecutive()
+        ref = ref[ref != 0].tolist()
+        assert tok[b, :n[b]].tolist() == ref, b
+    # metrics: device path == host path, with the reference's sample-length quirk (lengths far beyond T)
+    vocab = {i: (c if i >= 4 else "") for i, c in enumerate(["<s>", "<pad>", "</s>", "<unk>"] + list("|abcdefghijklmnopqrstuvwxyz'"))}
+    target = torch.randint(4, V, (B, 40))
+    target[:, 30:] = Cc.Offsets.PAD
+    sample_lens = torch.full((B,), 100000)
+    m_host = Cc.ctc_metrics(lp.float(), target, sample_lens, vocab)
+    m_dev = Cc.ctc_metrics(lp.cuda(), target.cuda(), sample_lens.cuda(), vocab)
+    assert m_host == m_dev and m_host["c_total"] == B * 30
