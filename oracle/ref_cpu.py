@@ -493,3 +493,20 @@ def init_state_dict(seed=0, d_model=768, num_heads=12, num_layers=12, d_ff=None,
         sd["proj.weight"] = f32(rs.uniform(-b, b, (ctc_labels, d_model)))
         sd["proj.bias"] = f32(np.zeros(ctc_labels))
     return sd
+
+
+def crop_to_min_batches(samples, max_length, target_tokens_per_batch):
+    """AudioFileDataset.__iter__ (audio8/data.py:409-426) restated: accumulate samples while len(samples) * min_length is
+    below the budget; once it is not, yield the accumulated samples cropped to min_length and DROP the sample in hand
+    (the reference only appends inside the `if`); min_length carries over to the next batch."""
+    out = []
+    min_length, predicted, acc = max_length, 0, []
+    for smp in samples:
+        if predicted < target_tokens_per_batch:
+            min_length = min(min_length, len(smp))
+            acc.append(smp)
+            predicted = len(acc) * min_length
+        else:
+            out.append(np.stack([x[:min_length] for x in acc]))
+            acc, predicted = [], 0
+    return out

@@ -111,3 +111,23 @@ def test_ctc_metrics_and_edit_distance():
     tgt = torch.tensor([[5, 5, 4, 6, 6, 2, 1, 1]])
     assert Cc.ctc_metrics(lp, tgt, [10 ** 6], vocab) == dict(wv_errors=1, w_errors=1, w_total=2, c_errors=1, c_total=5)
     assert Cc.edit_distance("kitten", "sitting") == 3 and Cc.edit_distance([], [1, 2]) == 2
+
+
+def test_crop_to_min_batching_matches_oracle_incl_dropped_sample_quirk():
+    """audio8_amd.onramp.crop_to_min_batches against the oracle's restatement of AudioFileDataset.__iter__
+    (audio8/data.py:409-426) on ragged inputs; the sample that arrives when the budget is full is dropped."""
+    from audio8_amd.onramp import crop_to_min_batches
+    from oracle import ref_cpu as R
+    rng = np.random.default_rng(0)
+    for trial in range(5):
+        lens = rng.integers(50, 400, size=60)
+        samples = [np.arange(n, dtype=np.float32) + 1000 * i for i, n in enumerate(lens)]
+        got = [np.stack(b) for b in crop_to_min_batches(iter(samples), 300, 1200)]
+        want = R.crop_to_min_batches(samples, 300, 1200)
+        assert len(got) == len(want) >= 2
+        for g, w in zip(got, want):
+            np.testing.assert_array_equal(g, w)
+    # the quirk, explicitly: with budget 2 * 100 the third sample closes the batch and never appears anywhere
+    s = [np.full(100, i, dtype=np.float32) for i in range(6)]
+    b = [np.stack(x) for x in crop_to_min_batches(iter(s), 100, 200)]
+    assert [sorted(set(x[:, 0].tolist())) for x in b] == [[0.0, 1.0], [3.0, 4.0]]

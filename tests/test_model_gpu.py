@@ -433,3 +433,30 @@ def test_bucketed_reducer_on_gpu_streams_with_fake_collective(restore_dtype, mon
         a, b = double[k].numpy(), single[k].numpy()
         # one Adam step moves each element by ~lr = 1e-3; elements with rounding-level gradients may differ by a fraction of it
         assert np.isfinite(a).all() and np.abs(a - b).max() < 2.5e-3, (k, float(np.abs(a - b).max()))
+
+
+def test_batch_onramp_uploads_cropped_batches():
+    """BatchOnRamp: ragged host waveforms -> [B, min_len] device batch through pinned double buffers on a copy stream;
+    contents equal the host crop/stack, slots are reused safely, over-submission is refused."""
+    from audio8_amd.onramp import BatchOnRamp
+    rng = np.random.default_rng(1)
+    ramp = BatchOnRamp(depth=2)
+    want = []
+    outs = []
+    for step in range(5):
+        lens = rng.integers(1000, 5000, size=4)
+        samples = [rng.standard_normal(n).astype(np.float32) for n in lens]
+        ramp.submit(samples)
+        want.append(np.stack([s[:lens.min()] for s in samples]))
+        if step >= 1:                                   # keep one batch in flight, like a training loop
+            outs.append(ramp.get())
+    outs.append(ramp.get())
+    torch.cuda.synchronize()
+    assert len(outs) == len(want)
+    for o, w in zip(outs, want):
+        assert o.is_cuda and o.dtype == torch.float32
+        np.testing.assert_array_equal(o.cpu().numpy(), w)
+    ramp.submit([np.zeros(10, np.float32)])
+    ramp.submit([np.zeros(10, np.float32)])
+    with pytest.raises(RuntimeError):
+        ramp.submit([np.zeros(10, np.float32)])
