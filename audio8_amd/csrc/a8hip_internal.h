@@ -3,5 +3,6 @@
 #include "../../include/a8hip.h"
 
 // a8_set_tuning table (runtime.hip): [0] GEMM variant, [1] ln_bwd geometry NW*100 + rows per wave,
-// [2..4] attention fwd / dK,dV / dQ geometry NW*10 + row groups per wave, [6] posconv wgrad loop splits
+// [2..4] attention fwd / dK,dV / dQ geometry NW*10 + row groups per wave, [5] min tiles for the register-pipelined NT
+// GEMM (0 = off), [6] posconv wgrad loop splits
 extern int g_a8_tuning[8];

@@ -55,7 +55,10 @@ int a8_gemm(const a8_gemm_desc* d, void* stream);
  * weight-gradient products of an encoder layer fill the chip together without split-K.  Replaces the same
  * per-parameter autograd GEMMs as a8_gemm. */
 int a8_gemm_grouped(const a8_gemm_desc* descs, int n, void* stream);
-/* developer tuning knob (key 0: GEMM stage geometry variant); never needed for correctness */
+/* developer tuning knobs, never needed for correctness (defaults are the measured best): key 0 GEMM stage geometry
+ * variant; 1 LayerNorm-backward geometry (waves*100 + rows per wave); 2..4 attention fwd / dK,dV / dQ geometry (waves*10 +
+ * 16-row groups per wave); 5 minimum tile count for the experimental register-pipelined 256x128 NT GEMM (0 = off);
+ * 6 positional-conv weight-gradient loop splits */
 int a8_set_tuning(int key, int value);
 
 /* ---- per-step weight preparation (the f32 -> compute-dtype casts the reference's autocast-free f32 path never needs;
