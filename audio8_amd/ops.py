@@ -687,53 +687,55 @@ class EncoderLayerFn(torch.autograd.Function):
 # ------------------------------------------------------------------ Gumbel vector quantiser
 class VQFn(torch.autograd.Function):
     """GumbelVectorQuantizer.forward (audio8/wav2vec2.py:547-576): returns (q [N, G*D], prob_ppl [1]).
-    The 512->G*V projection runs in exact f32 (2944 rows: negligible) so code selection tracks the
-    f32 reference as closely as possible; `gumbel` injects the noise (None: drawn with torch's recipe)."""
+    The 512->G*V projection and its gradients run in the compute dtype like every other Linear (f32 logits out of the bf16
+    MFMA in bf16 mode: the exact-f32 GEMM path is a latency-bound 0.3 ms per step for 2 GFLOP); selection, softmax statistics
+    and perplexity are f32.  `gumbel` injects the noise (None: drawn with torch's recipe)."""
 
     @staticmethod
     def forward(ctx, y, wp, bp, vars_, G, V, tau, training, gumbel):
         N, Cin = y.shape
         D = vars_.shape[-1]
-        yf = y if y.dtype == torch.float32 else K.cast(y.contiguous(), torch.float32)
-        logits = K.gemm(L.NT, yf, wp.detach().contiguous(), N, G * V, Cin, bias=bp.detach()).view(N * G, V)
+        y = y.contiguous()
+        wpc = _wcast(wp, y.dtype).contiguous()
+        logits = K.gemm(L.NT, y, wpc, N, G * V, Cin, bias=bp.detach(), out_dtype=torch.float32).view(N * G, V)
         if training and gumbel is None:
             gumbel = -torch.empty_like(logits).exponential_().log()
         vars2d = vars_.detach().reshape(G * V, D)
         codes, avg = K.vq_select(logits, gumbel if training else None, tau)
         q = K.vq_gather(vars2d, codes, N, G, V, D, y.dtype)
         ppl, dppl = K.vq_ppl(avg)
-        ctx.save_for_backward(yf, wp, logits, gumbel if training else None, codes, vars2d, dppl)
-        ctx.cfg = (G, V, D, tau, training, y.dtype, vars_.shape)
+        ctx.save_for_backward(y, wpc, logits, gumbel if training else None, codes, vars2d, dppl)
+        ctx.cfg = (G, V, D, tau, training, vars_.shape)
         ctx.params = (wp, bp, vars_)
         ctx.mark_non_differentiable(codes)
         return q, ppl, codes
 
     @staticmethod
     def backward(ctx, dq, dppl_out, _dcodes):
-        yf, wp, logits, gumbel, codes, vars2d, dppl = ctx.saved_tensors
-        G, V, D, tau, training, ydt, vshape = ctx.cfg
-        N, Cin = yf.shape
-        dev = yf.device
-        dqf = dq.contiguous()
-        if dqf.dtype != torch.float32:
-            dqf = K.cast(dqf, torch.float32)
+        y, wpc, logits, gumbel, codes, vars2d, dppl = ctx.saved_tensors
+        G, V, D, tau, training, vshape = ctx.cfg
+        N, Cin = y.shape
+        dev, dt = y.device, y.dtype
+        dqc = dq.contiguous()
+        if dqc.dtype != dt:
+            dqc = K.cast(dqc, dt)
         eproj = None
         if training:
             eproj = torch.empty((N, G * V), device=dev, dtype=torch.float32)
+            vars_c = vars2d if dt == torch.float32 else K.cast(vars2d.contiguous(), dt)
             for g in range(G):
-                K.gemm(L.NT, dqf[:, g * D:], vars2d[g * V:], N, V, D, lda=G * D, out=eproj[:, g * V:], ldc=G * V)
+                K.gemm(L.NT, dqc, vars_c[g * V:], N, V, D, lda=G * D, a_off=g * D, out=eproj, c_off=g * V, ldc=G * V)
         pwp, pbp, pvars = ctx.params
         tv = _target(pvars)
         dvars = tv.view(G * V, D) if tv is not None else torch.zeros_like(vars2d)
         gppl = dppl_out.contiguous().float() if dppl_out is not None else torch.zeros(1, device=dev)
-        dlogits = K.vq_bwd(logits, gumbel, tau, codes, vars2d, dqf, eproj, dppl, gppl, dvars, N, G, V, D, training).view(N, G * V)
+        dlogits = K.vq_bwd(logits, gumbel, tau, codes, vars2d, dqc, eproj, dppl, gppl, dvars, N, G, V, D, training).view(N, G * V)
         if tv is not None:
             _ready(pvars)
-        dwp = acc_wgrad(pwp, dlogits, yf, G * V, Cin, N)
         dbp = acc_colsum(pbp, dlogits)
-        dy = K.gemm(L.NN, dlogits, wp.detach().contiguous(), N, Cin, G * V)
-        if ydt != torch.float32:
-            dy = K.cast(dy, ydt)
+        dl = dlogits if dt == torch.float32 else K.cast(dlogits, dt)
+        dwp = acc_wgrad(pwp, dl, y, G * V, Cin, N)
+        dy = K.gemm(L.NN, dl, wpc, N, Cin, G * V)
         return dy, dwp, dbp, (None if tv is not None else dvars.view(vshape)), None, None, None, None, None
 
 
