@@ -360,8 +360,8 @@ extern "C" int a8_contrastive_bwd(int dtype, const void* ctx, const void* lat, c
     A8_REQUIRE(dtype == A8_BF16 || dtype == A8_F32, "a8_contrastive_bwd: bad dtype");
     if (rows == 0) return A8_OK;
     const int rpg = rows_per_group;
-    const bool grouped = rpg > 0 && rows % rpg == 0;
-    const int rpg4 = (rpg + 3) & ~3;                     // the f32 TN GEMM wants M % 4 == 0: W rows are padded with zero columns
+    const bool grouped = rpg > 0 && rows % rpg == 0 && (dtype != A8_BF16 || rpg <= 504);   // (the bf16 copy of W reuses the Cf slab)
+    const int rpg4 = (rpg + 7) & ~7;                     // the TN GEMM wants M % 4 (f32) / % 8 (bf16) == 0: W rows are padded with zero columns
     // scratch: ic[rows] il[rows] wA[rows*(N+1)] wU[rows*(N+1)] | U[rows] W[rows*rpg] Cf[rows*256] G[rows*256]
     auto al4 = [](size_t n) { return (n + 3) & ~(size_t)3; };              // sub-buffers start 16-byte aligned (GEMM operands)
     A8_REQUIRE(((uintptr_t)scratch & 15) == 0, "a8_contrastive_bwd: scratch must be 16-byte aligned");
@@ -394,11 +394,16 @@ extern "C" int a8_contrastive_bwd(int dtype, const void* ctx, const void* lat, c
     if (int e = a8_check_launch("a8_contrastive_bwd")) return e;
     if (!grouped) return A8_OK;
     // G_b [rpg, 256] = W_b^T [rpg x rpg] . C_b [rpg x 256] in exact f32, 8 utterances per grouped launch
-    const float* cf = (const float*)ctx;
+    // G_b [rpg, 256] = W_b^T [rpg x rpg] . C_b [rpg x 256], 8 utterances per grouped launch: exact f32 in f32 mode; in
+    // bf16 mode the coefficient matrix is rounded to bf16 (the result is rounded to bf16 by the caller anyway) and the
+    // product runs on the bf16 MFMA straight from the bf16 context rows
+    const void* amat = W;
+    const void* bmat = ctx;
     if (dtype == A8_BF16) {
-        if (int e = a8_cast(A8_BF16, A8_F32, ctx, Cf, (int64_t)rows * 256, stream)) return e;
-        cf = Cf;
+        if (int e = a8_cast(A8_F32, A8_BF16, W, Cf, (int64_t)rows * rpg4, stream)) return e;     // Cf: rows*256 floats >= rows*rpg4 bf16
+        amat = Cf;
     }
+    const int esz = dtype == A8_BF16 ? 2 : 4;
     const int ngrp = rows / rpg;
     for (int g0 = 0; g0 < ngrp; g0 += 8) {
         a8_gemm_desc d[8];
@@ -406,9 +411,9 @@ extern "C" int a8_contrastive_bwd(int dtype, const void* ctx, const void* lat, c
         for (int i = 0; i < cnt; ++i) {
             const size_t off = (size_t)(g0 + i) * rpg;
             d[i] = a8_gemm_desc{};
-            d[i].dtype = A8_F32; d[i].layout = A8_GEMM_TN; d[i].M = rpg4; d[i].N = 256; d[i].K = rpg;
-            d[i].A = W + off * rpg4; d[i].lda = rpg4;
-            d[i].B = cf + off * 256; d[i].ldb = 256;
+            d[i].dtype = dtype; d[i].layout = A8_GEMM_TN; d[i].M = rpg4; d[i].N = 256; d[i].K = rpg;
+            d[i].A = (const char*)amat + off * rpg4 * esz; d[i].lda = rpg4;
+            d[i].B = (const char*)bmat + off * 256 * esz; d[i].ldb = 256;
             d[i].C = G + (size_t)(g0 + i) * rpg4 * 256; d[i].ldc = 256;
             d[i].out_f32 = 1; d[i].splitk = 1; d[i].alpha = 1.0f;
         }

@@ -313,7 +313,7 @@ def contrastive_bwd(ctx, lat, neg_idx, logits, gscale, rows_per_group=0):
     N = neg_idx.shape[1]
     dctx = torch.empty((rows, Cn), device=ctx.device, dtype=torch.float32)
     dlat = torch.zeros((rows, Cn), device=ctx.device, dtype=torch.float32)
-    scratch = torch.empty((rows * (2 + 2 * (N + 1) + 1 + int(rows_per_group) + 3 + 768) + 32,), device=ctx.device, dtype=torch.float32)    # A8_CONTRASTIVE_BWD_SCRATCH_FLOATS
+    scratch = torch.empty((rows * (2 + 2 * (N + 1) + 1 + int(rows_per_group) + 7 + 768) + 32,), device=ctx.device, dtype=torch.float32)    # A8_CONTRASTIVE_BWD_SCRATCH_FLOATS
     L.check(L.lib().a8_contrastive_bwd(L.dt(ctx), L.ptr(_c(ctx)), L.ptr(_c(lat)), L.ptr(_c(neg_idx)), L.ptr(logits), L.ptr(gscale),
                                        L.ptr(dctx), L.ptr(dlat), L.ptr(scratch), rows, N, Cn, int(rows_per_group), L.stream()), "a8_contrastive_bwd")
     return dctx, dlat

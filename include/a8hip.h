@@ -173,7 +173,7 @@ int a8_contrastive_fwd(int dtype, const void* ctx, const void* lat, const int32_
  * global atomics per pair (any pair that does not obey it is still handled); 0 = no assumption.
  * scratch: A8_CONTRASTIVE_BWD_SCRATCH_FLOATS(rows, N, rows_per_group) floats, 16-byte aligned. */
 #define A8_CONTRASTIVE_BWD_SCRATCH_FLOATS(rows, N, rows_per_group) \
-    ((size_t)(rows) * (2 + 2 * ((N) + 1) + 1 + ((size_t)(rows_per_group) + 3) + 256 + 2 * 256) + 32)
+    ((size_t)(rows) * (2 + 2 * ((N) + 1) + 1 + ((size_t)(rows_per_group) + 7) + 256 + 2 * 256) + 32)
 int a8_contrastive_bwd(int dtype, const void* ctx, const void* lat, const int32_t* neg_idx, const float* logits,
                        const float* gscale, float* dctx, float* dlat, float* scratch, int rows, int N, int C,
                        int rows_per_group, void* stream);
