@@ -44,6 +44,10 @@ ARGTYPES = {
     "a8_add": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
     "a8_posconv_fwd": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "a8_posconv_wgrad": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "a8_loss_combine": [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p],
+    "a8_loss_combine_bwd": [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p],
+    "a8_weightnorm_pack": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "a8_weightnorm_bwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "a8_gelu_bwd_bias": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p],
     "a8_attn_fwd": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_uint32, C.c_void_p],
     "a8_attn_bwd": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_uint32, C.c_void_p],
@@ -138,10 +142,10 @@ EXPORTS = [
     "a8_layernorm_fwd", "a8_layernorm_bwd",
     "a8_cast", "a8_dropout", "a8_mask_fill_rows", "a8_mask_fill_rows_bwd", "a8_mask_zero_cols", "a8_zero_rows",
     "a8_gather_rows", "a8_scatter_add_rows", "a8_add",
-    "a8_posconv_fwd", "a8_posconv_wgrad", "a8_gelu_bwd_bias",
+    "a8_posconv_fwd", "a8_posconv_wgrad", "a8_weightnorm_pack", "a8_weightnorm_bwd", "a8_gelu_bwd_bias",
     "a8_attn_fwd", "a8_attn_bwd",
     "a8_vq_select", "a8_vq_gather", "a8_vq_ppl", "a8_vq_bwd",
-    "a8_contrastive_fwd", "a8_contrastive_bwd", "a8_ctc_greedy_decode",
+    "a8_contrastive_fwd", "a8_contrastive_bwd", "a8_loss_combine", "a8_loss_combine_bwd", "a8_ctc_greedy_decode",
     "a8_ctc_fwd_bwd", "a8_log_softmax_fwd", "a8_log_softmax_bwd",
     "a8_sumsq", "a8_adamw",
 ]

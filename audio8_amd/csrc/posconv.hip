@@ -245,6 +245,114 @@ __global__ __launch_bounds__(256) void posconv_wgrad_kernel(const char* __restri
     }
 }
 
+// ------------------------------------------------------------------ weight norm (nn.utils.weight_norm(dim=2))
+// v f32 [d][dg][k]; w[o][ci][kk] = g[kk] * v[o][ci][kk] / ||v[:, :, kk]||  (audio8/wav2vec2.py:609).
+// Three small launches each way instead of the tape's dozen element-wise passes over the 4.7 M-element kernel:
+// per-output-channel partial sums -> one reducing block -> a transposing pass that writes the operand images of
+// posconv_fwd_kernel (forward) or accumulates dv (backward).  Slabs go through a padded LDS tile so that both the
+// global read and the global write are contiguous.
+constexpr int WN_MAXK = 128, WN_MAXDG = 64;
+
+// part[o][kk] = sum_ci v[o][ci][kk]^2                              (dwg == nullptr)
+//             = sum_ci dwg[o][kk][ci] * v[o][ci][kk]               (backward: dwg is [d][k][dg])
+__global__ __launch_bounds__(256) void wn_partial_kernel(const float* __restrict__ v, const float* __restrict__ dwg,
+                                                         float* __restrict__ part, int dg, int k) {
+    __shared__ float tile[WN_MAXK * (WN_MAXDG + 1)];
+    const int o = blockIdx.x, n = dg * k;
+    const float* vo = v + (size_t)o * n;
+    if (dwg) {
+        const float* dwo = dwg + (size_t)o * n;
+        for (int e = threadIdx.x; e < n; e += 256) tile[(e / dg) * (dg + 1) + e % dg] = dwo[e];
+        __syncthreads();
+    }
+    for (int kk = threadIdx.x; kk < k; kk += 256) {
+        float acc = 0.f;
+        for (int ci = 0; ci < dg; ++ci) {
+            const float x = vo[ci * k + kk];
+            acc += dwg ? tile[kk * (dg + 1) + ci] * x : x * x;
+        }
+        part[(size_t)o * k + kk] = acc;
+    }
+}
+
+// fwd (dg_out == nullptr): stat[kk] = 1 / sqrt(sum_o part[o][kk])            (inverse norm)
+// bwd: stat[kk] = dot[kk] = sum_o part[o][kk];  dg_out[kk] += dot[kk] * inv_norm[kk]
+__global__ __launch_bounds__(1024) void wn_reduce_kernel(const float* __restrict__ part, const float* __restrict__ inv_norm,
+                                                         float* __restrict__ stat, float* __restrict__ dg_out, int d, int k) {
+    __shared__ float red[1024];
+    const int rows = 1024 / k, r = threadIdx.x / k, kk = threadIdx.x % k;       // k divides 1024 (checked by the host)
+    float acc = 0.f;
+    for (int o = r; o < d; o += rows) acc += part[(size_t)o * k + kk];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (r == 0) {
+        for (int j = 1; j < rows; ++j) acc += red[j * k + kk];
+        if (dg_out) {
+            stat[kk] = acc;
+            dg_out[kk] += acc * inv_norm[kk];
+        } else {
+            stat[kk] = 1.0f / sqrtf(acc);
+        }
+    }
+}
+
+// blockIdx.y = 0: wf[o][kk][ci] = s[kk] v[o][ci][kk]                 (o = g*dg + co: [G][co][kk][ci])
+// blockIdx.y = 1: block b = (g, ci): wt[g][ci][kk'][co] = s[k-1-kk'] v[g*dg+co][ci][k-1-kk'],  s = g * inv_norm
+template <typename T>
+__global__ __launch_bounds__(256) void wn_pack_kernel(const float* __restrict__ v, const float* __restrict__ gain,
+                                                      const float* __restrict__ inv_norm, T* __restrict__ wf, T* __restrict__ wt,
+                                                      int dg, int k) {
+    __shared__ float tile[WN_MAXDG * (WN_MAXK + 1)];
+    __shared__ float sc[WN_MAXK];
+    const int b = blockIdx.x, n = dg * k;
+    for (int kk = threadIdx.x; kk < k; kk += 256) sc[kk] = gain[kk] * inv_norm[kk];
+    if (blockIdx.y == 0) {
+        const float* vo = v + (size_t)b * n;
+        for (int e = threadIdx.x; e < n; e += 256) tile[(e / k) * (k + 1) + e % k] = vo[e];
+        __syncthreads();
+        T* dst = wf + (size_t)b * n;
+        for (int e = threadIdx.x; e < n; e += 256) {
+            const int kk = e / dg, ci = e % dg;
+            dst[e] = from_f<T>(tile[ci * (k + 1) + kk] * sc[kk]);
+        }
+    } else {
+        const int g = b / dg, ci = b % dg;
+        for (int e = threadIdx.x; e < n; e += 256) {
+            const int co = e / k, kk = e % k;
+            tile[co * (k + 1) + kk] = v[((size_t)(g * dg + co) * dg + ci) * k + kk];
+        }
+        __syncthreads();
+        T* dst = wt + (size_t)b * n;
+        for (int e = threadIdx.x; e < n; e += 256) {
+            const int kf = k - 1 - e / dg, co = e % dg;
+            dst[e] = from_f<T>(tile[co * (k + 1) + kf] * sc[kf]);
+        }
+    }
+}
+
+// dv[o][ci][kk] += s[kk] * (dwg[o][kk][ci] - v[o][ci][kk] * dot[kk] * inv_norm[kk]^2)
+__global__ __launch_bounds__(256) void wn_bwd_kernel(const float* __restrict__ dwg, const float* __restrict__ v,
+                                                     const float* __restrict__ gain, const float* __restrict__ inv_norm,
+                                                     const float* __restrict__ dot, float* __restrict__ dv, int dg, int k) {
+    __shared__ float tile[WN_MAXK * (WN_MAXDG + 1)];
+    __shared__ float sc[WN_MAXK], pj[WN_MAXK];
+    const int o = blockIdx.x, n = dg * k;
+    for (int kk = threadIdx.x; kk < k; kk += 256) {
+        const float in = inv_norm[kk];
+        sc[kk] = gain[kk] * in;
+        pj[kk] = dot[kk] * in * in;
+    }
+    const float* dwo = dwg + (size_t)o * n;
+    for (int e = threadIdx.x; e < n; e += 256) tile[(e / dg) * (dg + 1) + e % dg] = dwo[e];
+    __syncthreads();
+    const float* vo = v + (size_t)o * n;
+    float* dvo = dv + (size_t)o * n;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const int ci = e / k, kk = e % k;
+        dvo[e] += sc[kk] * (tile[kk * (dg + 1) + ci] - vo[e] * pj[kk]);
+    }
+}
+
 }  // namespace
 
 extern "C" int a8_posconv_fwd(int dtype, const void* x, const void* w, const float* bias, void* y, void* z,
@@ -288,4 +396,33 @@ extern "C" int a8_posconv_wgrad(int dtype, const void* x, const void* dz, float*
         else hipLaunchKernelGGL((posconv_wgrad_kernel<float, 64>), grid, dim3(256), 0, s, (const char*)x, (const char*)dz, dw, B, T_, d, pad_left);
     }
     return a8_check_launch("a8_posconv_wgrad");
+}
+
+extern "C" int a8_weightnorm_pack(int dtype, const float* v, const float* g, void* wf, void* wt, float* inv_norm, float* scratch,
+                                  int d, int groups, int k, void* stream) {
+    A8_REQUIRE(groups >= 1 && d % groups == 0, "a8_weightnorm_pack: d=%d not divisible by groups=%d", d, groups);
+    const int dg = d / groups;
+    A8_REQUIRE(k >= 1 && k <= WN_MAXK && 1024 % k == 0 && dg <= WN_MAXDG, "a8_weightnorm_pack: k=%d must divide 1024 (<= %d), d/groups=%d <= %d",
+               k, WN_MAXK, dg, WN_MAXDG);
+    A8_REQUIRE(dtype == A8_F32 || dtype == A8_BF16, "a8_weightnorm_pack: bad dtype");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(wn_partial_kernel, dim3(d), dim3(256), 0, s, v, (const float*)nullptr, scratch, dg, k);
+    hipLaunchKernelGGL(wn_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)scratch, (const float*)nullptr, inv_norm, (float*)nullptr, d, k);
+    if (dtype == A8_BF16) hipLaunchKernelGGL(wn_pack_kernel<bf16>, dim3(d, 2), dim3(256), 0, s, v, g, (const float*)inv_norm, (bf16*)wf, (bf16*)wt, dg, k);
+    else hipLaunchKernelGGL(wn_pack_kernel<float>, dim3(d, 2), dim3(256), 0, s, v, g, (const float*)inv_norm, (float*)wf, (float*)wt, dg, k);
+    return a8_check_launch("a8_weightnorm_pack");
+}
+
+extern "C" int a8_weightnorm_bwd(const float* dwg, const float* v, const float* g, const float* inv_norm, float* dv, float* dgain,
+                                 float* scratch, int d, int groups, int k, void* stream) {
+    A8_REQUIRE(groups >= 1 && d % groups == 0, "a8_weightnorm_bwd: d=%d not divisible by groups=%d", d, groups);
+    const int dg = d / groups;
+    A8_REQUIRE(k >= 1 && k <= WN_MAXK && 1024 % k == 0 && dg <= WN_MAXDG, "a8_weightnorm_bwd: k=%d must divide 1024 (<= %d), d/groups=%d <= %d",
+               k, WN_MAXK, dg, WN_MAXDG);
+    hipStream_t s = (hipStream_t)stream;
+    float* dot = scratch + (size_t)d * k;
+    hipLaunchKernelGGL(wn_partial_kernel, dim3(d), dim3(256), 0, s, v, dwg, scratch, dg, k);
+    hipLaunchKernelGGL(wn_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)scratch, inv_norm, dot, dgain, d, k);
+    hipLaunchKernelGGL(wn_bwd_kernel, dim3(d), dim3(256), 0, s, dwg, v, g, inv_norm, (const float*)dot, dv, dg, k);
+    return a8_check_launch("a8_weightnorm_bwd");
 }

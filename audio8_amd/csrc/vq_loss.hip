@@ -292,6 +292,21 @@ __global__ void contrastive_combine_kernel(const T* __restrict__ lat, const floa
     dlat[i] += it * G[gi] - to_f(lat[i]) * it * it * U[j];
 }
 
+// loss = w_xe * (xe_sum / rows) + w_div * (n_vars - ppl) / n_vars, in the reference's operation order
+// (audio8/wav2vec2.py:390-392); backward hands each branch its scalar cotangent.  One lane: these are scalars.
+__global__ void loss_combine_kernel(const float* __restrict__ xe_sum, const float* __restrict__ ppl, float rows, float n_vars,
+                                    float w_xe, float w_div, float* __restrict__ loss) {
+    const float xe = xe_sum[0] / rows;
+    const float diversity = w_div * (n_vars - ppl[0]) / n_vars;
+    loss[0] = w_xe * xe + diversity;
+}
+__global__ void loss_combine_bwd_kernel(const float* __restrict__ dloss, float rows, float n_vars, float w_xe, float w_div,
+                                        float* __restrict__ dxe_sum, float* __restrict__ dppl) {
+    const float g = dloss[0];
+    dxe_sum[0] = g * w_xe / rows;
+    dppl[0] = -(g * w_div) / n_vars;
+}
+
 int gridw(int rows) { int b = (rows + 3) / 4; return b < 1 ? 1 : (b > 2048 ? 2048 : b); }
 
 }  // namespace
@@ -423,4 +438,16 @@ extern "C" int a8_contrastive_bwd(int dtype, const void* ctx, const void* lat, c
     if (dtype == A8_BF16) hipLaunchKernelGGL(contrastive_combine_kernel<bf16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16*)lat, il, G, U, dlat, n, rpg, rpg4);
     else hipLaunchKernelGGL(contrastive_combine_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)lat, il, G, U, dlat, n, rpg, rpg4);
     return a8_check_launch("a8_contrastive_bwd");
+}
+
+extern "C" int a8_loss_combine(const float* xe_sum, const float* ppl, int rows, float n_vars, float w_xe, float w_div, float* loss, void* stream) {
+    A8_REQUIRE(rows > 0 && n_vars > 0.f, "a8_loss_combine: rows=%d and n_vars must be positive", rows);
+    hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, xe_sum, ppl, (float)rows, n_vars, w_xe, w_div, loss);
+    return a8_check_launch("a8_loss_combine");
+}
+
+extern "C" int a8_loss_combine_bwd(const float* dloss, int rows, float n_vars, float w_xe, float w_div, float* dxe_sum, float* dppl, void* stream) {
+    A8_REQUIRE(rows > 0 && n_vars > 0.f, "a8_loss_combine_bwd: rows=%d and n_vars must be positive", rows);
+    hipLaunchKernelGGL(loss_combine_bwd_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, dloss, (float)rows, n_vars, w_xe, w_div, dxe_sum, dppl);
+    return a8_check_launch("a8_loss_combine_bwd");
 }

@@ -242,6 +242,27 @@ def posconv_wgrad(x, dz, dw_g, groups, k, pad_left):
     L.check(L.lib().a8_posconv_wgrad(L.dt(x), L.ptr(_c(x)), L.ptr(_c(dz)), L.ptr(dw_g), B, T, d, groups, k, pad_left, L.stream()), "a8_posconv_wgrad")
 
 
+def weightnorm_pack(v, g, groups, dtype):
+    """v f32 [d, d/groups, k], g f32 [..k] -> (wf [G][co][kk][ci], wt [G][ci][kk'][co]) in `dtype`, inv_norm f32 [k]."""
+    L.require_cuda(v, g)
+    d, dg, k = v.shape
+    wf = torch.empty((groups, dg, k, dg), device=v.device, dtype=dtype)
+    wt = torch.empty((groups, dg, k, dg), device=v.device, dtype=dtype)
+    inv_norm = torch.empty((k,), device=v.device, dtype=torch.float32)
+    scratch = torch.empty((d * k,), device=v.device, dtype=torch.float32)
+    L.check(L.lib().a8_weightnorm_pack(L.dt(wf), L.ptr(_c(v)), L.ptr(_c(g)), L.ptr(wf), L.ptr(wt), L.ptr(inv_norm), L.ptr(scratch), d, groups, k,
+                                       L.stream()), "a8_weightnorm_pack")
+    return wf, wt, inv_norm
+
+
+def weightnorm_bwd_(dwg, v, g, inv_norm, dv, dgain, groups):
+    """dv f32 [d, d/groups, k] and dgain f32 [k] += the weight-norm gradients of dwg f32 [G][co][kk][ci]."""
+    d, dg, k = v.shape
+    scratch = torch.empty((d * k + k,), device=v.device, dtype=torch.float32)
+    L.check(L.lib().a8_weightnorm_bwd(L.ptr(_c(dwg)), L.ptr(_c(v)), L.ptr(_c(g)), L.ptr(inv_norm), L.ptr(dv), L.ptr(dgain), L.ptr(scratch), d, groups, k,
+                                      L.stream()), "a8_weightnorm_bwd")
+
+
 # ----------------------------------------------------------------------------- attention
 def attn_fwd(q, k, v, B, T, H, ld_qkv, scale, keymask=None, p=0.0, seed=0):
     """q,k,v: [B*T, ld_qkv] views (head h at columns h*64..); returns (o [B*T, H*64], lse f32 [B,H,T])."""
@@ -317,6 +338,21 @@ def contrastive_bwd(ctx, lat, neg_idx, logits, gscale, rows_per_group=0):
     L.check(L.lib().a8_contrastive_bwd(L.dt(ctx), L.ptr(_c(ctx)), L.ptr(_c(lat)), L.ptr(_c(neg_idx)), L.ptr(logits), L.ptr(gscale),
                                        L.ptr(dctx), L.ptr(dlat), L.ptr(scratch), rows, N, Cn, int(rows_per_group), L.stream()), "a8_contrastive_bwd")
     return dctx, dlat
+
+
+def loss_combine(xe_sum, ppl, rows, n_vars, w_xe, w_div):
+    L.require_cuda(xe_sum, ppl)
+    if xe_sum.dtype != torch.float32 or ppl.dtype != torch.float32 or xe_sum.numel() != 1 or ppl.numel() != 1:
+        raise RuntimeError("a8hip loss_combine: xe_sum and ppl must be one-element f32 tensors")
+    loss = torch.empty((1,), device=xe_sum.device, dtype=torch.float32)
+    L.check(L.lib().a8_loss_combine(L.ptr(_c(xe_sum)), L.ptr(_c(ppl)), rows, n_vars, w_xe, w_div, L.ptr(loss), L.stream()), "a8_loss_combine")
+    return loss
+
+
+def loss_combine_bwd(dloss, rows, n_vars, w_xe, w_div):
+    out = torch.empty((2,), device=dloss.device, dtype=torch.float32)
+    L.check(L.lib().a8_loss_combine_bwd(L.ptr(dloss), rows, n_vars, w_xe, w_div, L.ptr(out), L.ptr(out[1:]), L.stream()), "a8_loss_combine_bwd")
+    return out[:1], out[1:]
 
 
 # ----------------------------------------------------------------------------- CTC + log-softmax

@@ -115,7 +115,7 @@ class Conv1DSame(nn.Module):
         m = self.conv[1]
         if not isinstance(m, _WeightNormConvParams):
             raise RuntimeError("Conv1DSame: call weight_norm_() first (the audio path always does)")
-        return ops.PosConvFn.apply(x, m.effective_weight(), m.bias, m.groups, self.pad[0])
+        return ops.PosConvFn.apply(x, m.weight_v, m.weight_g, m.bias, m.groups, self.pad[0])
 
 
 class MultiHeadedAttention(nn.Module):

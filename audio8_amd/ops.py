@@ -1,9 +1,8 @@
 """Autograd surface of the hot path: coarse torch.autograd.Functions whose forward/backward are
 fixed sequences of liba8hip kernel launches (audio8_amd/kernels.py).  PyTorch supplies device
 memory, the stream and the autograd tape; no arithmetic of the path runs in ATen, except
-O(#params)-sized weight preparation (weight-norm of the pos-conv, conv-weight re-layout, bias
-concatenation) which is left to torch ops on purpose: it is plumbing, differentiable by the
-tape, and three orders of magnitude below the activations in bytes.
+O(#params)-sized weight plumbing (conv-weight re-layout views, bias concatenation outside the
+flat-state layout) and the scalar composition of the loss.
 """
 import math
 
@@ -482,8 +481,13 @@ class ConvStackFn(torch.autograd.Function):
             # fused data gradient: write dx[b, p, :] (* gelu'(z)) straight from the GEMM epilogues
             npad = 1 if (i - 1 >= 1 and feats[i - 1][1] == 3) else 0          # the layer below reads dz[t-1], dz[t]
             prow = Lin + 2 * npad
-            dx = torch.zeros((B * prow, cin), device=dz.device, dtype=dtype) if (npad or Lin > 2 * (Lout - 1) + k) else \
-                torch.empty((B * prow, cin), device=dz.device, dtype=dtype)
+            dx = torch.empty((B * prow, cin), device=dz.device, dtype=dtype)
+            written = 2 * Lout + (1 if k == 3 else 0)          # the GEMMs below write positions 0 .. written-1 of every utterance
+            dxv = dx.view(B, prow, cin)
+            if npad:
+                dxv[:, :npad].zero_()                          # only the pad rows and the uncovered tail need clearing
+            if npad + written < prow:
+                dxv[:, npad + written:].zero_()
             act = L.ACT_MUL_GELU_GRAD if zprev is not None else L.ACT_NONE
             zk = dict(zin=zprev, ldz=2 * cin, z_bs=Lin * cin) if zprev is not None else {}
             if k == 2:
@@ -518,31 +522,29 @@ class ConvStackFn(torch.autograd.Function):
 
 # ------------------------------------------------------------------ positional conv
 class PosConvFn(torch.autograd.Function):
-    """y = x + gelu(conv1d_same(x; w) + bias), grouped, k = 128  (audio8/wav2vec2.py:634-638).
-    w is the effective (weight-normed) kernel [d, d/G, k] in f32; the tape differentiates the weight-norm."""
+    """y = x + gelu(conv1d_same(x; w) + bias), grouped, k = 128, with w = weight_norm(v, g; dim=2)
+    (audio8/wav2vec2.py:609, 634-638).  v f32 [d, d/G, k], g f32 [1, 1, k]: the weight norm and its gradient are
+    part of this node (a8_weightnorm_pack / a8_weightnorm_bwd), not of the tape."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, groups, pad_left):
+    def forward(ctx, x, v, g, bias, groups, pad_left):
         B, T, d = x.shape
-        dg, k = w.shape[1], w.shape[2]
-        wg = w.detach().view(groups, dg, dg, k)
-        wf = wg.permute(0, 1, 3, 2).contiguous()                       # [G][co][kk][ci]
-        wt = wg.flip(3).permute(0, 2, 3, 1).contiguous()               # [G][ci][kk'][co]  (data-gradient kernel)
-        if x.dtype != torch.float32:
-            wf, wt = K.cast(wf, x.dtype), K.cast(wt, x.dtype)
+        k = v.shape[2]
+        wf, wt, inv_norm = K.weightnorm_pack(v.detach(), g.detach(), groups, x.dtype)
         y, z = K.posconv_fwd(x.contiguous(), wf, bias.detach(), groups, k, pad_left, 1, want_z=True)
-        ctx.save_for_backward(x, z, wt)
-        ctx.groups, ctx.pad_left, ctx.k, ctx.dg = groups, pad_left, k, dg
-        ctx.params = (bias,)
+        ctx.save_for_backward(x, z, wt, inv_norm)
+        ctx.groups, ctx.pad_left, ctx.k = groups, pad_left, k
+        ctx.params = (v, g, bias)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, z, wt = ctx.saved_tensors
+        x, z, wt, inv_norm = ctx.saved_tensors
         B, T, d = x.shape
-        G, k, dg = ctx.groups, ctx.k, ctx.dg
+        G, k = ctx.groups, ctx.k
+        dg = d // G
         dy = dy.contiguous()
-        (pbias,) = ctx.params
+        pv, pg, pbias = ctx.params
         tb = _target(pbias)
         dbias = tb if tb is not None else torch.zeros((d,), device=x.device, dtype=torch.float32)
         dz = K.gelu_bwd_bias(dy, z, dbias)
@@ -553,8 +555,15 @@ class PosConvFn(torch.autograd.Function):
         dx = K.add(dy, dxc)
         dwg = torch.zeros((G, dg, k, dg), device=x.device, dtype=torch.float32)
         K.posconv_wgrad(x, dz, dwg, G, k, ctx.pad_left)
-        dw = dwg.permute(0, 1, 3, 2).reshape(d, dg, k)
-        return dx, dw, dbias, None, None
+        tv, tg = _target(pv), _target(pg)
+        direct = tv is not None and tg is not None
+        dv = tv if direct else torch.zeros(pv.shape, device=x.device, dtype=torch.float32)
+        dgain = tg if direct else torch.zeros(pg.shape, device=x.device, dtype=torch.float32)
+        K.weightnorm_bwd_(dwg, pv.detach(), pg.detach(), inv_norm, dv, dgain, G)
+        if direct:
+            _ready(pv, pg)
+            dv = dgain = None
+        return dx, dv, dgain, dbias, None, None
 
 
 # ------------------------------------------------------------------ transformer encoder layer (post-LN)
@@ -741,26 +750,42 @@ class VQFn(torch.autograd.Function):
 
 # ------------------------------------------------------------------ contrastive loss
 class ContrastiveXEFn(torch.autograd.Function):
-    """mean over masked frames of CE([cos(c, q+), cos(c, q-_1..N)], 0)  (audio8/wav2vec2.py:384-390)."""
+    """CE([cos(c, q+), cos(c, q-_1..N)], 0) over the masked frames (audio8/wav2vec2.py:384-390): the mean (default) or,
+    with mean=False, the f32 [1] sum that PretrainLossFn divides itself."""
 
     @staticmethod
-    def forward(ctx, ctx_rows, lat_rows, neg_idx, rows_per_group=0):
+    def forward(ctx, ctx_rows, lat_rows, neg_idx, rows_per_group=0, mean=True):
         logits, loss_sum = K.contrastive_fwd(ctx_rows.contiguous(), lat_rows.contiguous(), neg_idx)
         ctx.save_for_backward(ctx_rows, lat_rows, neg_idx, logits)
-        ctx.rows_per_group = rows_per_group
+        ctx.rows_per_group, ctx.mean = rows_per_group, mean
         rows = ctx_rows.shape[0]
         ctx.mark_non_differentiable(logits)
-        return loss_sum[0] / rows, logits
+        return (loss_sum[0] / rows if mean else loss_sum), logits
 
     @staticmethod
     def backward(ctx, dloss, _dlogits):
         c, q, neg_idx, logits = ctx.saved_tensors
         rows = c.shape[0]
-        gscale = (dloss.float() / rows).reshape(1).contiguous()
+        gscale = (dloss.float() / rows).reshape(1).contiguous() if ctx.mean else dloss.reshape(1)
         dctx, dlat = K.contrastive_bwd(c.contiguous(), q.contiguous(), neg_idx, logits, gscale, ctx.rows_per_group)
         if c.dtype != torch.float32:
             dctx, dlat = K.cast(dctx, c.dtype), K.cast(dlat, q.dtype)
-        return dctx, dlat, None, None
+        return dctx, dlat, None, None, None
+
+
+class PretrainLossFn(torch.autograd.Function):
+    """w_xe * (xe_sum / rows) + w_div * (n_vars - prob_ppl) / n_vars as ONE launch each way (audio8/wav2vec2.py:390-392);
+    xe_sum, prob_ppl: f32 one-element device tensors."""
+
+    @staticmethod
+    def forward(ctx, xe_sum, ppl, rows, n_vars, w_xe, w_div):
+        ctx.cfg = (int(rows), float(n_vars), float(w_xe), float(w_div))
+        return K.loss_combine(xe_sum, ppl, *ctx.cfg)
+
+    @staticmethod
+    def backward(ctx, dloss):
+        dxe, dppl = K.loss_combine_bwd(dloss.contiguous().float(), *ctx.cfg)
+        return dxe, dppl, None, None, None, None
 
 
 # ------------------------------------------------------------------ log-softmax head + CTC

@@ -199,10 +199,9 @@ class Wav2Vec2Loss(nn.Module):
                 raise RuntimeError("a8hip: prefetched negatives do not match this loss (shape %s vs %s)"
                                    % (plan.neg_shape, (B * Tm, self.sample.n_negatives)))
             neg_idx = ops.host_i32(self.sample.indices(B, Tm).reshape(B * Tm, self.sample.n_negatives), outputs.device)
-        xe_loss, logits = ops.ContrastiveXEFn.apply(ctx, latents.reshape(B * Tm, C), neg_idx, Tm)   # negatives stay inside the utterance
+        xe_sum, logits = ops.ContrastiveXEFn.apply(ctx, latents.reshape(B * Tm, C), neg_idx, Tm, False)   # negatives stay inside the utterance
         self.last_logits = logits
-        diversity = DIVERSITY_WGT * (self.n_vars - gs_probs) / self.n_vars
-        return (XE_WGT * xe_loss + diversity).reshape(())
+        return ops.PretrainLossFn.apply(xe_sum, gs_probs.reshape(1), B * Tm, self.n_vars, XE_WGT, DIVERSITY_WGT).reshape(())
 
 
 def create_loss(n_vars, n_negatives):

@@ -133,6 +133,17 @@ int a8_posconv_fwd(int dtype, const void* x, const void* w, const float* bias, v
 /* dw f32 [G][dg_out][k][dg_in] += sum_{b,t} dz[b,t,co] x[b,t+kk-pad_left,ci] */
 int a8_posconv_wgrad(int dtype, const void* x, const void* dz, float* dw, int B, int T, int d, int groups, int k,
                      int pad_left, void* stream);
+/* Weight norm of the positional conv kernel (nn.utils.weight_norm(name="weight", dim=2), audio8/wav2vec2.py:609):
+ * v f32 [d][d/groups][k], g f32 [k]:  w[o][ci][kk] = g[kk] * v[o][ci][kk] / ||v[:, :, kk]||.
+ * a8_weightnorm_pack writes the two operand images a8_posconv_fwd takes, in `dtype`:
+ *   wf [G][co][kk][ci] = w[g*dg+co][ci][kk] (forward),  wt [G][ci][kk'][co] = w[g*dg+co][ci][k-1-kk'] (data gradient),
+ * and inv_norm f32 [k] = 1 / ||v[:, :, kk]|| for the backward pass.  scratch: f32 [d*k].  k must divide 1024 (<= 128).
+ * a8_weightnorm_bwd takes dwg f32 [G][co][kk][ci] (what a8_posconv_wgrad produces) through the weight norm:
+ *   dgain[kk] += <dw, v>_kk * inv_norm[kk];   dv += g * inv_norm * (dw - v * <dw, v>_kk * inv_norm^2).   scratch: f32 [d*k + k]. */
+int a8_weightnorm_pack(int dtype, const float* v, const float* g, void* wf, void* wt, float* inv_norm, float* scratch,
+                       int d, int groups, int k, void* stream);
+int a8_weightnorm_bwd(const float* dwg, const float* v, const float* g, const float* inv_norm, float* dv, float* dgain,
+                      float* scratch, int d, int groups, int k, void* stream);
 /* dz = dy * gelu'(z) (z NULL: dz = dy); dbias[cols] += column sums of dz.  dz and dbias may each be NULL. */
 int a8_gelu_bwd_bias(int dtype, const void* dy, const void* z, void* dz, float* dbias, int rows, int cols, void* stream);
 
@@ -155,6 +166,12 @@ int a8_vq_select(const float* logits, const float* gumbel, float tau, int32_t* c
 int a8_vq_gather(int dtype, const float* vars, const int32_t* codes, void* q, int N, int G, int V, int D, void* stream);
 /* prob_ppl = sum exp(-sum p log(p + 1e-7)) over avg_probs[V] -> ppl[0]; dppl_davg[V] */
 int a8_vq_ppl(const float* avg_probs, float* ppl, float* dppl_davg, int V, void* stream);
+/* Scalar composition of the pretraining loss (Wav2Vec2Loss.__call__, audio8/wav2vec2.py:390-392), on device so that the
+ * step has no host read-back and no chain of one-element kernels:
+ *   loss[0] = w_xe * (xe_sum[0] / rows) + w_div * (n_vars - ppl[0]) / n_vars
+ * a8_loss_combine_bwd: dxe_sum[0] = dloss[0] * w_xe / rows;  dppl[0] = -dloss[0] * w_div / n_vars. */
+int a8_loss_combine(const float* xe_sum, const float* ppl, int rows, float n_vars, float w_xe, float w_div, float* loss, void* stream);
+int a8_loss_combine_bwd(const float* dloss, int rows, float n_vars, float w_xe, float w_div, float* dxe_sum, float* dppl, void* stream);
 /* backward: dq dtype [N, G*D]; dvars f32 [G*V, D] += ; dlogits f32 [R,V] =
  *   straight-through soft path: d/dlogits of sum_v ysoft_v * <dq_g, vars_v>  (ysoft = softmax((logits+gumbel)/tau))
  * + diversity path: gppl * dppl/dlogits through avg_probs = mean softmax(logits). */

@@ -215,6 +215,36 @@ def test_posconv(dtype, dm, T):
     close(dw, dw_ref, 2e-4 if dtype == torch.float32 else 3e-2, "posconv wgrad")
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("dm,k", [(768, 128), (1024, 128), (96, 32)])
+def test_weightnorm_pack_and_bwd(dtype, dm, k):
+    """a8_weightnorm_pack / a8_weightnorm_bwd against torch's tape through nn.utils.weight_norm(dim=2)'s formula
+    (audio8/wav2vec2.py:609): operand images in both layouts, inverse norms, dv and dg (accumulating)."""
+    from audio8_amd import kernels as K
+    from oracle import ref_cpu as R
+    G = 16 if dm >= 768 else 2
+    dg = dm // G
+    v = rnd((dm, dg, k), 2, 0.02).requires_grad_(True)
+    g = (v.detach().norm(2, dim=(0, 1), keepdim=True) * (1 + 0.1 * rnd((1, 1, k), 3))).requires_grad_(True)
+    w = R.weight_norm_dim2(g, v)                                                  # [dm, dg, k]
+    d = "cuda"
+    wf, wt, inv_norm = K.weightnorm_pack(v.detach().to(d), g.detach().to(d), G, dtype)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    close(wf, w.detach().view(G, dg, dg, k).permute(0, 1, 3, 2), tol, "wf")
+    close(wt, w.detach().view(G, dg, dg, k).flip(3).permute(0, 2, 3, 1), tol, "wt")
+    close(inv_norm, 1.0 / v.detach().norm(2, dim=(0, 1)), 1e-5, "inv_norm")
+    if dtype != torch.float32:
+        return
+    dw = rnd((dm, dg, k), 7)
+    w.backward(dw)
+    dwg = dw.view(G, dg, dg, k).permute(0, 1, 3, 2).contiguous().to(d)            # [G][co][kk][ci]
+    dv0, dg0 = rnd((dm, dg, k), 8), rnd((1, 1, k), 9)
+    dv, dgain = dv0.clone().to(d), dg0.clone().to(d)
+    K.weightnorm_bwd_(dwg, v.detach().to(d), g.detach().to(d), inv_norm, dv, dgain, G)
+    close(dv, dv0 + v.grad, 2e-5, "dv")
+    close(dgain, dg0 + g.grad, 2e-5, "dg")
+
+
 # ------------------------------------------------------------------ attention
 def _attn_ref(q, k, v, keymask, scale, drop_keep=None, p=0.0):
     s = torch.matmul(q, k.transpose(-2, -1)) * scale

@@ -45,6 +45,13 @@ def main():
             ce = max(ce, e)
     u += ce - cs
     print(f"  GPU busy (union of all queues): {u / 1e6:.3f} ms of {(t1 - t0) / 1e6:.3f} ms")
+    if len(sys.argv) > 3:      # every dispatch of one kernel in the last step: duration, grid, what ran before it
+        key = sys.argv[3]
+        for i, r in enumerate(step):
+            if key in r["Kernel_Name"]:
+                dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+                prev = step[i - 1]["Kernel_Name"][:50] if i else "-"
+                print(f"    t={(int(r['Start_Timestamp']) - t0) / 1e6:7.3f} ms  {dur:7.1f} us  grid {r.get('Grid_Size_X', '?'):>9}  {r['Kernel_Name'][:110]}  <- {prev}")
 
 
 if __name__ == "__main__":
