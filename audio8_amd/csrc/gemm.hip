@@ -227,11 +227,19 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
     typedef StageTile<T, KB> ST;
     typedef KcGeom<KB> G;
     typedef Mma<T> MM;
-    constexpr int BK = ST::BK, TILE = G::OPBYTES, EPC = 16 / (int)sizeof(T), SZ = (int)sizeof(T);
-    constexpr int NW = 2 * NWM;                   // waves per block: NWM along M x 2 along N; a wave owns (64 * 2 / NWM) x 64 of the tile
-    constexpr int MI = 8 / NWM;                   // 16-row fragments per wave along M (4 or 2)
-    constexpr int PPW = G::NPIECE / NW;           // LDS-DMA pieces per wave per operand per stage
-    __shared__ __attribute__((aligned(1024))) char lds[NST * 2 * TILE];
+    constexpr int BK = ST::BK, EPC = 16 / (int)sizeof(T), SZ = (int)sizeof(T);
+    constexpr int NW = 2 * NWM;                   // waves per block: NWM along M x 2 along N
+    constexpr int MI = NWM == 2 ? 4 : 2;          // 16-row fragments per wave along M: a wave owns (16 MI) x 64 of the tile
+    constexpr int BM = 16 * MI * NWM;             // tile rows: 128, or 160 with 10 waves (NWM = 5, both operands K-contiguous only)
+    static_assert(BM == 128 || !(AKS || BKS), "the 160-row tile is built for K-contiguous operands");
+    constexpr int TA = BM * G::KROW, TB = G::OPBYTES, STAGE = TA + TB;
+    constexpr int NPA = TA / 1024, NPB = TB / 1024;                        // 1 KB LDS-DMA pieces per operand per stage
+    constexpr int PPA = (NPA + NW - 1) / NW, PPB = (NPB + NW - 1) / NW;    // ... per wave (the last may be missing when NW does not divide)
+    constexpr int PPW = PPA > PPB ? PPA : PPB;
+    constexpr bool UNEVEN = NPA % NW != 0 || NPB % NW != 0;                // then a wave without a last piece DMAs 16 zero bytes per lane
+    constexpr int RING = NST * STAGE + (UNEVEN ? 1024 : 0);                // into a spare KB, so that vmcnt counts stay uniform
+    constexpr int EPI = NW * 16 * MI * 64 * 4;                             // epilogue staging: a 64-column f32 slab per wave
+    __shared__ __attribute__((aligned(1024))) char lds[RING > EPI ? RING : EPI];
 
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -246,7 +254,7 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
     const int grp = tile / tpg, first_m = grp * GROUP_M;
     const int gsz = min(GROUP_M, g.tiles_m - first_m);
     const int tin = tile - grp * tpg;
-    const int m0 = (first_m + tin % gsz) * 128, n0 = (tin / gsz) * 128;
+    const int m0 = (first_m + tin % gsz) * BM, n0 = (tin / gsz) * 128;
     const int kbeg = split * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
     const int nkb = (kend - kbeg + BK - 1) / BK;
@@ -307,12 +315,13 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
         }
     }
     auto issue = [&](int kb) {
-        char* ta = lds + (kb % NST) * 2 * TILE;
-        char* tb = ta + TILE;
+        char* ta = lds + (kb % NST) * STAGE;
+        char* tb = ta + TA;
         const int k0 = kbeg + kb * BK;
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
-            const int p = w + NW * j;
+            const int p = w + NW * j;                 // wave-uniform: a missing last piece is a scalar branch
+            const bool has_a = j < PPA && (NPA % NW == 0 || p < NPA), has_b = j < PPB && (NPB % NW == 0 || p < NPB);
             const char* sa;
             if constexpr (!AKS) {
                 const int k = k0 + a_k[j];
@@ -323,7 +332,8 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
                 a_cur[j] += a_step;
                 if (g.A.rpb) { a_r[j] += BK; while (a_r[j] >= (int)g.A.rpb) { a_r[j] -= (int)g.A.rpb; a_cur[j] += a_wrap; } }
             }
-            glds16(sa, ta + p * 1024);
+            if (has_a) glds16(sa, ta + p * 1024);
+            else if (UNEVEN && j < PPA) glds16(zero, lds + NST * STAGE);
             const char* sb;
             if constexpr (!BKS) {
                 const int k = k0 + b_k[j];
@@ -334,7 +344,8 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
                 b_cur[j] += b_step;
                 if (g.B.rpb) { b_r[j] += BK; while (b_r[j] >= (int)g.B.rpb) { b_r[j] -= (int)g.B.rpb; b_cur[j] += b_wrap; } }
             }
-            glds16(sb, tb + p * 1024);
+            if (has_b) glds16(sb, tb + p * 1024);
+            else if (UNEVEN && j < PPB) glds16(zero, lds + NST * STAGE);
         }
     };
 
@@ -348,13 +359,13 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
     for (int s = 0; s < NST - 1; ++s) issue(s);
     for (int kb = 0; kb < nkb; ++kb) {
         // stage kb has landed once all but the (NST-2) youngest stages' DMAs of this wave are done (2*PPW per stage per lane)
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NST - 2) * 2 * PPW) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NST - 2) * (PPA + PPB)) : "memory");
         __builtin_amdgcn_s_barrier();
         // DMA issue order, measured: with plain b128 fragment reads (NT) issuing the refill first is best; with
         // transposed reads (twice the LDS instructions) issuing it after the reads hides its issue slots in their latency
         if constexpr (!(AKS || BKS)) issue(kb + NST - 1);
-        const char* ta = lds + (kb % NST) * 2 * TILE;
-        const char* tb = ta + TILE;
+        const char* ta = lds + (kb % NST) * STAGE;
+        const char* tb = ta + TA;
         // all fragment reads of the k-tile are issued up front (one exposed LDS latency per tile, counted lgkmcnt waits
         // after that), pinned ahead of the MFMA block
         typename MM::Frag fa[ST::KSTEPS][MI], fb[ST::KSTEPS][4];
@@ -384,7 +395,6 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    static_assert(NST * 2 * TILE >= NW * 16 * MI * 64 * 4, "epilogue staging needs a 64-column f32 slab per wave");
     gemm_epilogue<T, MI, NWM>(g, acc, lds, w, m0, n0, lane);
 }
 
@@ -512,7 +522,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pf_kernel(const GemmArgs g) {
 }
 
 template <typename T, bool AKS, bool BKS, int KB, int NST, int NWM>
-__global__ __launch_bounds__(128 * NWM, (NST * 2 * 8192 * KB <= 65536) ? NWM : NWM / 2) void gemm_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(128 * NWM, NWM == 5 ? 3 : (NST * 2 * 8192 * KB <= 65536) ? NWM : NWM / 2) void gemm_kernel(const GemmArgs g) {
     gemm_body<T, AKS, BKS, KB, NST, NWM>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n * g.nsplit));
 }
 
@@ -617,6 +627,19 @@ extern "C" int a8_gemm(const a8_gemm_desc* d, void* stream) {
         if ((long long)tm * g.tiles_n >= g_a8_tuning[5]) {
             g.tiles_m = tm;
             hipLaunchKernelGGL(gemm_pf_kernel<bf16>, dim3(tm * g.tiles_n * g.nsplit), dim3(512), 0, s, g);
+            return a8_check_launch("a8_gemm");
+        }
+    }
+    // Between one and two 128-row tiles per CU (e.g. M = 6248, N = 768: 294 tiles on 256 CUs) the launch lasts as long as the
+    // CUs that got two.  160-row tiles (10 waves) cut such a grid to at most one block per CU: 240 blocks of 1.25 units
+    // instead of 38 CUs with 2.  a8_set_tuning key 7: 1 = on (default), 0 = off.
+    if (d->dtype == A8_BF16 && d->layout == A8_GEMM_NT && g_variant == 5 && g_a8_tuning[7] > 0 && grid > 256 && grid <= 512) {
+        const long long g160 = (long long)cdiv(d->M, 160) * g.tiles_n * g.nsplit;
+        if (g160 <= 256) {
+            g.tiles_m = cdiv(d->M, 160);
+            if (g_a8_tuning[7] == 2) hipLaunchKernelGGL((gemm_kernel<bf16, false, false, 2, 2, 5>), dim3((int)g160), dim3(640), 0, s, g);
+            else if (g_a8_tuning[7] == 3) hipLaunchKernelGGL((gemm_kernel<bf16, false, false, 2, 3, 5>), dim3((int)g160), dim3(640), 0, s, g);
+            else hipLaunchKernelGGL((gemm_kernel<bf16, false, false, 2, 4, 5>), dim3((int)g160), dim3(640), 0, s, g);
             return a8_check_launch("a8_gemm");
         }
     }
