@@ -630,9 +630,10 @@ extern "C" int a8_gemm(const a8_gemm_desc* d, void* stream) {
             return a8_check_launch("a8_gemm");
         }
     }
-    // Between one and two 128-row tiles per CU (e.g. M = 6248, N = 768: 294 tiles on 256 CUs) the launch lasts as long as the
-    // CUs that got two.  160-row tiles (10 waves) cut such a grid to at most one block per CU: 240 blocks of 1.25 units
-    // instead of 38 CUs with 2.  a8_set_tuning key 7: 1 = on (default), 0 = off.
+    // Experiment, off by default (a8_set_tuning key 7: 0 = off; 2 / 3 / 4 = ring depth): between one and two 128-row tiles
+    // per CU (M = 6248, N = 768: 294 tiles on 256 CUs) the launch lasts as long as the 38 CUs that got two.  160-row tiles
+    // (10 waves) give 240 blocks, at most one per CU -- and the same time at any ring depth: a lone block's k-tile costs its
+    // LDS-read phase plus its MFMA phase in series (~0.8 us), which two co-resident blocks overlap (tools/tile160.py).
     if (d->dtype == A8_BF16 && d->layout == A8_GEMM_NT && g_variant == 5 && g_a8_tuning[7] > 0 && grid > 256 && grid <= 512) {
         const long long g160 = (long long)cdiv(d->M, 160) * g.tiles_n * g.nsplit;
         if (g160 <= 256) {

@@ -248,45 +248,67 @@ __global__ __launch_bounds__(256) void posconv_wgrad_kernel(const char* __restri
 // ------------------------------------------------------------------ weight norm (nn.utils.weight_norm(dim=2))
 // v f32 [d][dg][k]; w[o][ci][kk] = g[kk] * v[o][ci][kk] / ||v[:, :, kk]||  (audio8/wav2vec2.py:609).
 // Three small launches each way instead of the tape's dozen element-wise passes over the 4.7 M-element kernel:
-// per-output-channel partial sums -> one reducing block -> a transposing pass that writes the operand images of
+// per-output-channel partial sums -> a few reducing blocks -> a transposing pass that writes the operand images of
 // posconv_fwd_kernel (forward) or accumulates dv (backward).  Slabs go through a padded LDS tile so that both the
-// global read and the global write are contiguous.
+// global read and the global write are contiguous.  DG / KK = 0: run-time sizes (any k that is a power of two in 16..128).
 constexpr int WN_MAXK = 128, WN_MAXDG = 64;
+template <int DG, int KK> struct WnDims {
+    int dg_, k_;
+    A8_DEV WnDims(int dg, int k) : dg_(dg), k_(k) {}
+    A8_DEV int dg() const { return DG ? DG : dg_; }
+    A8_DEV int k() const { return KK ? KK : k_; }
+};
 
 // part[o][kk] = sum_ci v[o][ci][kk]^2                              (dwg == nullptr)
 //             = sum_ci dwg[o][kk][ci] * v[o][ci][kk]               (backward: dwg is [d][k][dg])
+template <int DG, int KK>
 __global__ __launch_bounds__(256) void wn_partial_kernel(const float* __restrict__ v, const float* __restrict__ dwg,
-                                                         float* __restrict__ part, int dg, int k) {
+                                                         float* __restrict__ part, int dg_rt, int k_rt) {
     __shared__ float tile[WN_MAXK * (WN_MAXDG + 1)];
+    __shared__ float red[256];
+    const WnDims<DG, KK> D(dg_rt, k_rt);
+    const int dg = D.dg(), k = D.k();
     const int o = blockIdx.x, n = dg * k;
     const float* vo = v + (size_t)o * n;
     if (dwg) {
         const float* dwo = dwg + (size_t)o * n;
+#pragma unroll 4
         for (int e = threadIdx.x; e < n; e += 256) tile[(e / dg) * (dg + 1) + e % dg] = dwo[e];
         __syncthreads();
     }
-    for (int kk = threadIdx.x; kk < k; kk += 256) {
-        float acc = 0.f;
-        for (int ci = 0; ci < dg; ++ci) {
-            const float x = vo[ci * k + kk];
-            acc += dwg ? tile[kk * (dg + 1) + ci] * x : x * x;
-        }
+    const int rows = 256 / k, r = threadIdx.x / k, kk = threadIdx.x % k;         // k divides 256
+    float acc = 0.f;
+#pragma unroll 8
+    for (int ci = r; ci < dg; ci += rows) {
+        const float x = vo[ci * k + kk];
+        acc += dwg ? tile[kk * (dg + 1) + ci] * x : x * x;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (r == 0) {
+        for (int j = 1; j < rows; ++j) acc += red[j * k + kk];
         part[(size_t)o * k + kk] = acc;
     }
 }
 
+// Block b owns columns [16 b, 16 b + 16): 64 row groups x 16 columns.
 // fwd (dg_out == nullptr): stat[kk] = 1 / sqrt(sum_o part[o][kk])            (inverse norm)
 // bwd: stat[kk] = dot[kk] = sum_o part[o][kk];  dg_out[kk] += dot[kk] * inv_norm[kk]
 __global__ __launch_bounds__(1024) void wn_reduce_kernel(const float* __restrict__ part, const float* __restrict__ inv_norm,
                                                          float* __restrict__ stat, float* __restrict__ dg_out, int d, int k) {
     __shared__ float red[1024];
-    const int rows = 1024 / k, r = threadIdx.x / k, kk = threadIdx.x % k;       // k divides 1024 (checked by the host)
+    const int r = threadIdx.x >> 4, c = threadIdx.x & 15, kk = blockIdx.x * 16 + c;
     float acc = 0.f;
-    for (int o = r; o < d; o += rows) acc += part[(size_t)o * k + kk];
+#pragma unroll 4
+    for (int o = r; o < d; o += 64) acc += part[(size_t)o * k + kk];
     red[threadIdx.x] = acc;
     __syncthreads();
+    for (int h = 32; h >= 1; h >>= 1) {
+        if (r < h) red[threadIdx.x] += red[threadIdx.x + 16 * h];
+        __syncthreads();
+    }
     if (r == 0) {
-        for (int j = 1; j < rows; ++j) acc += red[j * k + kk];
+        acc = red[c];
         if (dg_out) {
             stat[kk] = acc;
             dg_out[kk] += acc * inv_norm[kk];
@@ -298,31 +320,37 @@ __global__ __launch_bounds__(1024) void wn_reduce_kernel(const float* __restrict
 
 // blockIdx.y = 0: wf[o][kk][ci] = s[kk] v[o][ci][kk]                 (o = g*dg + co: [G][co][kk][ci])
 // blockIdx.y = 1: block b = (g, ci): wt[g][ci][kk'][co] = s[k-1-kk'] v[g*dg+co][ci][k-1-kk'],  s = g * inv_norm
-template <typename T>
+template <typename T, int DG, int KK>
 __global__ __launch_bounds__(256) void wn_pack_kernel(const float* __restrict__ v, const float* __restrict__ gain,
                                                       const float* __restrict__ inv_norm, T* __restrict__ wf, T* __restrict__ wt,
-                                                      int dg, int k) {
+                                                      int dg_rt, int k_rt) {
     __shared__ float tile[WN_MAXDG * (WN_MAXK + 1)];
     __shared__ float sc[WN_MAXK];
+    const WnDims<DG, KK> D(dg_rt, k_rt);
+    const int dg = D.dg(), k = D.k();
     const int b = blockIdx.x, n = dg * k;
     for (int kk = threadIdx.x; kk < k; kk += 256) sc[kk] = gain[kk] * inv_norm[kk];
     if (blockIdx.y == 0) {
         const float* vo = v + (size_t)b * n;
+#pragma unroll 4
         for (int e = threadIdx.x; e < n; e += 256) tile[(e / k) * (k + 1) + e % k] = vo[e];
         __syncthreads();
         T* dst = wf + (size_t)b * n;
+#pragma unroll 4
         for (int e = threadIdx.x; e < n; e += 256) {
             const int kk = e / dg, ci = e % dg;
             dst[e] = from_f<T>(tile[ci * (k + 1) + kk] * sc[kk]);
         }
     } else {
         const int g = b / dg, ci = b % dg;
+#pragma unroll 4
         for (int e = threadIdx.x; e < n; e += 256) {
             const int co = e / k, kk = e % k;
             tile[co * (k + 1) + kk] = v[((size_t)(g * dg + co) * dg + ci) * k + kk];
         }
         __syncthreads();
         T* dst = wt + (size_t)b * n;
+#pragma unroll 4
         for (int e = threadIdx.x; e < n; e += 256) {
             const int kf = k - 1 - e / dg, co = e % dg;
             dst[e] = from_f<T>(tile[co * (k + 1) + kf] * sc[kf]);
@@ -331,11 +359,14 @@ __global__ __launch_bounds__(256) void wn_pack_kernel(const float* __restrict__ 
 }
 
 // dv[o][ci][kk] += s[kk] * (dwg[o][kk][ci] - v[o][ci][kk] * dot[kk] * inv_norm[kk]^2)
+template <int DG, int KK>
 __global__ __launch_bounds__(256) void wn_bwd_kernel(const float* __restrict__ dwg, const float* __restrict__ v,
                                                      const float* __restrict__ gain, const float* __restrict__ inv_norm,
-                                                     const float* __restrict__ dot, float* __restrict__ dv, int dg, int k) {
+                                                     const float* __restrict__ dot, float* __restrict__ dv, int dg_rt, int k_rt) {
     __shared__ float tile[WN_MAXK * (WN_MAXDG + 1)];
     __shared__ float sc[WN_MAXK], pj[WN_MAXK];
+    const WnDims<DG, KK> D(dg_rt, k_rt);
+    const int dg = D.dg(), k = D.k();
     const int o = blockIdx.x, n = dg * k;
     for (int kk = threadIdx.x; kk < k; kk += 256) {
         const float in = inv_norm[kk];
@@ -343,15 +374,20 @@ __global__ __launch_bounds__(256) void wn_bwd_kernel(const float* __restrict__ d
         pj[kk] = dot[kk] * in * in;
     }
     const float* dwo = dwg + (size_t)o * n;
+#pragma unroll 4
     for (int e = threadIdx.x; e < n; e += 256) tile[(e / dg) * (dg + 1) + e % dg] = dwo[e];
     __syncthreads();
     const float* vo = v + (size_t)o * n;
     float* dvo = dv + (size_t)o * n;
+#pragma unroll 4
     for (int e = threadIdx.x; e < n; e += 256) {
         const int ci = e / k, kk = e % k;
         dvo[e] += sc[kk] * (tile[kk * (dg + 1) + ci] - vo[e] * pj[kk]);
     }
 }
+
+// compile-time sizes for the two shapes audio8 builds (d/groups = 48 or 64, k = 128); anything else takes run-time sizes
+#define WN_DISPATCH(dg, k, CALL) do { if ((k) == 128 && (dg) == 48) { CALL(48, 128); } else if ((k) == 128 && (dg) == 64) { CALL(64, 128); } else { CALL(0, 0); } } while (0)
 
 }  // namespace
 
@@ -402,14 +438,19 @@ extern "C" int a8_weightnorm_pack(int dtype, const float* v, const float* g, voi
                                   int d, int groups, int k, void* stream) {
     A8_REQUIRE(groups >= 1 && d % groups == 0, "a8_weightnorm_pack: d=%d not divisible by groups=%d", d, groups);
     const int dg = d / groups;
-    A8_REQUIRE(k >= 1 && k <= WN_MAXK && 1024 % k == 0 && dg <= WN_MAXDG, "a8_weightnorm_pack: k=%d must divide 1024 (<= %d), d/groups=%d <= %d",
+    A8_REQUIRE(k >= 16 && k <= WN_MAXK && (k & (k - 1)) == 0 && dg <= WN_MAXDG, "a8_weightnorm_pack: k=%d must be a power of two in 16..%d, d/groups=%d <= %d",
                k, WN_MAXK, dg, WN_MAXDG);
     A8_REQUIRE(dtype == A8_F32 || dtype == A8_BF16, "a8_weightnorm_pack: bad dtype");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(wn_partial_kernel, dim3(d), dim3(256), 0, s, v, (const float*)nullptr, scratch, dg, k);
-    hipLaunchKernelGGL(wn_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)scratch, (const float*)nullptr, inv_norm, (float*)nullptr, d, k);
-    if (dtype == A8_BF16) hipLaunchKernelGGL(wn_pack_kernel<bf16>, dim3(d, 2), dim3(256), 0, s, v, g, (const float*)inv_norm, (bf16*)wf, (bf16*)wt, dg, k);
-    else hipLaunchKernelGGL(wn_pack_kernel<float>, dim3(d, 2), dim3(256), 0, s, v, g, (const float*)inv_norm, (float*)wf, (float*)wt, dg, k);
+#define WN_PART(DG, KK) hipLaunchKernelGGL((wn_partial_kernel<DG, KK>), dim3(d), dim3(256), 0, s, v, (const float*)nullptr, scratch, dg, k)
+    WN_DISPATCH(dg, k, WN_PART);
+#undef WN_PART
+    hipLaunchKernelGGL(wn_reduce_kernel, dim3(k / 16), dim3(1024), 0, s, (const float*)scratch, (const float*)nullptr, inv_norm, (float*)nullptr, d, k);
+#define WN_PACK(DG, KK) do { \
+        if (dtype == A8_BF16) hipLaunchKernelGGL((wn_pack_kernel<bf16, DG, KK>), dim3(d, 2), dim3(256), 0, s, v, g, (const float*)inv_norm, (bf16*)wf, (bf16*)wt, dg, k); \
+        else hipLaunchKernelGGL((wn_pack_kernel<float, DG, KK>), dim3(d, 2), dim3(256), 0, s, v, g, (const float*)inv_norm, (float*)wf, (float*)wt, dg, k); } while (0)
+    WN_DISPATCH(dg, k, WN_PACK);
+#undef WN_PACK
     return a8_check_launch("a8_weightnorm_pack");
 }
 
@@ -417,12 +458,16 @@ extern "C" int a8_weightnorm_bwd(const float* dwg, const float* v, const float* 
                                  float* scratch, int d, int groups, int k, void* stream) {
     A8_REQUIRE(groups >= 1 && d % groups == 0, "a8_weightnorm_bwd: d=%d not divisible by groups=%d", d, groups);
     const int dg = d / groups;
-    A8_REQUIRE(k >= 1 && k <= WN_MAXK && 1024 % k == 0 && dg <= WN_MAXDG, "a8_weightnorm_bwd: k=%d must divide 1024 (<= %d), d/groups=%d <= %d",
+    A8_REQUIRE(k >= 16 && k <= WN_MAXK && (k & (k - 1)) == 0 && dg <= WN_MAXDG, "a8_weightnorm_bwd: k=%d must be a power of two in 16..%d, d/groups=%d <= %d",
                k, WN_MAXK, dg, WN_MAXDG);
     hipStream_t s = (hipStream_t)stream;
     float* dot = scratch + (size_t)d * k;
-    hipLaunchKernelGGL(wn_partial_kernel, dim3(d), dim3(256), 0, s, v, dwg, scratch, dg, k);
-    hipLaunchKernelGGL(wn_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)scratch, inv_norm, dot, dgain, d, k);
-    hipLaunchKernelGGL(wn_bwd_kernel, dim3(d), dim3(256), 0, s, dwg, v, g, inv_norm, (const float*)dot, dv, dg, k);
+#define WN_PART(DG, KK) hipLaunchKernelGGL((wn_partial_kernel<DG, KK>), dim3(d), dim3(256), 0, s, v, dwg, scratch, dg, k)
+    WN_DISPATCH(dg, k, WN_PART);
+#undef WN_PART
+    hipLaunchKernelGGL(wn_reduce_kernel, dim3(k / 16), dim3(1024), 0, s, (const float*)scratch, inv_norm, dot, dgain, d, k);
+#define WN_BWD(DG, KK) hipLaunchKernelGGL((wn_bwd_kernel<DG, KK>), dim3(d), dim3(256), 0, s, dwg, v, g, inv_norm, (const float*)dot, dv, dg, k)
+    WN_DISPATCH(dg, k, WN_BWD);
+#undef WN_BWD
     return a8_check_launch("a8_weightnorm_bwd");
 }

@@ -58,7 +58,8 @@ int a8_gemm_grouped(const a8_gemm_desc* descs, int n, void* stream);
 /* developer tuning knobs, never needed for correctness (defaults are the measured best): key 0 GEMM stage geometry
  * variant; 1 LayerNorm-backward geometry (waves*100 + rows per wave); 2..4 attention fwd / dK,dV / dQ geometry (waves*10 +
  * 16-row groups per wave); 5 minimum tile count for the experimental register-pipelined 256x128 NT GEMM (0 = off);
- * 6 positional-conv weight-gradient loop splits */
+ * 6 positional-conv weight-gradient loop splits; 7 experimental 160-row NT GEMM tiles for 257..512-tile problems (0 = off,
+ * 2..4 = LDS ring depth) */
 int a8_set_tuning(int key, int value);
 
 /* ---- per-step weight preparation (the f32 -> compute-dtype casts the reference's autocast-free f32 path never needs;
@@ -137,7 +138,7 @@ int a8_posconv_wgrad(int dtype, const void* x, const void* dz, float* dw, int B,
  * v f32 [d][d/groups][k], g f32 [k]:  w[o][ci][kk] = g[kk] * v[o][ci][kk] / ||v[:, :, kk]||.
  * a8_weightnorm_pack writes the two operand images a8_posconv_fwd takes, in `dtype`:
  *   wf [G][co][kk][ci] = w[g*dg+co][ci][kk] (forward),  wt [G][ci][kk'][co] = w[g*dg+co][ci][k-1-kk'] (data gradient),
- * and inv_norm f32 [k] = 1 / ||v[:, :, kk]|| for the backward pass.  scratch: f32 [d*k].  k must divide 1024 (<= 128).
+ * and inv_norm f32 [k] = 1 / ||v[:, :, kk]|| for the backward pass.  scratch: f32 [d*k].  k: a power of two in 16..128.
  * a8_weightnorm_bwd takes dwg f32 [G][co][kk][ci] (what a8_posconv_wgrad produces) through the weight norm:
  *   dgain[kk] += <dw, v>_kk * inv_norm[kk];   dv += g * inv_norm * (dw - v * <dw, v>_kk * inv_norm^2).   scratch: f32 [d*k + k]. */
 int a8_weightnorm_pack(int dtype, const float* v, const float* g, void* wf, void* wt, float* inv_norm, float* scratch,

@@ -181,6 +181,50 @@ def test_gemm_add_epilogue(dtype):
     np.testing.assert_allclose(out.double().cpu().numpy(), ref.numpy(), rtol=tol, atol=tol)
 
 
+@pytest.mark.parametrize("depth", [2, 3, 4])
+def test_gemm_160_row_tiles_match_default(depth):
+    """The experimental 160-row-tile NT kernel (a8_set_tuning key 7; 10 waves, uneven LDS-DMA piece counts padded with
+    zero-page DMAs) walks K in the default order: bit-identical outputs on the 257..512-tile shapes that dispatch to it,
+    with M tails (6248 = 39 * 160 + 8), bias/GELU/zout, the residual-add and the column-sum epilogues."""
+    from audio8_amd import kernels as Kn, _lib as L
+    dev, bf = "cuda", torch.bfloat16
+
+    def both(fn):
+        L.check(L.lib().a8_set_tuning(7, 0), "tune")
+        ref = fn()
+        L.check(L.lib().a8_set_tuning(7, depth), "tune")
+        try:
+            got = fn()
+        finally:
+            L.check(L.lib().a8_set_tuning(7, 0), "tune")
+        for r, g_ in zip(ref, got):
+            assert torch.equal(r, g_)
+
+    for (M, N, K) in [(6248, 768, 768), (6248, 768, 3080), (5000, 896, 520), (33000, 128, 136)]:
+        A, B = _mk((M, K), bf, 1).to(dev), _mk((N, K), bf, 2).to(dev)
+        bias, z = torch.randn(N, device=dev), _mk((M, N), bf, 5).to(dev)
+        both(lambda: (Kn.gemm(L.NT, A, B, M, N, K),))
+
+        def gelu_zout():
+            zo = torch.empty(M, N, device=dev, dtype=bf)
+            return Kn.gemm(L.NT, A, B, M, N, K, bias=bias, act=L.ACT_GELU, zout=zo), zo
+        both(gelu_zout)
+        both(lambda: (Kn.gemm(L.NT, A, B, M, N, K, act=L.ACT_ADD, zin=z, ldz=N),))
+
+        def with_colsum():
+            cs = torch.zeros(N, device=dev)
+            return Kn.gemm(L.NT, A, B, M, N, K, act=L.ACT_MUL_GELU_GRAD, zin=z, ldz=N, colsum=cs), cs
+        L.check(L.lib().a8_set_tuning(7, 0), "tune")
+        r0, c0 = with_colsum()
+        L.check(L.lib().a8_set_tuning(7, depth), "tune")
+        try:
+            r1, c1 = with_colsum()
+        finally:
+            L.check(L.lib().a8_set_tuning(7, 0), "tune")
+        assert torch.equal(r0, r1)
+        torch.testing.assert_close(c0, c1, rtol=1e-4, atol=1e-2)       # (column sums combine in a different block order)
+
+
 def test_gemm_register_pipelined_kernel_matches_default():
     """The 256x128 register-pipelined NT kernel (a8_set_tuning key 5) walks K in the same order as the default kernel:
     outputs must be bit-identical across shapes with M/N/K tails, the conv row remap and every epilogue."""
