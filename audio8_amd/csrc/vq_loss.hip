@@ -11,15 +11,18 @@ namespace {
 constexpr int VMAX_PER_LANE = 8;   // V <= 512
 
 // ------------------------------------------------------------------ VQ: argmax + mean softmax
-__global__ __launch_bounds__(256) void vq_select_kernel(const float* __restrict__ logits, const float* __restrict__ gumbel,
-                                                        int32_t* __restrict__ codes, float* __restrict__ avg, int R, int V) {
-    __shared__ float s_avg[64 * VMAX_PER_LANE];
+// One row per wave, 16 rows per block: the block's 16 softmax rows are summed through LDS and written as ONE partial
+// row (no atomics: R*V same-address adds, LDS or global, were 25 of this kernel's 30 us); vq_avg_reduce_kernel sums the
+// partial rows into avg_probs.
+constexpr int VQ_ROWS = 16;
+__global__ __launch_bounds__(64 * VQ_ROWS) void vq_select_kernel(const float* __restrict__ logits, const float* __restrict__ gumbel,
+                                                                 int32_t* __restrict__ codes, float* __restrict__ partial, int R, int V) {
+    __shared__ float s_p[VQ_ROWS * 64 * VMAX_PER_LANE];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < V; i += 256) s_avg[i] = 0.f;
-    __syncthreads();
-    const float invR = 1.0f / (float)R;
-    for (int row = blockIdx.x * 4 + wv; row < R; row += gridDim.x * 4) {
-        float x[VMAX_PER_LANE];
+    const int row = blockIdx.x * VQ_ROWS + wv;
+    float x[VMAX_PER_LANE];
+    float inv = 0.f;
+    if (row < R) {
         float mx = -INFINITY, best = -INFINITY;
         int bi = 0x7fffffff;
 #pragma unroll
@@ -44,14 +47,35 @@ __global__ __launch_bounds__(256) void vq_select_kernel(const float* __restrict_
 #pragma unroll
         for (int j = 0; j < VMAX_PER_LANE; ++j) { x[j] = (lane + 64 * j < V) ? __expf(x[j] - mx) : 0.f; s += x[j]; }
         s = wave_sum(s);
-        const float inv = invR / s;
-#pragma unroll
-        for (int j = 0; j < VMAX_PER_LANE; ++j)
-            if (lane + 64 * j < V) atomicAdd(&s_avg[lane + 64 * j], x[j] * inv);
+        inv = 1.0f / ((float)R * s);
         if (lane == 0) codes[row] = bi;
     }
+#pragma unroll
+    for (int j = 0; j < VMAX_PER_LANE; ++j)
+        if (lane + 64 * j < V) s_p[wv * V + lane + 64 * j] = row < R ? x[j] * inv : 0.f;
     __syncthreads();
-    for (int i = threadIdx.x; i < V; i += 256) atomicAdd(avg + i, s_avg[i]);
+    for (int v = threadIdx.x; v < V; v += 64 * VQ_ROWS) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < VQ_ROWS; ++q) t += s_p[q * V + v];
+        partial[(long long)blockIdx.x * V + v] = t;
+    }
+}
+
+// avg[v] = sum_b partial[b][v]; block c owns columns [64 c, 64 c + 64), 16 row groups
+__global__ __launch_bounds__(1024) void vq_avg_reduce_kernel(const float* __restrict__ partial, float* __restrict__ avg, int nb, int V) {
+    __shared__ float red[1024];
+    const int r = threadIdx.x >> 6, v = blockIdx.x * 64 + (threadIdx.x & 63);
+    float t = 0.f;
+    if (v < V)
+        for (int b = r; b < nb; b += 16) t += partial[(long long)b * V + v];
+    red[threadIdx.x] = t;
+    __syncthreads();
+    if (r == 0 && v < V) {
+#pragma unroll
+        for (int q = 1; q < 16; ++q) t += red[q * 64 + (threadIdx.x & 63)];
+        avg[v] = t;
+    }
 }
 
 template <typename T>
@@ -311,12 +335,14 @@ int gridw(int rows) { int b = (rows + 3) / 4; return b < 1 ? 1 : (b > 2048 ? 204
 
 }  // namespace
 
-extern "C" int a8_vq_select(const float* logits, const float* gumbel, float tau, int32_t* codes, float* avg_probs, int R, int V, void* stream) {
+extern "C" int a8_vq_select(const float* logits, const float* gumbel, float tau, int32_t* codes, float* avg_probs, float* scratch,
+                            int R, int V, void* stream) {
     A8_REQUIRE(V >= 1 && V <= 64 * VMAX_PER_LANE, "a8_vq_select: V=%d must be <= %d", V, 64 * VMAX_PER_LANE);
     A8_REQUIRE(tau > 0.f, "a8_vq_select: tau must be positive");
-    if (hipMemsetAsync(avg_probs, 0, sizeof(float) * V, (hipStream_t)stream) != hipSuccess) return a8_set_error(A8_ERR_LAUNCH, "a8_vq_select: memset failed");
-    if (R == 0) return A8_OK;
-    hipLaunchKernelGGL(vq_select_kernel, dim3(gridw(R) > 256 ? 256 : gridw(R)), dim3(256), 0, (hipStream_t)stream, logits, gumbel, codes, avg_probs, R, V);
+    A8_REQUIRE(R >= 0, "a8_vq_select: bad row count");
+    const int nb = cdiv(R, VQ_ROWS);                    // (R = 0: avg_probs = 0)
+    if (nb) hipLaunchKernelGGL(vq_select_kernel, dim3(nb), dim3(64 * VQ_ROWS), 0, (hipStream_t)stream, logits, gumbel, codes, scratch, R, V);
+    hipLaunchKernelGGL(vq_avg_reduce_kernel, dim3(cdiv(V, 64)), dim3(1024), 0, (hipStream_t)stream, (const float*)scratch, avg_probs, nb, V);
     return a8_check_launch("a8_vq_select");
 }
 

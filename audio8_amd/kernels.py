@@ -291,7 +291,8 @@ def vq_select(logits, gumbel, tau):
     R, V = logits.shape
     codes = torch.empty((R,), device=logits.device, dtype=torch.int32)
     avg = torch.empty((V,), device=logits.device, dtype=torch.float32)
-    L.check(L.lib().a8_vq_select(L.ptr(_c(logits)), L.ptr(_c(gumbel)), _f(tau), L.ptr(codes), L.ptr(avg), R, V, L.stream()), "a8_vq_select")
+    scratch = torch.empty((((R + 15) // 16) * V,), device=logits.device, dtype=torch.float32)        # A8_VQ_SELECT_SCRATCH_FLOATS
+    L.check(L.lib().a8_vq_select(L.ptr(_c(logits)), L.ptr(_c(gumbel)), _f(tau), L.ptr(codes), L.ptr(avg), L.ptr(scratch), R, V, L.stream()), "a8_vq_select")
     return codes, avg
 
 

@@ -161,8 +161,11 @@ int a8_attn_bwd(int dtype, const void* q, const void* k, const void* v, const vo
 
 /* ---- Gumbel-softmax product quantiser (GumbelVectorQuantizer.forward audio8/wav2vec2.py:547-576) ----
  * logits f32 [R, V] (R = B*Tm*G rows), gumbel f32 [R,V] or NULL (eval: plain argmax);
- * codes i32 [R]; ysoft_sel f32 [R] (y_soft at the chosen code); avg_probs f32 [V] (zeroed by the call) */
-int a8_vq_select(const float* logits, const float* gumbel, float tau, int32_t* codes, float* avg_probs, int R, int V, void* stream);
+ * codes i32 [R]; avg_probs f32 [V] = mean over rows of softmax(logits) (written, not accumulated);
+ * scratch: f32 [A8_VQ_SELECT_SCRATCH_FLOATS(R, V)] (per-block partial rows: no atomics anywhere) */
+#define A8_VQ_SELECT_SCRATCH_FLOATS(R, V) ((((size_t)(R) + 15) / 16) * (size_t)(V))
+int a8_vq_select(const float* logits, const float* gumbel, float tau, int32_t* codes, float* avg_probs, float* scratch,
+                 int R, int V, void* stream);
 /* q[n, g*D + :] = vars[g*V + codes[n*G+g], :]  (codebook gather; vars f32 [G*V, D]); q dtype [N, G*D] */
 int a8_vq_gather(int dtype, const float* vars, const int32_t* codes, void* q, int N, int G, int V, int D, void* stream);
 /* prob_ppl = sum exp(-sum p log(p + 1e-7)) over avg_probs[V] -> ppl[0]; dppl_davg[V] */

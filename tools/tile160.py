@@ -19,13 +19,13 @@ for N, Kd in ((768, 768), (768, 2304), (768, 3072), (640, 512)):
     outs = {}
     res = []
     for rnd in range(2):
-        for thr in (0, 2, 3, 4):
+        for thr in (0, 2, 4):
             L.check(L.lib().a8_set_tuning(7, thr), "tune")
             out = torch.empty(M, N, device="cuda", dtype=bf)
             t = timeit(lambda: K.gemm(L.NT, A, B, M, N, Kd, out=out, bias=bias), iters=30)
             outs[thr] = out
             res.append("key7=%d %.1f us (%.0f TF/s)" % (thr, t, 2.0 * M * N * Kd / t / 1e6))
-    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[3]) and torch.equal(outs[0], outs[4])
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[4])
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     print("M=%d N=%d K=%d tiles=%d: " % (M, N, Kd, tiles) + " | ".join(res), flush=True)
-L.check(L.lib().a8_set_tuning(7, 1), "tune")
+L.check(L.lib().a8_set_tuning(7, 0), "tune")
