@@ -95,127 +95,129 @@ template <int KB> struct StageTile<float, KB> {
     }
 };
 
-// ---- epilogue (shared by the main-loop variants).  Needs NWM*2 waves x (16*MI rows x 64 cols x 4 B) of free LDS.
-template <typename T, int MI, int NWM>
+// ---- epilogue (shared by the main-loop variants).  Needs NWM*2 waves x (16*MI/NP rows x 64 cols x 4 B) of free LDS;
+// NP = passes over the wave's rows (2 halves the staging so that small-LDS variants keep their occupancy).
+template <typename T, int MI, int NWM, int NP = 1>
 A8_DEV void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MI][4], char* lds, const int w, const int m0, const int n0, const int lane) {
     const int wm = w >> 1, wn = w & 1;
-    // ---- epilogue through LDS: each wave parks its 64x64 f32 sub-tile in its own 16 KB of the (now free) ring, then
+    // ---- epilogue through LDS: each wave parks its 64-column f32 sub-tile in its own slab of the (now free) ring, then
     // walks it row by row so that every global store / f32 atomic wave-instruction is ONE contiguous row segment
     // (256 B of f32, 128 B of bf16) instead of 16 rows x 16 B -- the shape the memory-side atomic units need.
     constexpr int WROWS = 16 * MI;                                    // rows of the tile owned by a wave
-    float* cw = reinterpret_cast<float*>(lds) + w * (WROWS * 64);
-    {
-        const int g4 = lane >> 4, li = lane & 15;
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                f32x4 v = acc[i][j];
-                v *= g.alpha;
-                *reinterpret_cast<f32x4*>(cw + (16 * i + li) * 64 + (((4 * j + g4) ^ li) << 2)) = v;
-            }
-    }
-    __builtin_amdgcn_wave_barrier();      // the tile is wave-private: program order of this wave's LDS ops suffices
-    const int mw = m0 + wm * WROWS, nw = n0 + wn * 64;
+    constexpr int MP = MI / NP, PROWS = 16 * MP;                      // fragments / rows per pass
+    static_assert(MI % NP == 0, "passes must divide the wave's row fragments");
+    float* cw = reinterpret_cast<float*>(lds) + w * (PROWS * 64);
+    const int nw = n0 + wn * 64;
     auto zrow = [&](int m) -> long long { return g.z_rpb ? (m / g.z_rpb) * g.z_bs + (m % g.z_rpb) * g.ldz : (long long)m * g.ldz; };
     const bool f32_rows = g.out_f32 || sizeof(T) == 4;
-    if (f32_rows) {
-        const int n = nw + lane;
-        const bool n_ok = n < g.N;
-        const float bn = (g.bias && !g.bias_rows && n_ok) ? g.bias[n] : 0.f;
-        float csum = 0.f;
-        for (int rr = 0; rr < WROWS; ++rr) {
-            const int m = mw + rr;
-            if (m >= g.M) break;
-            float v = cw[rr * 64 + ((((lane >> 2) ^ (rr & 15))) << 2) + (lane & 3)] + bn;
-            if (g.bias && g.bias_rows) v += g.bias[m];
-            if (!n_ok) continue;
-            if (g.zout) reinterpret_cast<T*>(g.zout)[zrow(m) + n] = from_f<T>(v);
-            if (g.act == A8_ACT_GELU) v = gelu_f(v);
-            else if (g.act == A8_ACT_MUL_GELU_GRAD) v *= gelu_grad_f(to_f(reinterpret_cast<const T*>(g.zin)[zrow(m) + n]));
-            else if (g.act == A8_ACT_ADD) v += to_f(reinterpret_cast<const T*>(g.zin)[zrow(m) + n]);
-            const long long crow = g.c_rpb ? (m / g.c_rpb) * g.c_bs + (m % g.c_rpb) * g.ldc : (long long)m * g.ldc;
-            float* cp = reinterpret_cast<float*>(g.C) + crow + n;
-            if (g.atomic) atomicAdd(cp, v);
-            else *cp = v;
-            csum += v;
-        }
-        if (g.colsum) {                                  // block-uniform: combine the NWM row-waves in LDS, one atomic per column per block
-            cw[lane] = csum;                             // the wave is done with its staging area
-            __syncthreads();
-            if (wm == 0) {
-                float t = 0.f;
+    float csum1 = 0.f;
+    float csum8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int q = 0; q < NWM; ++q) t += reinterpret_cast<const float*>(lds)[(q * 2 + wn) * (WROWS * 64) + lane];
-                if (n_ok) atomicAdd(g.colsum + n, t);
+    for (int ps = 0; ps < NP; ++ps) {
+        if (ps) __builtin_amdgcn_wave_barrier();
+        {
+            const int g4 = lane >> 4, li = lane & 15;
+#pragma unroll
+            for (int i = 0; i < MP; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 v = acc[ps * MP + i][j];
+                    v *= g.alpha;
+                    *reinterpret_cast<f32x4*>(cw + (16 * i + li) * 64 + (((4 * j + g4) ^ li) << 2)) = v;
+                }
+        }
+        __builtin_amdgcn_wave_barrier();      // the tile is wave-private: program order of this wave's LDS ops suffices
+        const int mw = m0 + wm * WROWS + ps * PROWS;
+        if (f32_rows) {
+            const int n = nw + lane;
+            const bool n_ok = n < g.N;
+            const float bn = (g.bias && !g.bias_rows && n_ok) ? g.bias[n] : 0.f;
+            for (int rr = 0; rr < PROWS; ++rr) {
+                const int m = mw + rr;
+                if (m >= g.M) break;
+                float v = cw[rr * 64 + ((((lane >> 2) ^ (rr & 15))) << 2) + (lane & 3)] + bn;
+                if (g.bias && g.bias_rows) v += g.bias[m];
+                if (!n_ok) continue;
+                if (g.zout) reinterpret_cast<T*>(g.zout)[zrow(m) + n] = from_f<T>(v);
+                if (g.act == A8_ACT_GELU) v = gelu_f(v);
+                else if (g.act == A8_ACT_MUL_GELU_GRAD) v *= gelu_grad_f(to_f(reinterpret_cast<const T*>(g.zin)[zrow(m) + n]));
+                else if (g.act == A8_ACT_ADD) v += to_f(reinterpret_cast<const T*>(g.zin)[zrow(m) + n]);
+                const long long crow = g.c_rpb ? (m / g.c_rpb) * g.c_bs + (m % g.c_rpb) * g.ldc : (long long)m * g.ldc;
+                float* cp = reinterpret_cast<float*>(g.C) + crow + n;
+                if (g.atomic) atomicAdd(cp, v);
+                else *cp = v;
+                csum1 += v;
+            }
+        } else {
+            // 16-bit output: lane owns 8 consecutive columns (16 B), a wave-instruction covers 8 rows x 128 B
+            const int c8 = (lane & 7) << 3;                 // first column within the wave's 64
+            const int n = nw + c8;
+            const bool n_ok = n < g.N;
+            float bn[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bn[e] = (g.bias && !g.bias_rows && n_ok) ? g.bias[n + e] : 0.f;
+            typedef T T8 __attribute__((ext_vector_type(8)));
+            for (int it = 0; it < PROWS / 8; ++it) {
+                if (mw + 8 * it >= g.M) break;
+                const int rr = 8 * it + (lane >> 3);
+                const int m = mw + rr;
+                const int ch = c8 >> 2;                      // even 16-byte chunk index; its partner is ch + 1
+                const f32x4 p0 = *reinterpret_cast<const f32x4*>(cw + rr * 64 + ((ch ^ (rr & 15)) << 2));
+                const f32x4 p1 = *reinterpret_cast<const f32x4*>(cw + rr * 64 + (((ch + 1) ^ (rr & 15)) << 2));
+                if (m >= g.M || !n_ok) continue;
+                float v[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+                const float bm = (g.bias && g.bias_rows) ? g.bias[m] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += bn[e] + bm;
+                if (g.zout) {
+                    T8 zv;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) zv[e] = from_f<T>(v[e]);
+                    *reinterpret_cast<T8*>(reinterpret_cast<T*>(g.zout) + zrow(m) + n) = zv;
+                }
+                if (g.act == A8_ACT_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+                } else if (g.act == A8_ACT_MUL_GELU_GRAD) {
+                    const T8 zz = *reinterpret_cast<const T8*>(reinterpret_cast<const T*>(g.zin) + zrow(m) + n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(to_f(zz[e]));
+                } else if (g.act == A8_ACT_ADD) {
+                    const T8 zz = *reinterpret_cast<const T8*>(reinterpret_cast<const T*>(g.zin) + zrow(m) + n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += to_f(zz[e]);
+                }
+                const long long crow = g.c_rpb ? (m / g.c_rpb) * g.c_bs + (m % g.c_rpb) * g.ldc : (long long)m * g.ldc;
+                T8 ov;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { ov[e] = from_f<T>(v[e]); csum8[e] += v[e]; }
+                *reinterpret_cast<T8*>(reinterpret_cast<T*>(g.C) + crow + n) = ov;
             }
         }
-    } else {
-        // 16-bit output: lane owns 8 consecutive columns (16 B), a wave-instruction covers 8 rows x 128 B
-        const int c8 = (lane & 7) << 3;                 // first column within the wave's 64
-        const int n = nw + c8;
-        const bool n_ok = n < g.N;
-        float bn[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bn[e] = (g.bias && !g.bias_rows && n_ok) ? g.bias[n + e] : 0.f;
-        typedef T T8 __attribute__((ext_vector_type(8)));
-        float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int it = 0; it < WROWS / 8; ++it) {
-            if (mw + 8 * it >= g.M) break;
-            const int rr = 8 * it + (lane >> 3);
-            const int m = mw + rr;
-            const int ch = c8 >> 2;                      // even 16-byte chunk index; its partner is ch + 1
-            const f32x4 p0 = *reinterpret_cast<const f32x4*>(cw + rr * 64 + ((ch ^ (rr & 15)) << 2));
-            const f32x4 p1 = *reinterpret_cast<const f32x4*>(cw + rr * 64 + (((ch + 1) ^ (rr & 15)) << 2));
-            if (m >= g.M || !n_ok) continue;
-            float v[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
-            const float bm = (g.bias && g.bias_rows) ? g.bias[m] : 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += bn[e] + bm;
-            if (g.zout) {
-                T8 zv;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) zv[e] = from_f<T>(v[e]);
-                *reinterpret_cast<T8*>(reinterpret_cast<T*>(g.zout) + zrow(m) + n) = zv;
-            }
-            if (g.act == A8_ACT_GELU) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
-            } else if (g.act == A8_ACT_MUL_GELU_GRAD) {
-                const T8 zz = *reinterpret_cast<const T8*>(reinterpret_cast<const T*>(g.zin) + zrow(m) + n);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(to_f(zz[e]));
-            } else if (g.act == A8_ACT_ADD) {
-                const T8 zz = *reinterpret_cast<const T8*>(reinterpret_cast<const T*>(g.zin) + zrow(m) + n);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += to_f(zz[e]);
-            }
-            const long long crow = g.c_rpb ? (m / g.c_rpb) * g.c_bs + (m % g.c_rpb) * g.ldc : (long long)m * g.ldc;
-            T8 ov;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { ov[e] = from_f<T>(v[e]); csum[e] += v[e]; }
-            *reinterpret_cast<T8*>(reinterpret_cast<T*>(g.C) + crow + n) = ov;
-        }
-        if (g.colsum) {                                  // block-uniform; lanes l, l+8, .. l+56 hold the same 8 columns
+    }
+    if (g.colsum) {                                      // block-uniform: combine the NWM row-waves in LDS, one atomic per column per block
+        if (f32_rows) {
+            cw[lane] = csum1;                            // the wave is done with its staging area
+        } else {                                         // lanes l, l+8, .. l+56 hold the same 8 columns
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float t = csum[e];
+                float t = csum8[e];
                 t += __shfl_xor(t, 8, 64);
                 t += __shfl_xor(t, 16, 64);
                 t += __shfl_xor(t, 32, 64);
-                csum[e] = t;
+                csum8[e] = t;
             }
             if (lane < 8) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) cw[lane * 8 + e] = csum[e];      // the wave is done with its staging area
+                for (int e = 0; e < 8; ++e) cw[lane * 8 + e] = csum8[e];
             }
-            __syncthreads();
-            if (wm == 0) {                               // one atomic per column per block (128 per tile)
-                float t = 0.f;
+        }
+        __syncthreads();
+        if (wm == 0) {
+            float t = 0.f;
 #pragma unroll
-                for (int q = 0; q < NWM; ++q) t += reinterpret_cast<const float*>(lds)[(q * 2 + wn) * (WROWS * 64) + lane];
-                if (nw + lane < g.N) atomicAdd(g.colsum + nw + lane, t);
-            }
+            for (int q = 0; q < NWM; ++q) t += reinterpret_cast<const float*>(lds)[(q * 2 + wn) * (PROWS * 64) + lane];
+            if (nw + lane < g.N) atomicAdd(g.colsum + nw + lane, t);
         }
     }
 }
@@ -238,7 +240,8 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
     constexpr int PPW = PPA > PPB ? PPA : PPB;
     constexpr bool UNEVEN = NPA % NW != 0 || NPB % NW != 0;                // then a wave without a last piece DMAs 16 zero bytes per lane
     constexpr int RING = NST * STAGE + (UNEVEN ? 1024 : 0);                // into a spare KB, so that vmcnt counts stay uniform
-    constexpr int EPI = NW * 16 * MI * 64 * 4;                             // epilogue staging: a 64-column f32 slab per wave
+    constexpr int NP = (KB == 1 && NST == 2) ? 2 : 1;                      // small-LDS variant: epilogue in two passes
+    constexpr int EPI = NW * 16 * MI * 64 * 4 / NP;                        // epilogue staging: a 64-column f32 slab per wave
     __shared__ __attribute__((aligned(1024))) char lds[RING > EPI ? RING : EPI];
 
     const int t = threadIdx.x, lane = t & 63;
@@ -395,7 +398,7 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    gemm_epilogue<T, MI, NWM>(g, acc, lds, w, m0, n0, lane);
+    gemm_epilogue<T, MI, NWM, NP>(g, acc, lds, w, m0, n0, lane);
 }
 
 // ---- register-pipelined main loop for large NT problems (both operands K-contiguous, 16-bit):
@@ -522,7 +525,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pf_kernel(const GemmArgs g) {
 }
 
 template <typename T, bool AKS, bool BKS, int KB, int NST, int NWM>
-__global__ __launch_bounds__(128 * NWM, NWM == 5 ? 3 : (NST * 2 * 8192 * KB <= 65536) ? NWM : NWM / 2) void gemm_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(128 * NWM, NWM == 5 ? 3 : (KB == 1 && NST == 2) ? 4 : (NST * 2 * 8192 * KB <= 65536) ? NWM : NWM / 2) void gemm_kernel(const GemmArgs g) {
     gemm_body<T, AKS, BKS, KB, NST, NWM>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n * g.nsplit));
 }
 
@@ -568,6 +571,7 @@ template <typename T> int launch(const a8_gemm_desc* d, const GemmArgs& g, int g
             case 1: return launch2<T, 1, 4, 2>(d, g, grid, s);
             case 5: return launch2<T, 2, 2, 4>(d, g, grid, s);      // 8 waves per block (4 waves/SIMD at 2 blocks/CU)
             case 6: return launch2<T, 1, 4, 4>(d, g, grid, s);      // 8 waves, 64-byte rows, 4-deep ring
+            case 7: return launch2<T, 1, 2, 2>(d, g, grid, s);      // 4 waves of 64x64, 64-byte rows, 2-deep ring: 32 KB of LDS, 4 blocks/CU
             default: return launch2<T, 2, 2, 2>(d, g, grid, s);
         }
     } else {
@@ -592,7 +596,7 @@ static int build_args(const a8_gemm_desc* d, GemmArgs& g, long long* grid) {
     A8_REQUIRE(d->lda % epc == 0 && d->ldb % epc == 0 && d->ldc % 4 == 0, "a8_gemm: leading dimensions must keep 16-byte alignment");
     A8_REQUIRE(((uintptr_t)d->A % 16) == 0 && ((uintptr_t)d->B % 16) == 0 && ((uintptr_t)d->C % 16) == 0, "a8_gemm: pointers must be 16-byte aligned");
     A8_REQUIRE(d->a_bs % epc == 0 && d->b_bs % epc == 0, "a8_gemm: batch strides must keep 16-byte alignment");
-    const int bk = d->dtype == A8_BF16 ? ((g_variant == 1 || g_variant == 6) ? 32 : 64) : 16;
+    const int bk = d->dtype == A8_BF16 ? ((g_variant == 1 || g_variant == 6 || g_variant == 7) ? 32 : 64) : 16;
     g.A = Op{(const char*)d->A, d->lda, d->a_rpb, d->a_bs};
     g.B = Op{(const char*)d->B, d->ldb, d->b_rpb, d->b_bs};
     g.C = (char*)d->C; g.ldc = d->ldc; g.c_rpb = d->c_rpb; g.c_bs = d->c_bs;

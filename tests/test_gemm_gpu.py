@@ -105,7 +105,7 @@ def test_gemm_rejects_bad_args():
         Kn.gemm(L.NT, A, A, 16, 16, 12)
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 6, 7])
 @pytest.mark.parametrize("layout", ["NT", "NN", "TN"])
 def test_gemm_tuning_variants_are_exact(variant, layout):
     """Every stage-geometry / wave-count variant selectable through a8_set_tuning computes the same exact result."""
