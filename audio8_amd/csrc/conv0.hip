@@ -63,58 +63,94 @@ A8_DEV void conv_frame(const float* xs, int tl, const float (&w)[8][KW], float (
     }
 }
 
-// ---- forward pass 1: per-chunk (sum, sumsq) per channel -> part[b][chunk][c][2]
-constexpr int CHF = 256;
-__global__ __launch_bounds__(256) void conv0_stats_kernel(const float* __restrict__ x, const float* __restrict__ wg,
-                                                          float* __restrict__ part, int L, int L0, int nchunk) {
-    __shared__ float xs[ST * CHF + 8];
-    __shared__ float red[4][CC][2];
-    const int b = blockIdx.y, chunk = blockIdx.x, t0 = chunk * CHF;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c0 = lane * 8;
-    stage_x<CHF>(xs, x + (long long)b * L, t0, L);
-    float w[8][KW];
-    load_w(w, wg, c0);
-    __syncthreads();
-    float s[8], q[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
-    for (int tl = wv; tl < CHF && t0 + tl < L0; tl += 4) {
-        float v[8], xv[KW];
-        conv_frame(xs, tl, w, v, xv);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { s[j] += v[j]; q[j] = fmaf(v[j], v[j], q[j]); }
+// ---- forward passes 1+2: GroupNorm statistics WITHOUT running the conv.  The conv is linear in 10 taps, so per (b,c)
+//   sum_t v = sum_k w[c][k] S[k],   sum_t v^2 = sum_{j,k} w[c][j] w[c][k] R[j][k],
+//   S[k] = sum_t x[5t+k],  R[j][k] = sum_t x[5t+j] x[5t+k]        (65 channel-free numbers per utterance)
+// Pass 1 accumulates S and R per chunk of frames in f64 (products of f32 samples are exact in f64, so filters whose
+// output is small against their taps' energy lose nothing to cancellation); pass 2 (one block per utterance) sums the
+// chunks and evaluates the two forms per channel in f64.  (Was: a pass computing all 204.8 M conv outputs, 60 us.)
+constexpr int CHF = 256;                         // frames per block of the apply pass
+constexpr int CHM = 512;                         // frames per moments block
+constexpr int NMOM = KW + KW * (KW + 1) / 2;     // S[10], then the upper triangle of R row by row
+A8_DEV void mom_jk(int i, int& j, int& k) {      // moment index -> taps: i < 10: S[i] (k = -1); else R[j][k], j <= k, row by row
+    if (i < KW) { j = i; k = -1; return; }
+    int r = i - KW;
+    j = 0;
+    while (r >= KW - j) { r -= KW - j; ++j; }
+    k = j + r;
+}
+// Lane l of every wave owns moment l; wave w walks frames w, w+4, ... over an f64 copy of the chunk (f64 converts and
+// FMAs are quarter rate: convert once).  The 65th moment, R[9][9], is a thread-strided side loop.  No atomics.
+__global__ __launch_bounds__(256) void conv0_moments_kernel(const float* __restrict__ x, double* __restrict__ part, int L, int L0, int nchunk) {
+    __shared__ double xd[ST * CHM + 8];
+    __shared__ double red[4][NMOM + 1];
+    const int b = blockIdx.y, chunk = blockIdx.x, t0 = chunk * CHM;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    {
+        const float* xb = x + (long long)b * L;
+        const int s0 = ST * t0;
+        for (int i = threadIdx.x; i < ST * CHM + (KW - ST); i += 256) xd[i] = (s0 + i < L) ? (double)xb[s0 + i] : 0.0;
     }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { red[wv][c0 + j][0] = s[j]; red[wv][c0 + j][1] = q[j]; }
     __syncthreads();
-    float* out = part + ((long long)b * nchunk + chunk) * CC * 2;
-    for (int i = threadIdx.x; i < CC * 2; i += 256) {
-        const int c = i >> 1, h = i & 1;
-        out[i] = red[0][c][h] + red[1][c][h] + red[2][c][h] + red[3][c][h];
+    int j0, k0;
+    mom_jk(lane, j0, k0);
+    const int nfr = min(CHM, L0 - t0);
+    double m0 = 0.0, m0b = 0.0, m1 = 0.0;
+    // S moments multiply by a constant 1.0 parked behind the chunk (stride 0): one uniform loop for all lanes
+    if (threadIdx.x == 0) xd[ST * CHM + 7] = 1.0;
+    __syncthreads();
+    const double* pj = xd + j0;
+    const double* pk = k0 >= 0 ? xd + k0 : xd + ST * CHM + 7;
+    const int sk = k0 >= 0 ? ST : 0;
+    int tl = wv;
+#pragma unroll 4
+    for (; tl + 4 < nfr; tl += 8) {
+        m0 = fma(pj[ST * tl], pk[sk * tl], m0);
+        m0b = fma(pj[ST * (tl + 4)], pk[sk * (tl + 4)], m0b);
     }
+    if (tl < nfr) m0 = fma(pj[ST * tl], pk[sk * tl], m0);
+    m0 += m0b;
+    for (int tl = threadIdx.x; tl < nfr; tl += 256) { const double e = xd[ST * tl + KW - 1]; m1 = fma(e, e, m1); }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m1 += __shfl_xor(m1, o, 64);
+    red[wv][lane] = m0;
+    if (lane == 0) red[wv][NMOM - 1] = m1;
+    __syncthreads();
+    if (threadIdx.x < NMOM)
+        part[((long long)b * nchunk + chunk) * NMOM + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-// ---- forward pass 2: (mean, rstd) per (b,c) in f64; 16 lanes share one (b,c) and stride over its chunks
-__global__ void conv0_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats, int B, int nchunk, int L0, float eps) {
-    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, sub = threadIdx.x & 15;
-    double s = 0.0, q = 0.0;
-    if (i < B * CC) {
-        const int b = i / CC, c = i % CC;
-        for (int ch = sub; ch < nchunk; ch += 16) {
-            const float* p = part + (((long long)b * nchunk + ch) * CC + c) * 2;
-            s += (double)p[0];
-            q += (double)p[1];
-        }
+// one block of CC threads per utterance: (mean, rstd) per channel from the utterance's moments
+__global__ __launch_bounds__(CC) void conv0_finalize_kernel(const double* __restrict__ part, const float* __restrict__ wg,
+                                                            float* __restrict__ stats, int nchunk, int L0, float eps) {
+    __shared__ double mom[NMOM];
+    __shared__ double slab[7][NMOM];
+    const int b = blockIdx.x, c = threadIdx.x;
+    if (c < 7 * NMOM) {                          // 7 slices of the chunk list per moment
+        const int i = c % NMOM, r = c / NMOM;
+        double t = 0.0;
+        for (int ch = r; ch < nchunk; ch += 7) t += part[((long long)b * nchunk + ch) * NMOM + i];
+        slab[r][i] = t;
     }
+    __syncthreads();
+    if (c < NMOM) mom[c] = ((slab[0][c] + slab[1][c]) + (slab[2][c] + slab[3][c])) + ((slab[4][c] + slab[5][c]) + slab[6][c]);
+    __syncthreads();
+    double w[KW];
 #pragma unroll
-    for (int o = 8; o >= 1; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
-    if (i < B * CC && sub == 0) {
-        const double mu = s / L0;
-        double var = q / L0 - mu * mu;
-        if (var < 0.0) var = 0.0;
-        stats[i * 2 + 0] = (float)mu;
-        stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    for (int k = 0; k < KW; ++k) w[k] = (double)wg[c * KW + k];
+    double s = 0.0, q = 0.0;
+    int n = KW;
+#pragma unroll
+    for (int j = 0; j < KW; ++j) {
+        s += w[j] * mom[j];
+#pragma unroll
+        for (int k = j; k < KW; ++k) { q += (j == k ? 1.0 : 2.0) * w[j] * w[k] * mom[n]; ++n; }
     }
+    const double mu = s / L0;
+    double var = q / L0 - mu * mu;
+    if (var < 0.0) var = 0.0;
+    stats[((long long)b * CC + c) * 2 + 0] = (float)mu;
+    stats[((long long)b * CC + c) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
 // ---- forward pass 3: out = gelu(gn(conv(x)))
@@ -286,10 +322,12 @@ extern "C" int a8_conv0_gn_gelu_fwd(int dtype, const float* x, const float* w, c
     A8_REQUIRE(C_ == CC, "a8_conv0_gn_gelu_fwd: C must be %d (got %d)", CC, C_);
     A8_REQUIRE(L >= KW && B >= 1, "a8_conv0_gn_gelu_fwd: bad B=%d L=%d", B, L);
     A8_REQUIRE(dtype == A8_F32 || dtype == A8_BF16, "a8_conv0_gn_gelu_fwd: bad dtype");
-    const int L0 = conv0_out_len(L), nchunk = cdiv(L0, CHF);
+    A8_REQUIRE(((uintptr_t)part % 8) == 0, "a8_conv0_gn_gelu_fwd: scratch must be 8-byte aligned");
+    const int L0 = conv0_out_len(L), nchunk = cdiv(L0, CHF), nmom = cdiv(L0, CHM);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(conv0_stats_kernel, dim3(nchunk, B), dim3(256), 0, s, x, w, part, L, L0, nchunk);
-    hipLaunchKernelGGL(conv0_finalize_kernel, dim3(cdiv(B * CC * 16, 256)), dim3(256), 0, s, part, stats, B, nchunk, L0, eps);
+    double* mpart = reinterpret_cast<double*>(part);          // [B][nmom][65] doubles
+    hipLaunchKernelGGL(conv0_moments_kernel, dim3(nmom, B), dim3(256), 0, s, x, mpart, L, L0, nmom);
+    hipLaunchKernelGGL(conv0_finalize_kernel, dim3(B), dim3(CC), 0, s, (const double*)mpart, w, stats, nmom, L0, eps);
     if (dtype == A8_BF16)
         hipLaunchKernelGGL(conv0_apply_kernel<bf16>, dim3(nchunk, B), dim3(256), 0, s, x, w, gn_w, gn_b, stats, (bf16*)out, L, L0);
     else

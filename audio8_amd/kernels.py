@@ -118,7 +118,7 @@ def conv0_gn_gelu_fwd(x, w, gn_w, gn_b, out_dtype, eps=1e-5):
     L0 = conv_out_len(Ls, 10, 5)
     out = torch.empty((B, L0, Cn), device=x.device, dtype=out_dtype)
     stats = torch.empty((B, Cn, 2), device=x.device, dtype=torch.float32)
-    part = torch.empty((B, (L0 + 255) // 256, Cn, 2), device=x.device, dtype=torch.float32)
+    part = torch.empty((B * ((L0 + 511) // 512) * 65,), device=x.device, dtype=torch.float64)      # A8_CONV0_FWD_SCRATCH_FLOATS
     L.check(L.lib().a8_conv0_gn_gelu_fwd(L.dt(out), L.ptr(_c(x)), L.ptr(_c(w)), L.ptr(gn_w), L.ptr(gn_b), L.ptr(out), L.ptr(stats),
                                          L.ptr(part), B, Ls, Cn, _f(eps), L.stream()), "a8_conv0_gn_gelu_fwd")
     return out, stats

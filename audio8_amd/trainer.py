@@ -148,7 +148,7 @@ class WeightCache:
 class GradReducer:
     """Bucketed all-reduce of the flat gradient buffer, overlapped with backward."""
 
-    def __init__(self, state: FlatState, bucket_mb: float = 32.0, process_group=None):
+    def __init__(self, state: FlatState, bucket_mb: float = 32.0, process_group=None, tail_elems: int = 65536):
         self.state = state
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -166,6 +166,22 @@ class GradReducer:
             if hi - lo >= cap or i == 0:
                 self.buckets.append({"lo": lo, "hi": hi, "members": members, "pending": len(members)})
                 hi, members = lo, []
+        # The parameters whose gradients arrive LAST (the first ones: conv layer 0 and its GroupNorm, a few thousand
+        # elements) get a bucket of their own: the big final bucket then goes out while conv layer 0's backward still runs,
+        # and only a latency-sized exchange is left exposed after the last backward kernel.
+        last = self.buckets[-1]
+        idx = sorted(last["members"])
+        n_tail, acc = 0, 0
+        for i in idx:
+            size = (state.offsets[i + 1] if i + 1 < len(state.params) else state.total) - state.offsets[i]
+            if acc + size > tail_elems:
+                break
+            acc += size
+            n_tail += 1
+        if 0 < n_tail < len(idx):
+            cut = state.offsets[idx[n_tail]]
+            self.buckets[-1] = {"lo": cut, "hi": last["hi"], "members": idx[n_tail:], "pending": len(idx) - n_tail}
+            self.buckets.append({"lo": last["lo"], "hi": cut, "members": idx[:n_tail], "pending": n_tail})
         self.bucket_of = {}
         for b, bk in enumerate(self.buckets):
             for i in bk["members"]:

@@ -76,7 +76,9 @@ int a8_prepare_weights_device(int dtype, const a8_wprep_desc* descs_dev, const i
 
 /* ---- conv layer 0 + GroupNorm + GELU (audio8/wav2vec2.py:417-423, Cin=1, k=10, s=5) --------------
  * x f32 [B,L]; w f32 [C,10]; out dtype [B,L0,C] channels-last; stats f32 [B,C,2] = (mean, rstd).
- * part is scratch f32 [B, nchunk, C, 2] with nchunk = ceil(L0 / 256). */
+ * part is scratch, 8-byte aligned, A8_CONV0_FWD_SCRATCH_FLOATS(B, L0) floats (f64 waveform moments per 512-frame chunk: the
+ * GroupNorm statistics come from 65 channel-free sums per utterance, not from a pass over the conv outputs). */
+#define A8_CONV0_FWD_SCRATCH_FLOATS(B, L0) ((size_t)(B) * (((size_t)(L0) + 511) / 512) * 65 * 2)
 int a8_conv0_gn_gelu_fwd(int dtype, const float* x, const float* w, const float* gn_w, const float* gn_b,
                          void* out, float* stats, float* part, int B, int L, int C, float eps, void* stream);
 /* backward: dout dtype [B,L0,C] -> dw f32 [C,10], dgn_w, dgn_b f32 [C] (all accumulated, +=).

@@ -29,8 +29,13 @@ def _worker(rank, world, port, q):
         frozen_probe = torch.nn.Parameter(torch.zeros(1000))       # never used in forward: its bucket gets no hook
         model.register_parameter("unused", frozen_probe)
         st = FlatState(model)
-        red = GradReducer(st, bucket_mb=0.2)
+        red = GradReducer(st, bucket_mb=0.2, tail_elems=2000)
         assert len(red.buckets) >= 2
+        cover = sorted((b["lo"], b["hi"]) for b in red.buckets)          # the buckets partition the flat buffer
+        assert cover[0][0] == 0 and cover[-1][1] == st.total and all(cover[i][1] == cover[i + 1][0] for i in range(len(cover) - 1))
+        assert sorted(i for b in red.buckets for i in b["members"]) == list(range(len(st.params)))
+        tail = red.buckets[-1]                                           # last-arriving gradients: a small bucket of their own
+        assert tail["lo"] == 0 and 0 < tail["hi"] - tail["lo"] <= 2000 and len(red.buckets) >= 3
         ok = True
         for step in range(2):
             st.zero_grad()

@@ -49,6 +49,33 @@ def test_conv0_gn_gelu(dtype):
     close(dgb, gb.grad, tol, "conv0 dgn_b")
 
 
+def test_conv0_statistics_on_correlated_audio_and_differencing_filters():
+    """GroupNorm statistics come from 65 waveform moments per utterance (sum_t v^2 = w^T R w): the hard case is a smooth,
+    DC-shifted waveform against differencing filters, whose outputs are tiny next to the energy of their taps
+    (cancellation in w^T R w).  Moments are accumulated in f64, so (mean, rstd) must still match an f64 reference."""
+    from audio8_amd import kernels as K
+    B, L, C = 2, 40000, 512
+    t = torch.arange(L, dtype=torch.float64)
+    x = torch.stack([0.3 + 0.5 * torch.sin(2 * math.pi * t / 400.0) + 0.01 * rnd((L,), 1).double(),
+                     -0.7 + 0.2 * torch.sin(2 * math.pi * t / 90.0) * torch.cos(2 * math.pi * t / 7000.0) + 1e-3 * rnd((L,), 2).double()]).float()
+    w = rnd((C, 1, 10), 3, math.sqrt(2 / 10))
+    w[0, 0] = torch.tensor([1., -1., 0, 0, 0, 0, 0, 0, 0, 0])                      # first difference
+    w[1, 0] = torch.tensor([1., -2., 1., 0, 0, 0, 0, 0, 0, 0])                     # second difference
+    w[2, 0] = torch.tensor([1., -4., 6., -4., 1., 0, 0, 0, 0, 0])                  # fourth difference
+    w[3, 0] = 0.1                                                                  # moving average (large mean, small variance)
+    w[4:260, 0] -= w[4:260, 0].mean(-1, keepdim=True)                              # zero-DC random filters
+    v = F.conv1d(x.double().unsqueeze(1), w.double(), stride=5)                    # [B, C, L0]
+    mu, var = v.mean(-1), v.var(-1, unbiased=False)
+    gw, gb = torch.ones(C), torch.zeros(C)
+    out, stats = K.conv0_gn_gelu_fwd(x.cuda(), w.cuda(), gw.cuda(), gb.cuda(), torch.float32)
+    st = stats.cpu().double()
+    scale = var.sqrt()
+    assert float(((st[..., 0] - mu).abs() / (scale + 1e-3)).max()) < 1e-5
+    np.testing.assert_allclose(st[..., 1].numpy(), (1.0 / (var + 1e-5).sqrt()).numpy(), rtol=2e-5)
+    ref = F.gelu(F.group_norm(v, C, gw.double(), gb.double(), 1e-5)).transpose(1, 2)
+    close(out, ref, 1e-4, "conv0 fwd on correlated audio")
+
+
 def test_conv0_golden_g3(golden_dir):
     """Layer 0 of the golden conv stack (reference's own ConvFeatureExtractionModel) in f32."""
     from audio8_amd import kernels as K
