@@ -132,6 +132,26 @@ template <> struct RowFrags<float> {
     }
 };
 
+// sum over the head dimension of a[row][:] * b[row][:] for the row this lane holds (lanes li, li+16, li+32, li+48 share a row)
+A8_DEV float row_dot(const RowFrags<bf16>& a, const RowFrags<bf16>& b) {
+    float s = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s = __builtin_fmaf((float)a.f[ks][i], (float)b.f[ks][i], s);
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    return s;
+}
+A8_DEV float row_dot(const RowFrags<float>& a, const RowFrags<float>& b) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s = __builtin_fmaf(a.f[i], b.f[i], s);
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    return s;
+}
+
 // acc[j][i] (i = 0..3) = 16x16 blocks of Tile . rows_j^T for G register-resident row groups: each tile fragment is
 // read from LDS once and feeds G MFMAs.   acc[j][i][r] = sum_d Tile[16i+4g+r][d] * rows_j[lane&15][d]
 template <typename T, int G> A8_DEV void tile_times_rows(const char* tile, const RowFrags<T> (&rf)[G], f32x4 (&acc)[G][4], int lane) {
@@ -353,32 +373,6 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnP P) {
     }
 }
 
-// ================================================================== delta = rowsum(dO * O)
-template <typename T>
-__global__ void attn_delta_kernel(const AttnP P) {
-    const long long n = (long long)P.B * P.T * P.H;
-    const long long idx = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 3;     // 8 lanes per (b,t,h)
-    const int sub = threadIdx.x & 7;
-    float s = 0.f;
-    if (idx < n) {
-        const int h = (int)(idx % P.H);
-        const long long bt = idx / P.H;
-        const T* op = reinterpret_cast<const T*>(P.o) + bt * P.ld_o + h * DH + sub * 8;
-        const T* dp = reinterpret_cast<const T*>(P.dout) + bt * P.ld_o + h * DH + sub * 8;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) s += to_f(op[i]) * to_f(dp[i]);
-    }
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 4, 64);
-    if (idx < n && sub == 0) {
-        const int h = (int)(idx % P.H);
-        const long long bt = idx / P.H;
-        const int b = (int)(bt / P.T), t = (int)(bt % P.T);
-        P.delta[((long long)(b * P.H + h)) * P.T + t] = s;
-    }
-}
-
 // ================================================================== backward A: dK, dV (key block stationary)
 // block = NW waves, each wave owns G groups of 16 keys; streams Q / dO tiles (+ lse, delta of the tile's queries)
 template <typename T, int NW, int G>
@@ -507,6 +501,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_q_kernel(const AttnP P) {
     const T* kb = reinterpret_cast<const T*>(P.k) + (long long)b * P.T * P.ld_qkv + h * DH;
     const T* vb = reinterpret_cast<const T*>(P.v) + (long long)b * P.T * P.ld_qkv + h * DH;
     const T* dob = reinterpret_cast<const T*>(P.dout) + (long long)b * P.T * P.ld_o + h * DH;
+    const T* ob = reinterpret_cast<const T*>(P.o) + (long long)b * P.T * P.ld_o + h * DH;
     const uint8_t* km = P.keymask ? P.keymask + (long long)b * P.T : nullptr;
     const int ntiles = (P.T + BT - 1) / BT;
 
@@ -522,7 +517,14 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_q_kernel(const AttnP P) {
         qf[j].load(qb + (long long)qi[j] * P.ld_qkv, ok, lane);
         dof[j].load(dob + (long long)qi[j] * P.ld_o, ok, lane);
         nlse[j] = ok ? -P.lse[(long long)bh * P.T + qi[j]] : 0.f;
-        ndelta[j] = ok ? -P.delta[(long long)bh * P.T + qi[j]] : 0.f;
+        {   // delta = rowsum(dO * O) of this block's own queries: computed here (this kernel runs first) and published for
+            // the dK/dV kernel -- no separate pass over O and dO
+            RowFrags<T> of;
+            of.load(ob + (long long)qi[j] * P.ld_o, ok, lane);
+            const float dl = row_dot(of, dof[j]);
+            ndelta[j] = -dl;
+            if (ok && g == 0) P.delta[(long long)bh * P.T + qi[j]] = dl;
+        }
         hb[j] = (pair_base(bh, P.T, P.Th, qi[j]) + (uint32_t)(2 * g) + P.seed) * HC1;
 #pragma unroll
         for (int i = 0; i < 4; ++i) dq[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -637,10 +639,8 @@ extern "C" int a8_attn_bwd(int dtype, const void* q, const void* k, const void* 
     P.B = B; P.T = T_; P.H = H; P.ld_qkv = ld_qkv; P.ld_o = ld_o; P.ld_d = ld_dqkv;
     set_softmax_params(P, scale, p, seed);
     hipStream_t s = (hipStream_t)stream;
-    const long long nrow = (long long)B * T_ * H;
-    if (dtype == A8_BF16) hipLaunchKernelGGL(attn_delta_kernel<bf16>, dim3(cdiv(nrow * 8, 256)), dim3(256), 0, s, P);
-    else hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(cdiv(nrow * 8, 256)), dim3(256), 0, s, P);
-    A8_ATTN_LAUNCH(attn_bwd_kv_kernel, 3, "a8_attn_bwd")
+    // dQ first: it computes delta = rowsum(dO * O) for its own query rows and publishes it for the dK/dV kernel
     A8_ATTN_LAUNCH(attn_bwd_q_kernel, 4, "a8_attn_bwd")
+    A8_ATTN_LAUNCH(attn_bwd_kv_kernel, 3, "a8_attn_bwd")
     return a8_check_launch("a8_attn_bwd");
 }
