@@ -9,15 +9,26 @@ import sys
 
 def main():
     d, nsteps = sys.argv[1], int(sys.argv[2])
-    st = glob.glob(d + "/*kernel_stats.csv")[0]
     tr = glob.glob(d + "/*kernel_trace.csv")[0]
-    rows = list(csv.DictReader(open(st)))
-    tot = sum(float(r["TotalDurationNs"]) for r in rows)
-    print(f"total kernel time {tot / 1e6 / nsteps:.3f} ms/step over {nsteps} steps")
-    for r in rows[:int(sys.argv[3]) if len(sys.argv) > 3 else 24]:
-        n = re.sub(r"\(anonymous namespace\)::", "", r["Name"])
+    # per-kernel table from the TRACE, restricted to the steady steps (after the first optimizer step: the --stats CSV also
+    # holds model set-up copies and every kernel's first launch, which includes loading its code object)
+    trace = list(csv.DictReader(open(tr)))
+    trace.sort(key=lambda r: int(r["Start_Timestamp"]))
+    ends = [i for i, r in enumerate(trace) if "adamw" in r["Kernel_Name"]]
+    steady, nst = trace[ends[0] + 1: ends[-1] + 1], len(ends) - 1
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in steady:
+        a = agg[r["Kernel_Name"]]
+        a[0] += 1
+        a[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    tot = sum(a[1] for a in agg.values())
+    print(f"total kernel time {tot / 1e6 / nst:.3f} ms/step over the {nst} steady steps of the trace (of {nsteps} run; the last two are bench.py's instrumented "
+          f"roofline steps, the very last one with the weight-gradient side stream off)")
+    top = sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(sys.argv[3]) if len(sys.argv) > 3 else 24]
+    for name, (calls, ns) in top:
+        n = re.sub(r"\(anonymous namespace\)::", "", name)
         n = re.sub(r"_ZN12_GLOBAL__N_1\d+", "", n)[:70]
-        print(f"{float(r['TotalDurationNs']) / 1e6 / nsteps:8.3f} ms/step  calls/step {int(r['Calls']) / nsteps:6.1f}  avg {float(r['AverageNs']) / 1e3:8.1f} us  {float(r['Percentage']):5.1f}%  {n}")
+        print(f"{ns / 1e6 / nst:8.3f} ms/step  calls/step {calls / nst:6.1f}  avg {ns / calls / 1e3:8.1f} us  {100 * ns / tot:5.1f}%  {n}")
     g = [r for r in csv.DictReader(open(tr)) if "gemm_kernel" in r["Kernel_Name"]]
     n = len(g) // nsteps
     agg = collections.OrderedDict()
