@@ -181,14 +181,16 @@ template <typename T> A8_DEV void load_row(const T* p, int lane, float (&v)[CPL]
     for (int i = 0; i < CPL; ++i) v[i] = to_f(p[lane + 64 * i]);
 }
 
+// inverse row norms of both operands in one launch: inv[0..rows) for x0, inv[rows..2 rows) for x1
 template <typename T>
-__global__ __launch_bounds__(256) void rownorm_kernel(const T* __restrict__ x, float* __restrict__ inv, int rows, int Cn) {
+__global__ __launch_bounds__(256) void rownorm_kernel(const T* __restrict__ x0, const T* __restrict__ x1, float* __restrict__ inv, int rows, int Cn) {
     const int lane = threadIdx.x & 63;
-    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < 2 * rows; r += gridDim.x * 4) {
+        const T* x = r < rows ? x0 + (long long)r * Cn : x1 + (long long)(r - rows) * Cn;
         float s = 0.f;
-        for (int c = lane; c < Cn; c += 64) { const float v = to_f(x[(long long)row * Cn + c]); s = fmaf(v, v, s); }
+        for (int c = lane; c < Cn; c += 64) { const float v = to_f(x[c]); s = fmaf(v, v, s); }
         s = wave_sum(s);
-        if (lane == 0) inv[row] = 1.0f / fmaxf(sqrtf(s), 1e-8f);   // torch.cosine_similarity eps
+        if (lane == 0) inv[r] = 1.0f / fmaxf(sqrtf(s), 1e-8f);   // torch.cosine_similarity eps
     }
 }
 
@@ -382,19 +384,17 @@ extern "C" int a8_contrastive_fwd(int dtype, const void* ctx, const void* lat, c
     float* ic = inv_norms; float* il = inv_norms + rows;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == A8_BF16) {
-        hipLaunchKernelGGL(rownorm_kernel<bf16>, dim3(gridw(rows)), dim3(256), 0, s, (const bf16*)ctx, ic, rows, Cn);
-        hipLaunchKernelGGL(rownorm_kernel<bf16>, dim3(gridw(rows)), dim3(256), 0, s, (const bf16*)lat, il, rows, Cn);
+        hipLaunchKernelGGL(rownorm_kernel<bf16>, dim3(gridw(2 * rows)), dim3(256), 0, s, (const bf16*)ctx, (const bf16*)lat, ic, rows, Cn);
         hipLaunchKernelGGL(contrastive_fwd_kernel<bf16>, dim3(gridw(rows)), dim3(256), 0, s, (const bf16*)ctx, (const bf16*)lat, neg_idx, ic, il, logits, loss_sum, rows, N);
     } else if (dtype == A8_F32) {
-        hipLaunchKernelGGL(rownorm_kernel<float>, dim3(gridw(rows)), dim3(256), 0, s, (const float*)ctx, ic, rows, Cn);
-        hipLaunchKernelGGL(rownorm_kernel<float>, dim3(gridw(rows)), dim3(256), 0, s, (const float*)lat, il, rows, Cn);
+        hipLaunchKernelGGL(rownorm_kernel<float>, dim3(gridw(2 * rows)), dim3(256), 0, s, (const float*)ctx, (const float*)lat, ic, rows, Cn);
         hipLaunchKernelGGL(contrastive_fwd_kernel<float>, dim3(gridw(rows)), dim3(256), 0, s, (const float*)ctx, (const float*)lat, neg_idx, ic, il, logits, loss_sum, rows, N);
     } else return a8_set_error(A8_ERR_ARG, "a8_contrastive_fwd: bad dtype");
     return a8_check_launch("a8_contrastive_fwd");
 }
 
 extern "C" int a8_contrastive_bwd(int dtype, const void* ctx, const void* lat, const int32_t* neg_idx, const float* logits,
-                                  const float* gscale, float* dctx, float* dlat, float* scratch, int rows, int N, int Cn,
+                                  const float* gscale, const float* inv_norms, float* dctx, float* dlat, float* scratch, int rows, int N, int Cn,
                                   int rows_per_group, void* stream) {
     A8_REQUIRE(Cn == 64 * CPL, "a8_contrastive_bwd: C must be %d (got %d)", 64 * CPL, Cn);
     A8_REQUIRE(N >= 1 && N + 1 <= 128, "a8_contrastive_bwd: N=%d must be in [1,127]", N);
@@ -406,8 +406,11 @@ extern "C" int a8_contrastive_bwd(int dtype, const void* ctx, const void* lat, c
     // scratch: ic[rows] il[rows] wA[rows*(N+1)] wU[rows*(N+1)] | U[rows] W[rows*rpg] Cf[rows*256] G[rows*256]
     auto al4 = [](size_t n) { return (n + 3) & ~(size_t)3; };              // sub-buffers start 16-byte aligned (GEMM operands)
     A8_REQUIRE(((uintptr_t)scratch & 15) == 0, "a8_contrastive_bwd: scratch must be 16-byte aligned");
-    float* ic = scratch; float* il = ic + al4(rows);
-    float* wA = il + al4(rows); float* wU = wA + al4((size_t)rows * (N + 1));
+    // inverse row norms: the forward's (inv_norms, [2][rows]) or recomputed into scratch (then contiguous too)
+    float* icw = scratch;
+    const float* ic = inv_norms ? inv_norms : icw;
+    const float* il = ic + rows;
+    float* wA = icw + 2 * al4(rows); float* wU = wA + al4((size_t)rows * (N + 1));
     float* U = wU + al4((size_t)rows * (N + 1));
     float* W = U + al4(rows);                           // U and W are cleared together
     float* Cf = W + (size_t)rows * (grouped ? rpg4 : 0);
@@ -417,8 +420,7 @@ extern "C" int a8_contrastive_bwd(int dtype, const void* ctx, const void* lat, c
         return a8_set_error(A8_ERR_LAUNCH, "a8_contrastive_bwd: memset failed");
 #define A8_CBWD(T)                                                                                                                     \
     {                                                                                                                                  \
-        hipLaunchKernelGGL(rownorm_kernel<T>, dim3(gridw(rows)), dim3(256), 0, s, (const T*)ctx, ic, rows, Cn);                        \
-        hipLaunchKernelGGL(rownorm_kernel<T>, dim3(gridw(rows)), dim3(256), 0, s, (const T*)lat, il, rows, Cn);                        \
+        if (!inv_norms) hipLaunchKernelGGL(rownorm_kernel<T>, dim3(gridw(2 * rows)), dim3(256), 0, s, (const T*)ctx, (const T*)lat, icw, rows, Cn); \
         if (grouped) {                                                                                                                 \
             hipLaunchKernelGGL((contrastive_bwd_kernel<T, false>), dim3(gridw(rows)), dim3(256), 0, s, (const T*)ctx, (const T*)lat, neg_idx, ic, il, \
                                logits, gscale, dctx, dlat, wA, wU, rows, N);                                                           \

@@ -319,24 +319,26 @@ def vq_bwd(logits, gumbel, tau, codes, vars2d, dq, eproj, dppl, gppl, dvars, N, 
 
 # ----------------------------------------------------------------------------- contrastive
 def contrastive_fwd(ctx, lat, neg_idx):
+    """-> (logits f32 [rows, N+1], loss_sum f32 [1], inv_norms f32 [2, rows] for contrastive_bwd)."""
     rows, Cn = ctx.shape
     N = neg_idx.shape[1]
     logits = torch.empty((rows, N + 1), device=ctx.device, dtype=torch.float32)
     loss_sum = torch.zeros((1,), device=ctx.device, dtype=torch.float32)
-    scratch = torch.empty((2 * rows,), device=ctx.device, dtype=torch.float32)
+    inv_norms = torch.empty((2, rows), device=ctx.device, dtype=torch.float32)
     L.check(L.lib().a8_contrastive_fwd(L.dt(ctx), L.ptr(_c(ctx)), L.ptr(_c(lat)), L.ptr(_c(neg_idx)), L.ptr(logits), L.ptr(loss_sum),
-                                       L.ptr(scratch), rows, N, Cn, L.stream()), "a8_contrastive_fwd")
-    return logits, loss_sum
+                                       L.ptr(inv_norms), rows, N, Cn, L.stream()), "a8_contrastive_fwd")
+    return logits, loss_sum, inv_norms
 
 
-def contrastive_bwd(ctx, lat, neg_idx, logits, gscale, rows_per_group=0):
-    """rows_per_group: frames per utterance when every frame's negatives come from its own utterance (0: no assumption)."""
+def contrastive_bwd(ctx, lat, neg_idx, logits, gscale, rows_per_group=0, inv_norms=None):
+    """rows_per_group: frames per utterance when every frame's negatives come from its own utterance (0: no assumption);
+    inv_norms: the forward's inverse row norms (None: recomputed)."""
     rows, Cn = ctx.shape
     N = neg_idx.shape[1]
     dctx = torch.empty((rows, Cn), device=ctx.device, dtype=torch.float32)
     dlat = torch.zeros((rows, Cn), device=ctx.device, dtype=torch.float32)
     scratch = torch.empty((rows * (2 + 2 * (N + 1) + 1 + int(rows_per_group) + 7 + 768) + 32,), device=ctx.device, dtype=torch.float32)    # A8_CONTRASTIVE_BWD_SCRATCH_FLOATS
-    L.check(L.lib().a8_contrastive_bwd(L.dt(ctx), L.ptr(_c(ctx)), L.ptr(_c(lat)), L.ptr(_c(neg_idx)), L.ptr(logits), L.ptr(gscale),
+    L.check(L.lib().a8_contrastive_bwd(L.dt(ctx), L.ptr(_c(ctx)), L.ptr(_c(lat)), L.ptr(_c(neg_idx)), L.ptr(logits), L.ptr(gscale), L.ptr(inv_norms),
                                        L.ptr(dctx), L.ptr(dlat), L.ptr(scratch), rows, N, Cn, int(rows_per_group), L.stream()), "a8_contrastive_bwd")
     return dctx, dlat
 

@@ -705,7 +705,8 @@ class VQFn(torch.autograd.Function):
         N, Cin = y.shape
         D = vars_.shape[-1]
         y = y.contiguous()
-        wpc = _wcast(wp, y.dtype).contiguous()
+        e = cached_weights(wp, y.dtype)
+        wpc, wpt = e if e is not None else (_wcast(wp, y.dtype).contiguous(), None)
         logits = K.gemm(L.NT, y, wpc, N, G * V, Cin, bias=bp.detach(), out_dtype=torch.float32).view(N * G, V)
         if training and gumbel is None:
             gumbel = -torch.empty_like(logits).exponential_().log()
@@ -715,6 +716,8 @@ class VQFn(torch.autograd.Function):
         ppl, dppl = K.vq_ppl(avg)
         ctx.save_for_backward(y, wpc, logits, gumbel if training else None, codes, vars2d, dppl)
         ctx.cfg = (G, V, D, tau, training, vars_.shape)
+        ev = cached_weights(vars_, y.dtype)
+        ctx.wts = (wpt, ev[0] if ev is not None else None)
         ctx.params = (wp, bp, vars_)
         ctx.mark_non_differentiable(codes)
         return q, ppl, codes
@@ -731,7 +734,7 @@ class VQFn(torch.autograd.Function):
         eproj = None
         if training:
             eproj = torch.empty((N, G * V), device=dev, dtype=torch.float32)
-            vars_c = vars2d if dt == torch.float32 else K.cast(vars2d.contiguous(), dt)
+            vars_c = ctx.wts[1] if ctx.wts[1] is not None else (vars2d if dt == torch.float32 else K.cast(vars2d.contiguous(), dt))
             for g in range(G):
                 K.gemm(L.NT, dqc, vars_c[g * V:], N, V, D, lda=G * D, a_off=g * D, out=eproj, c_off=g * V, ldc=G * V)
         pwp, pbp, pvars = ctx.params
@@ -744,7 +747,7 @@ class VQFn(torch.autograd.Function):
         dbp = acc_colsum(pbp, dlogits)
         dl = dlogits if dt == torch.float32 else K.cast(dlogits, dt)
         dwp = acc_wgrad(pwp, dl, y, G * V, Cin, N)
-        dy = K.gemm(L.NN, dl, wpc, N, Cin, G * V)
+        dy = _dgrad(dl, wpc, ctx.wts[0], N, Cin, G * V)
         return dy, dwp, dbp, (None if tv is not None else dvars.view(vshape)), None, None, None, None, None
 
 
@@ -755,8 +758,8 @@ class ContrastiveXEFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, ctx_rows, lat_rows, neg_idx, rows_per_group=0, mean=True):
-        logits, loss_sum = K.contrastive_fwd(ctx_rows.contiguous(), lat_rows.contiguous(), neg_idx)
-        ctx.save_for_backward(ctx_rows, lat_rows, neg_idx, logits)
+        logits, loss_sum, inv_norms = K.contrastive_fwd(ctx_rows.contiguous(), lat_rows.contiguous(), neg_idx)
+        ctx.save_for_backward(ctx_rows, lat_rows, neg_idx, logits, inv_norms)
         ctx.rows_per_group, ctx.mean = rows_per_group, mean
         rows = ctx_rows.shape[0]
         ctx.mark_non_differentiable(logits)
@@ -764,10 +767,10 @@ class ContrastiveXEFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dloss, _dlogits):
-        c, q, neg_idx, logits = ctx.saved_tensors
+        c, q, neg_idx, logits, inv_norms = ctx.saved_tensors
         rows = c.shape[0]
         gscale = (dloss.float() / rows).reshape(1).contiguous() if ctx.mean else dloss.reshape(1)
-        dctx, dlat = K.contrastive_bwd(c.contiguous(), q.contiguous(), neg_idx, logits, gscale, ctx.rows_per_group)
+        dctx, dlat = K.contrastive_bwd(c.contiguous(), q.contiguous(), neg_idx, logits, gscale, ctx.rows_per_group, inv_norms)
         if c.dtype != torch.float32:
             dctx, dlat = K.cast(dctx, c.dtype), K.cast(dlat, q.dtype)
         return dctx, dlat, None, None, None

@@ -103,7 +103,13 @@ class WeightCache:
                     self.cache[id(wq)] = (dst, dst_t)
                     fused.update((id(wq), id(wk), id(wv)))
         for n, p in model.named_parameters():
-            if id(p) in fused or not p.requires_grad or "quantizer" in n or "pos_conv" in n:
+            if id(p) in fused or not p.requires_grad or "pos_conv" in n:
+                continue
+            if n.endswith("quantizer.vars"):              # codebook [1, G*V, D]: a 2-D working copy for the straight-through product
+                r, c = p.shape[1], p.shape[2]
+                dst = alloc(r, c)
+                jobs.append((p, r, c, 1, -1, dst, None, 0, 0))
+                self.cache[id(p)] = (dst, None)
                 continue
             if p.dim() == 2:
                 r, c = p.shape

@@ -189,16 +189,17 @@ int a8_vq_bwd(int dtype, const float* logits, const float* gumbel, float tau, co
  * ctx dtype [B*Tm, C] (context at masked frames), lat dtype [B*Tm, C] (quantised latents), neg_idx i32 [B*Tm, N]
  * (row indices into lat).  logits f32 [B*Tm, N+1] (column 0 = positive), loss_sum f32[1] += sum_rows CE(row, 0). */
 int a8_contrastive_fwd(int dtype, const void* ctx, const void* lat, const int32_t* neg_idx, float* logits,
-                       float* loss_sum, float* inv_norms /* scratch f32 [2*rows] */, int rows, int N, int C, void* stream);
+                       float* loss_sum, float* inv_norms /* out f32 [2][rows]: 1/|ctx row|, 1/|lat row| */, int rows, int N, int C, void* stream);
 /* dctx, dlat f32 [rows, C] (dlat accumulated with atomics: zero it first); gscale multiplies d(loss_sum).
  * rows_per_group > 0 declares that a row's negatives come from its own group of that many consecutive rows (one utterance,
  * as Sampler.negatives draws them): the latent gradient is then a small dense product per group instead of
  * global atomics per pair (any pair that does not obey it is still handled); 0 = no assumption.
+ * inv_norms: what a8_contrastive_fwd wrote for the same rows, or NULL (recomputed).
  * scratch: A8_CONTRASTIVE_BWD_SCRATCH_FLOATS(rows, N, rows_per_group) floats, 16-byte aligned. */
 #define A8_CONTRASTIVE_BWD_SCRATCH_FLOATS(rows, N, rows_per_group) \
     ((size_t)(rows) * (2 + 2 * ((N) + 1) + 1 + ((size_t)(rows_per_group) + 7) + 256 + 2 * 256) + 32)
 int a8_contrastive_bwd(int dtype, const void* ctx, const void* lat, const int32_t* neg_idx, const float* logits,
-                       const float* gscale, float* dctx, float* dlat, float* scratch, int rows, int N, int C,
+                       const float* gscale, const float* inv_norms, float* dctx, float* dlat, float* scratch, int rows, int N, int C,
                        int rows_per_group, void* stream);
 
 /* ---- CTC (F.ctc_loss native path, audio8/ctc.py:186-206) + log_softmax head (audio8/wav2vec2.py:770) ----

@@ -494,7 +494,7 @@ def test_contrastive_against_golden(golden_dir, dtype, group_mode):
     Tm = lat.shape[0] // B
     idx = torch.from_numpy(g["idx"]).view(B, Tm, -1).reshape(B * Tm, -1).int()   # [B, N*Tm] is (t, n) row-major per b
     N = idx.shape[1]
-    logits, loss_sum = K.contrastive_fwd(ctx.to(dtype).to(d), lat.to(dtype).to(d), idx.to(d))
+    logits, loss_sum, inv_norms = K.contrastive_fwd(ctx.to(dtype).to(d), lat.to(dtype).to(d), idx.to(d))
     ref_logits = torch.from_numpy(g["logits"]).view(Tm, B, N + 1).transpose(0, 1).reshape(B * Tm, N + 1)   # reference rows are t*B + b
     tol = 1e-5 if dtype == torch.float32 else 1e-2
     close(logits, ref_logits, tol, "cosine logits")
@@ -505,7 +505,9 @@ def test_contrastive_against_golden(golden_dir, dtype, group_mode):
     # "grouped": the latent gradient is accumulated per utterance in LDS; a deliberately wrong group size (rows that
     # point outside their group) must still give the right answer through the per-pair fallback
     rpg = {"scatter": 0, "grouped": Tm, "grouped_wrong_size": max(1, Tm // 2) if (B * Tm) % max(1, Tm // 2) == 0 else 1}[group_mode]
-    dctx, dlat = K.contrastive_bwd(ctx.to(dtype).to(d), lat.to(dtype).to(d), idx.to(d), logits, gscale, rows_per_group=rpg)
+    # the forward's inverse norms (as the model passes them), or recomputed by the backward (scatter mode here)
+    dctx, dlat = K.contrastive_bwd(ctx.to(dtype).to(d), lat.to(dtype).to(d), idx.to(d), logits, gscale, rows_per_group=rpg,
+                                   inv_norms=None if group_mode == "scatter" else inv_norms)
     g_out = torch.from_numpy(g["g_outputs"])
     ref_dctx = g_out[mask.unsqueeze(-1).expand_as(g_out)].view(-1, C)
     tolb = 1e-4 if dtype == torch.float32 else 3e-2
