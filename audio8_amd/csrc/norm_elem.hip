@@ -158,17 +158,24 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const T* __restrict__ d
     for (int row = blockIdx.x * NW + (threadIdx.x >> 6); row < rows; row += gridDim.x * NW) {
         const float mu = mean[row], rs = rstd[row];
         float xh[MC][8], g[MC][8];
+        uint32_t keep[MC];                       // the dropout mask of this row's chunks: hashed once, used for x and for dx
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int c = 0; c < MC; ++c) {
             const int ch = lane + 64 * c;
+            keep[c] = 0xFFu;
             if (ch < nch) {
                 const long long off = (long long)row * cols + ch * 8;
                 float v[8], gm[8];
                 load8(x + off, v);
                 if (dr.thr) {
+                    keep[c] = 0;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = a8_keep(dr.seed, dr.stream, (uint32_t)(off + i), dr.thr) ? v[i] * dr.scale : 0.f;
+                    for (int i = 0; i < 8; ++i) {
+                        const bool kp = a8_keep(dr.seed, dr.stream, (uint32_t)(off + i), dr.thr);
+                        keep[c] |= (kp ? 1u : 0u) << i;
+                        v[i] = kp ? v[i] * dr.scale : 0.f;
+                    }
                 }
                 if (res) {
                     float r[8];
@@ -207,7 +214,7 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const T* __restrict__ d
                 if (dres) store8(dres + off, o);
                 if (dr.thr) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) o[i] = a8_keep(dr.seed, dr.stream, (uint32_t)(off + i), dr.thr) ? o[i] * dr.scale : 0.f;
+                    for (int i = 0; i < 8; ++i) o[i] = ((keep[c] >> i) & 1u) ? o[i] * dr.scale : 0.f;
                 }
                 if (dx) store8(dx + off, o);
                 if (dbias) {
