@@ -158,7 +158,9 @@ class GradReducer:
         self.state = state
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        self.enabled = self.world > 1
+        # A8_FORCE_REDUCER=1: run the whole exchange path (hooks, buckets, side stream, RCCL calls) on a single rank too --
+        # a rehearsal of the N > 1 code on a one-GPU box (an all-reduce over one rank leaves the data unchanged)
+        self.enabled = self.world > 1 or (dist.is_initialized() and os.environ.get("A8_FORCE_REDUCER", "0") == "1")
         self.on_gpu = state.flat_g.is_cuda
         self.side = torch.cuda.Stream() if (self.enabled and self.on_gpu) else None
         cap = int(bucket_mb * 1024 * 1024 / 4)
@@ -345,7 +347,7 @@ def init_distributed_from_env():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if torch.cuda.is_available():
         torch.cuda.set_device(local % max(1, torch.cuda.device_count()))      # (more ranks than GPUs only in rehearsals)
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("A8_FORCE_REDUCER", "0") == "1") and not dist.is_initialized():
         backend = os.environ.get("A8_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")   # nccl = RCCL on ROCm
         dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world)
     return rank, local, world

@@ -188,7 +188,7 @@ def main():
                           "last_loss": round(float(lv), 5)},
                "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -1,5 +1,6 @@
 """End-to-end GPU parity of the host model (audio8_amd.wav2vec2 / audio8_amd.ctc over the C ABI) against
 the CPU oracle on the same seeded inputs: loss, logits, sampled indices and every parameter gradient."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -464,3 +465,66 @@ def test_batch_onramp_uploads_cropped_batches():
     ramp.submit([np.zeros(10, np.float32)])
     with pytest.raises(RuntimeError):
         ramp.submit([np.zeros(10, np.float32)])
+
+
+_RCCL_REHEARSAL = r"""
+import os, sys, json
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["A8_REPO"])
+from audio8_amd import ops, wav2vec2 as W
+from audio8_amd.trainer import Stepper, init_distributed_from_env
+
+def run(force):
+    os.environ["A8_FORCE_REDUCER"] = "1" if force else "0"
+    torch.manual_seed(3); np.random.seed(3); ops.reset_seed_stream()
+    ops.set_compute_dtype(torch.bfloat16)
+    mdl = W.create_model(num_layers=2).cuda().train()
+    loss_fn = W.create_loss(640, 100)
+    st = Stepper(mdl, lr=1e-3, bucket_mb=8.0)
+    assert st.reducer.enabled == force
+    x = (0.1 * torch.randn(2, 16000, generator=torch.Generator().manual_seed(5))).clamp_(-1, 1).cuda()
+    losses = []
+    for _ in range(3):
+        st.zero_grad()
+        loss = loss_fn(mdl, x)
+        loss.backward()
+        losses.append(loss.item())
+        st.step()
+    torch.cuda.synchronize()
+    nb = len(st.reducer.buckets)
+    flat = st.state.flat_p.clone()
+    st.close()
+    return losses, flat, nb
+
+os.environ["A8_FORCE_REDUCER"] = "1"
+rank, local, world = init_distributed_from_env()          # nccl (= RCCL) process group of one rank
+assert dist.is_initialized() and dist.get_backend() == "nccl" and world == 1
+l1, p1, nb = run(True)
+l0, p0, _ = run(False)
+dist.destroy_process_group()
+print(json.dumps({"with": l1, "without": l0, "buckets": nb, "max_param_diff": float((p1 - p0).abs().max())}))
+"""
+
+
+def test_rccl_exchange_path_on_one_rank(tmp_path):
+    """The data-parallel exchange exactly as N > 1 runs it -- autograd hooks, direct-gradient marks, buckets launched from
+    the compute and weight-gradient streams, `dist.all_reduce(async_op=True)` on the reducer's side stream, finish() --
+    against the real RCCL backend with a process group of ONE rank (A8_FORCE_REDUCER=1; summing over one rank changes
+    nothing): three optimizer steps must reproduce the run without the reducer."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "rehearsal.py"
+    script.write_text(_RCCL_REHEARSAL)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", A8_REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["buckets"] > 3
+    assert all(np.isfinite(out["with"])) and len(out["with"]) == 3
+    # bf16 backward with atomics: the two runs agree to rounding noise, not bit for bit
+    np.testing.assert_allclose(out["with"], out["without"], rtol=2e-2)
+    assert out["max_param_diff"] < 5e-3
