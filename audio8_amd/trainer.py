@@ -195,6 +195,7 @@ class GradReducer:
             for i in bk["members"]:
                 self.bucket_of[i] = b
         self.handles = []
+        self.next_bucket = 0
         self.marked = [False] * len(state.params)
         self.extra_streams = []
         self.compute_stream = None
@@ -212,8 +213,12 @@ class GradReducer:
         self.marked[i] = True
         bk = self.buckets[self.bucket_of[i]]
         bk["pending"] -= 1
-        if bk["pending"] == 0 and not bk.get("launched"):
-            self._launch(bk)
+        # Collectives must be issued in the same order on every rank: buckets go out strictly in index order (the order in
+        # which backward completes them anyway); one whose gradients arrive early waits for its predecessors, one that
+        # never completes (frozen / dropped layers) holds the rest back until finish().
+        while self.next_bucket < len(self.buckets) and self.buckets[self.next_bucket]["pending"] == 0:
+            self._launch(self.buckets[self.next_bucket])
+            self.next_bucket += 1
 
     def _make_hook(self, i):
         def hook(_p):
@@ -258,15 +263,17 @@ class GradReducer:
             bk["launched"] = False
         self.marked = [False] * len(self.state.params)
         self.handles = []
+        self.next_bucket = 0
 
     def finish(self):
         """Issue any bucket whose parameters produced no gradient this step (frozen encoder, audio8/train.py:266-268),
         then make the compute stream wait for the exchange.  Gradients hold the SUM over ranks afterwards."""
         if not self.enabled:
             return
-        for bk in self.buckets:
+        for bk in self.buckets[self.next_bucket:]:       # in index order, like the ones already out
             if not bk.get("launched"):
                 self._launch(bk)
+        self.next_bucket = len(self.buckets)
         for h in self.handles:
             h.wait()
         if self.on_gpu:

@@ -488,21 +488,22 @@ def run(force):
         st.zero_grad()
         loss = loss_fn(mdl, x)
         loss.backward()
+        early = st.reducer.next_bucket if force else 0      # buckets already handed to RCCL when backward returns
         losses.append(loss.item())
         st.step()
     torch.cuda.synchronize()
     nb = len(st.reducer.buckets)
     flat = st.state.flat_p.clone()
     st.close()
-    return losses, flat, nb
+    return losses, flat, (nb, early)
 
 os.environ["A8_FORCE_REDUCER"] = "1"
 rank, local, world = init_distributed_from_env()          # nccl (= RCCL) process group of one rank
 assert dist.is_initialized() and dist.get_backend() == "nccl" and world == 1
-l1, p1, nb = run(True)
+l1, p1, (nb, early) = run(True)
 l0, p0, _ = run(False)
 dist.destroy_process_group()
-print(json.dumps({"with": l1, "without": l0, "buckets": nb, "max_param_diff": float((p1 - p0).abs().max())}))
+print(json.dumps({"with": l1, "without": l0, "buckets": nb, "launched_during_backward": early, "max_param_diff": float((p1 - p0).abs().max())}))
 """
 
 
@@ -524,6 +525,9 @@ def test_rccl_exchange_path_on_one_rank(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["buckets"] > 3
+    # in-order launching must not cost the overlap: backward completes the buckets in index order, so all of them are out
+    # before it returns (nothing is left for finish())
+    assert out["launched_during_backward"] == out["buckets"], out
     assert all(np.isfinite(out["with"])) and len(out["with"]) == 3
     # bf16 backward with atomics: the two runs agree to rounding noise, not bit for bit
     np.testing.assert_allclose(out["with"], out["without"], rtol=2e-2)
