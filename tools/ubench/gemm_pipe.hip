@@ -44,45 +44,52 @@ DEV int xcd_remap(int bid, int nwg) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
-__global__ __launch_bounds__(512, 2) void gemm_pipe(const bf16* __restrict__ A, const bf16* __restrict__ B, bf16* __restrict__ C,
-                                                    int M, int N, int K, int tiles_m, int tiles_n) {
+// EPI 0: C = bf16(acc).  EPI 1 (conv forward): Z = bf16(acc), C = bf16(act(acc)) with a GELU-cost activation.
+// Persistent: block b takes tiles b, b + gridDim.x, ...; the next tile's first two k-tiles are DMA'd before the current
+// tile's stores, so only the epilogue's own instructions are exposed.  lda: row stride of A in elements (conv rows overlap).
+DEV float act(float v) {                                   // ~GELU cost (x * sigmoid(1.702 x)), benchmark only
+    return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554f * v));
+}
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_pipe(const bf16* __restrict__ A, long long lda, const bf16* __restrict__ B,
+                                                    bf16* __restrict__ C, bf16* __restrict__ Z, int M, int N, int K, int tiles_m, int tiles_n) {
     __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6), wr = w >> 2, wc = w & 3;
-    const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    constexpr int GROUP_M = 8;
-    const int tpg = GROUP_M * tiles_n, grp = tile / tpg, first_m = grp * GROUP_M;
-    const int gsz = min(GROUP_M, tiles_m - first_m), tin = tile - grp * tpg;
-    const int m0 = (first_m + tin % gsz) * BM, n0 = (tin / gsz) * BN;
+    const int total = tiles_m * tiles_n;
     const int nk = K / BK;
+    constexpr int GROUP_M = 8;
+    auto tile_origin = [&](int v, int& m0, int& n0) {
+        const int tile = xcd_remap(v, total);
+        const int tpg = GROUP_M * tiles_n, grp = tile / tpg, first_m = grp * GROUP_M;
+        const int gsz = min(GROUP_M, tiles_m - first_m), tin = tile - grp * tpg;
+        m0 = (first_m + tin % gsz) * BM;
+        n0 = (tin / gsz) * BN;
+    };
 
     // LDS-DMA: 32 one-KB pieces (8 rows) per operand per stage, 4 per wave (pieces w, w+8, w+16, w+24: rows 64 apart, so one
     // per-lane pointer per operand and scalar offsets); the XOR swizzle sits on the source address
     const char* a_src;
     const char* b_src;
-    {
-        const int row = 8 * w + (lane >> 3), ch = (lane & 7) ^ (row & 7);
-        a_src = reinterpret_cast<const char*>(A + (long long)(m0 + row) * K) + ch * 16;
-        b_src = reinterpret_cast<const char*>(B + (long long)(n0 + row) * K) + ch * 16;
-    }
-    const long long jstep = 64ll * K * 2;          // bytes between pieces j and j+1 of a wave
+    const int srow = 8 * w + (lane >> 3), sch = (lane & 7) ^ (srow & 7);
+    auto set_src = [&](int m0, int n0) {
+        a_src = reinterpret_cast<const char*>(A + (long long)(m0 + srow) * lda) + sch * 16;
+        b_src = reinterpret_cast<const char*>(B + (long long)(n0 + srow) * K) + sch * 16;
+    };
+    const long long ajstep = 64ll * lda * 2, bjstep = 64ll * K * 2;          // bytes between pieces j and j+1 of a wave
     auto issue = [&](int kt) {
         char* ta = lds + (kt & 1) * STAGE;
         char* tb = ta + TA;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            glds16(a_src + j * jstep, ta + (w + 8 * j) * 1024);
-            glds16(b_src + j * jstep, tb + (w + 8 * j) * 1024);
+            glds16(a_src + j * ajstep, ta + (w + 8 * j) * 1024);
+            glds16(b_src + j * bjstep, tb + (w + 8 * j) * 1024);
         }
         a_src += KROW;
         b_src += KROW;
     };
 
     f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     bf16x8 a0[2][4], a1[2][4], b0[2][2], b1[2][2];
     const int ra = wr * 128, cb = wc * 64;
     auto rd_a = [&](bf16x8 (&f)[2][4], const char* ta, int half) {
@@ -137,25 +144,52 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe(const bf16* __restrict__ A, 
         mma(a1, bx, 1, 0);
         __builtin_amdgcn_sched_barrier(0);
     };
+    int m0, n0;
+    tile_origin(blockIdx.x, m0, n0);
+    set_src(m0, n0);
     issue(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
     if (nk > 1) issue(1);
-    rd_a(a0, lds, 0);
-    rd_b(b0, lds + TA, 0);
-    for (int kt = 0; kt < nk; kt += 2) {
-        step(kt, b0, b1);
-        if (kt + 1 < nk) step(kt + 1, b1, b0);
-    }
-    // epilogue (benchmark-grade): 8-byte stores straight from the accumulators
+    for (int v = blockIdx.x; v < total; v += gridDim.x) {
+        // k-tile 0 of this tile (and k-tile 1) were issued before the previous tile's stores
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + ra + 16 * i + (lane & 15), n = n0 + cb + 16 * j + 4 * (lane >> 4);
-            bf16x4 o = {(bf16)acc[i][j][0], (bf16)acc[i][j][1], (bf16)acc[i][j][2], (bf16)acc[i][j][3]};
-            *reinterpret_cast<bf16x4*>(C + (long long)m * N + n) = o;
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        rd_a(a0, lds, 0);
+        rd_b(b0, lds + TA, 0);
+        for (int kt = 0; kt < nk; kt += 2) {
+            step(kt, b0, b1);
+            if (kt + 1 < nk) step(kt + 1, b1, b0);
         }
+        // every fragment of this tile is in registers and every wave is past the last mid-tile barrier: the ring is free
+        const int cm0 = m0, cn0 = n0;
+        if (v + (int)gridDim.x < total) {
+            tile_origin(v + gridDim.x, m0, n0);
+            set_src(m0, n0);
+            issue(0);
+            if (nk > 1) issue(1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // epilogue (benchmark-grade): 8-byte stores straight from the accumulators
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = cm0 + ra + 16 * i + (lane & 15), n = cn0 + cb + 16 * j + 4 * (lane >> 4);
+                const f32x4 x = acc[i][j];
+                if (EPI == 1) {
+                    bf16x4 z = {(bf16)x[0], (bf16)x[1], (bf16)x[2], (bf16)x[3]};
+                    *reinterpret_cast<bf16x4*>(Z + (long long)m * N + n) = z;
+                    bf16x4 o = {(bf16)act(x[0]), (bf16)act(x[1]), (bf16)act(x[2]), (bf16)act(x[3])};
+                    *reinterpret_cast<bf16x4*>(C + (long long)m * N + n) = o;
+                } else {
+                    bf16x4 o = {(bf16)x[0], (bf16)x[1], (bf16)x[2], (bf16)x[3]};
+                    *reinterpret_cast<bf16x4*>(C + (long long)m * N + n) = o;
+                }
+            }
+    }
 }
 
 __global__ void ref_gemm(const bf16* A, const bf16* B, float* C, int M, int N, int K) {
@@ -173,27 +207,48 @@ __global__ void fill(bf16* p, long long n, uint32_t seed, int integer) {
     }
 }
 
-static void launch(const bf16* A, const bf16* B, bf16* C, int M, int N, int K) {
+template <int EPI>
+static void launch(const bf16* A, long long lda, const bf16* B, bf16* C, bf16* Z, int M, int N, int K, int grid) {
     const int tm = M / BM, tn = N / BN;
-    hipLaunchKernelGGL(gemm_pipe, dim3(tm * tn), dim3(512), 0, 0, A, B, C, M, N, K, tm, tn);
+    if (grid <= 0 || grid > tm * tn) grid = tm * tn;
+    hipLaunchKernelGGL(gemm_pipe<EPI>, dim3(grid), dim3(512), 0, 0, A, lda, B, C, Z, M, N, K, tm, tn);
+}
+
+template <int EPI>
+static void timeit(const char* what, const bf16* A, long long lda, const bf16* B, bf16* C, bf16* Z, int M, int N, int K, int grid) {
+    for (int i = 0; i < 3; ++i) launch<EPI>(A, lda, B, C, Z, M, N, K, grid);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int rnd = 0; rnd < 3; ++rnd) {
+        CK(hipEventRecord(e0));
+        const int it = 10;
+        for (int i = 0; i < it; ++i) launch<EPI>(A, lda, B, C, Z, M, N, K, grid);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms / it < best) best = ms / it;
+    }
+    printf("%-44s %dx%dx%d grid %5d: %.1f us  %.0f TFLOP/s\n", what, M, N, K, grid > 0 ? grid : (M / BM) * (N / BN), best * 1e3, 2.0 * M * N * K / (best * 1e-3) / 1e12);
 }
 
 int main() {
-    {   // exactness on integer-valued operands (all partial sums exact in f32)
-        const int M = 512, N = 768, K = 448;
+    {   // exactness on integer-valued operands (all partial sums exact in f32), through the persistent loop (12 tiles on 5 blocks)
+        const int M = 1024, N = 768, K = 448;
         bf16 *A, *B, *C; float* R;
         CK(hipMalloc(&A, sizeof(bf16) * M * K)); CK(hipMalloc(&B, sizeof(bf16) * N * K)); CK(hipMalloc(&C, sizeof(bf16) * M * N)); CK(hipMalloc(&R, sizeof(float) * M * N));
         hipLaunchKernelGGL(fill, dim3(256), dim3(256), 0, 0, A, (long long)M * K, 1u, 1);
         hipLaunchKernelGGL(fill, dim3(256), dim3(256), 0, 0, B, (long long)N * K, 2u, 1);
-        launch(A, B, C, M, N, K);
         hipLaunchKernelGGL(ref_gemm, dim3((N + 255) / 256, M), dim3(256), 0, 0, A, B, R, M, N, K);
-        CK(hipDeviceSynchronize());
         std::vector<bf16> hc((size_t)M * N); std::vector<float> hr((size_t)M * N);
-        CK(hipMemcpy(hc.data(), C, sizeof(bf16) * M * N, hipMemcpyDeviceToHost)); CK(hipMemcpy(hr.data(), R, sizeof(float) * M * N, hipMemcpyDeviceToHost));
-        long long bad = 0;
-        for (size_t i = 0; i < hc.size(); ++i) if ((float)hc[i] != (float)(bf16)hr[i]) { if (bad < 5) printf("mismatch at %zu: %f vs %f\n", i, (float)hc[i], hr[i]); ++bad; }
-        printf("exactness %dx%dx%d: %lld mismatches\n", M, N, K, bad);
-        if (bad) return 1;
+        for (int grid : {0, 5, 1}) {
+            CK(hipMemset(C, 0xFF, sizeof(bf16) * M * N));
+            launch<0>(A, K, B, C, nullptr, M, N, K, grid);
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(hc.data(), C, sizeof(bf16) * M * N, hipMemcpyDeviceToHost)); CK(hipMemcpy(hr.data(), R, sizeof(float) * M * N, hipMemcpyDeviceToHost));
+            long long bad = 0;
+            for (size_t i = 0; i < hc.size(); ++i) if ((float)hc[i] != (float)(bf16)hr[i]) { if (bad < 5) printf("mismatch at %zu: %f vs %f\n", i, (float)hc[i], hr[i]); ++bad; }
+            printf("exactness %dx%dx%d grid %d: %lld mismatches\n", M, N, K, grid, bad);
+            if (bad) return 1;
+        }
         CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(C)); CK(hipFree(R));
     }
     const int shapes[3][3] = {{4096, 4096, 8192}, {8192, 8192, 8192}, {8192, 4096, 4096}};
@@ -203,17 +258,23 @@ int main() {
         CK(hipMalloc(&A, sizeof(bf16) * (size_t)M * K)); CK(hipMalloc(&B, sizeof(bf16) * (size_t)N * K)); CK(hipMalloc(&C, sizeof(bf16) * (size_t)M * N));
         hipLaunchKernelGGL(fill, dim3(1024), dim3(256), 0, 0, A, (long long)M * K, 3u, 0);
         hipLaunchKernelGGL(fill, dim3(1024), dim3(256), 0, 0, B, (long long)N * K, 4u, 0);
-        for (int i = 0; i < 3; ++i) launch(A, B, C, M, N, K);
-        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-        for (int rnd = 0; rnd < 2; ++rnd) {
-            CK(hipEventRecord(e0));
-            const int it = 20;
-            for (int i = 0; i < it; ++i) launch(A, B, C, M, N, K);
-            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
-            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-            printf("%dx%dx%d random bf16: %.1f us  %.0f TFLOP/s\n", M, N, K, ms * 1e3 / it, 2.0 * M * N * K / (ms / it * 1e-3) / 1e12);
-        }
+        timeit<0>("square, one block per tile", A, K, B, C, nullptr, M, N, K, 0);
+        timeit<0>("square, persistent (256 blocks)", A, K, B, C, nullptr, M, N, K, 256);
         CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(C));
+    }
+    {   // conv layer 1 forward of the pretrain step: rows are overlapping windows (stride 1024 elements, 1536 long)
+        const int M = 781 * 256, N = 512, K = 1536; const long long lda = 1024;
+        bf16 *A, *B, *C, *Z;
+        const size_t na = (size_t)(M - 1) * lda + K;
+        CK(hipMalloc(&A, sizeof(bf16) * na)); CK(hipMalloc(&B, sizeof(bf16) * (size_t)N * K)); CK(hipMalloc(&C, sizeof(bf16) * (size_t)M * N)); CK(hipMalloc(&Z, sizeof(bf16) * (size_t)M * N));
+        hipLaunchKernelGGL(fill, dim3(1024), dim3(256), 0, 0, A, (long long)na, 5u, 0);
+        hipLaunchKernelGGL(fill, dim3(1024), dim3(256), 0, 0, B, (long long)N * K, 6u, 0);
+        timeit<0>("conv1 shape, plain, one block per tile", A, lda, B, C, Z, M, N, K, 0);
+        timeit<0>("conv1 shape, plain, persistent 256", A, lda, B, C, Z, M, N, K, 256);
+        timeit<1>("conv1 shape, act + z, one block per tile", A, lda, B, C, Z, M, N, K, 0);
+        timeit<1>("conv1 shape, act + z, persistent 256", A, lda, B, C, Z, M, N, K, 256);
+        timeit<1>("conv1 shape, act + z, persistent 512", A, lda, B, C, Z, M, N, K, 512);
+        CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(C)); CK(hipFree(Z));
     }
     return 0;
 }
