@@ -401,127 +401,168 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
     gemm_epilogue<T, MI, NWM, NP>(g, acc, lds, w, m0, n0, lane);
 }
 
-// ---- register-pipelined main loop for large NT problems (both operands K-contiguous, 16-bit):
-// 256x128 tile, 8 waves of 64x64 (0.5 KB of LDS fragment reads per MFMA instead of 0.75 at 32x64), 3-stage LDS-DMA
-// ring (DMA two k-tiles ahead), one block per CU.  With only 2 waves per SIMD the LDS latency is hidden inside the wave:
-// the fragments of k-tile kb+1 are read into a second register set while the MFMAs of k-tile kb run from the first
-// (the k-loop is unrolled by two so the sets swap roles without moves).
+// ---- pipelined 256 x 256 main loop for large NT problems with N % 256 == 0 and K % 64 == 0 (the conv layers: N = 512):
+// 8 waves of 128 x 64 (0.375 KB of fragment reads per MFMA instead of 0.75, half the staged bytes per FLOP), one block per CU.
+// Per k-tile t (LDS buffer b = t & 1), per wave, entering with the first A / B quarters of tile t in registers:
+//     read B1(t)                 | MFMA C00 += A0 B0
+//     read A1(t)                 | MFMA C01 += A0 B1
+//     wait: A1 in registers, this wave's DMA pieces of tile t+1 landed;   s_barrier
+//        -> nobody reads buffer b any more (all four operand quarters are in registers); tile t+1 is visible in buffer b^1
+//     DMA tile t+2 -> buffer b   | MFMA C11 += A1 B1
+//     read A0(t+1), B0(t+1) from b^1 (B0 into the registers B1 just vacated: the two B register sets swap roles every tile)
+//                                | MFMA C10 += A1 B0
+// so a tile's DMA has a whole k-tile to land, no wave waits on an LDS read it has just issued, and the k-tile boundary
+// has no barrier (validated standalone in tools/ubench/gemm_pipe.hip).  Rows beyond M are clamped to row M-1 on the way in
+// (their results are never stored).  Epilogue: NONE / GELU + zout / x gelu'(zin) / + zin, 16-bit outputs, 8-byte stores.
 template <typename T>
-A8_DEV void gemm_body_pf(const GemmArgs& g, const int bid) {
+__global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs g) {
     static_assert(sizeof(T) == 2, "16-bit operands");
-    typedef StageTile<T, 2> ST;
-    typedef KcGeom<2> G;
     typedef Mma<T> MM;
-    constexpr int BM = 256, BK = ST::BK, SZ = 2, EPC = 8, NWM = 4, NW = 8, MI = 4, NST = 3;
-    constexpr int TA = BM * G::KROW, TB = 128 * G::KROW, STAGE = TA + TB;
-    constexpr int PA = TA / 1024 / NW, PB = TB / 1024 / NW;
-    __shared__ __attribute__((aligned(1024))) char lds[NST * STAGE];
-    static_assert(NST * STAGE >= NW * 16 * MI * 64 * 4, "epilogue staging");
-
+    constexpr int KROW = 128, TA = 256 * KROW, TB = 256 * KROW, STAGE = TA + TB, SZ = 2;
+    __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
     const int t = threadIdx.x, lane = t & 63;
-    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = w >> 1, wn = w & 1;
-    const int split = bid / (g.tiles_m * g.tiles_n);
-    const int tile = bid - split * (g.tiles_m * g.tiles_n);
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6), wr = w >> 2, wc = w & 3;
+    const int tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
     constexpr int GROUP_M = 8;
-    const int tpg = GROUP_M * g.tiles_n;
-    const int grp = tile / tpg, first_m = grp * GROUP_M;
-    const int gsz = min(GROUP_M, g.tiles_m - first_m);
-    const int tin = tile - grp * tpg;
-    const int m0 = (first_m + tin % gsz) * BM, n0 = (tin / gsz) * 128;
-    const int kbeg = split * g.kchunk;
-    const int kend = min(g.K, kbeg + g.kchunk);
-    const int nkb = (kend - kbeg + BK - 1) / BK;
-    const char* zero = reinterpret_cast<const char*>(g_zero16);
+    const int tpg = GROUP_M * g.tiles_n, grp = tile / tpg, first_m = grp * GROUP_M;
+    const int gsz = min(GROUP_M, g.tiles_m - first_m), tin = tile - grp * tpg;
+    const int m0 = (first_m + tin % gsz) * 256, n0 = (tin / gsz) * 256;
+    const int nk = g.K / 64;
 
-    const char* a_ptr[PA]; int a_k[PA];
-    const char* b_ptr[PB]; int b_k[PB];
+    // LDS-DMA: 32 one-KB pieces (8 rows) per operand per stage, 4 per wave (rows 64 apart); XOR swizzle on the source address.
+    // A rows go through the row remap (conv windows, utterance boundaries): one 32-bit byte offset per piece and lane.
+    const int srow = 8 * w + (lane >> 3), sch = (lane & 7) ^ (srow & 7);
+    unsigned a_off[4];
 #pragma unroll
-    for (int j = 0; j < PA; ++j) {
-        const int p = w + NW * j, rl = G::RPP * p + lane / G::SPR, row = m0 + rl;
-        a_k[j] = (((lane % G::SPR) ^ G::swz(rl)) & (G::SPR - 1)) * EPC;
-        a_ptr[j] = row < g.M ? g.A.p + outer_off(g.A, row) * SZ : nullptr;
+    for (int j = 0; j < 4; ++j) {
+        const int row = min(m0 + srow + 64 * j, g.M - 1);
+        a_off[j] = (unsigned)(outer_off(g.A, row) * SZ + sch * 16);
     }
-#pragma unroll
-    for (int j = 0; j < PB; ++j) {
-        const int p = w + NW * j, rl = G::RPP * p + lane / G::SPR, row = n0 + rl;
-        b_k[j] = (((lane % G::SPR) ^ G::swz(rl)) & (G::SPR - 1)) * EPC;
-        b_ptr[j] = row < g.N ? g.B.p + outer_off(g.B, row) * SZ : nullptr;
-    }
-    auto issue = [&](int kb) {
-        char* ta = lds + (kb % NST) * STAGE;
+    const unsigned b_off = (unsigned)((long long)(n0 + srow) * g.B.ld * SZ + sch * 16);
+    const unsigned bjstep = (unsigned)(64 * g.B.ld * SZ);
+    unsigned koff = 0;
+    auto issue = [&](int kt) {
+        char* ta = lds + (kt & 1) * STAGE;
         char* tb = ta + TA;
-        const int k0 = kbeg + kb * BK;
 #pragma unroll
-        for (int j = 0; j < PA; ++j) {
-            const int k = k0 + a_k[j];
-            glds16((a_ptr[j] && k + EPC <= kend) ? a_ptr[j] + (long long)k * SZ : zero, ta + (w + NW * j) * 1024);
+        for (int j = 0; j < 4; ++j) {
+            glds16(g.A.p + (a_off[j] + koff), ta + (w + 8 * j) * 1024);
+            glds16(g.B.p + (b_off + j * bjstep + koff), tb + (w + 8 * j) * 1024);
         }
-#pragma unroll
-        for (int j = 0; j < PB; ++j) {
-            const int k = k0 + b_k[j];
-            glds16((b_ptr[j] && k + EPC <= kend) ? b_ptr[j] + (long long)k * SZ : zero, tb + (w + NW * j) * 1024);
-        }
+        koff += KROW;
     };
-    struct Frags { typename MM::Frag a[ST::KSTEPS][MI], b[ST::KSTEPS][4]; };
-    auto read_frags = [&](int kb, Frags& f) {
-        const char* ta = lds + (kb % NST) * STAGE;
-        const char* tb = ta + TA;
-#pragma unroll
-        for (int ks = 0; ks < ST::KSTEPS; ++ks) {
-#pragma unroll
-            for (int i = 0; i < MI; ++i) f.a[ks][i] = ST::kc_frag(ta, wm * (16 * MI) + 16 * i, ks, lane);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) f.b[ks][i] = ST::kc_frag(tb, wn * 64 + 16 * i, ks, lane);
-        }
+    auto frag = [&](const char* tl, int rb, int ks) {          // 16 rows x 32 k: lane & 15 = row, lane >> 4 = 16-byte chunk of the k-step
+        const int row = rb + (lane & 15);
+        return *reinterpret_cast<const typename MM::Frag*>(tl + row * KROW + (((ks * 4 + (lane >> 4)) ^ (row & 7)) << 4));
     };
 
-    f32x4 acc[MI][4];
+    f32x4 acc[8][4];
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    issue(0); issue(1); issue(2);
-    static_assert(PA + PB == 6, "the s_waitcnt immediates below encode 6 and 12 outstanding DMA pieces");
-    // (the builtin, not inline asm: the compiler's own wait-count bookkeeping must see these waits, or it re-inserts a
-    //  full lgkmcnt(0) in front of the MFMAs and serialises the fragment prefetch)
-    __builtin_amdgcn_s_waitcnt(0x0F7C);                  // vmcnt(12): k-tile 0 has landed
-    __builtin_amdgcn_s_barrier();
-    Frags f0, f1;
-    read_frags(0, f0);
-    __builtin_amdgcn_sched_barrier(0);
-    // one k-tile: MFMAs from `cur` while the next k-tile's fragments stream into `nxt`
-    auto step = [&](int kb, Frags& cur, Frags& nxt) {
-        // k-tile kb+1 has landed once at most one DMA round (k-tile kb+2) is outstanding; lgkmcnt(0): this wave's reads
-        // of the stage about to be refilled are complete before it signals the barrier
-        __builtin_amdgcn_s_waitcnt(0x0076);              // vmcnt(6) lgkmcnt(0)
-        __builtin_amdgcn_s_barrier();
-        issue(kb + 3);                                   // refills the stage read one iteration ago; beyond K: zero page
-        read_frags(kb + 1, nxt);
-        // pin the order: the compiler otherwise sinks these reads to their first use (the next step) and hoists that
-        // step's MFMAs over its barrier, which turns the pipeline back into read -> wait -> MFMA
+    typename MM::Frag a0[2][4], a1[2][4], b0[2][2], b1[2][2];
+    const int ra = wr * 128, cb = wc * 64;
+    auto rd_a = [&](typename MM::Frag (&f)[2][4], const char* ta, int half) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) f[ks][i] = frag(ta, ra + 64 * half + 16 * i, ks);
+    };
+    auto rd_b = [&](typename MM::Frag (&f)[2][2], const char* tb, int half) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) f[ks][i] = frag(tb, cb + 32 * half + 16 * i, ks);
+    };
+    // swapped operands: accumulator register r <-> 4 consecutive n, lane & 15 <-> m
+    auto mma = [&](const typename MM::Frag (&fa)[2][4], const typename MM::Frag (&fb)[2][2], int ah, int bh) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[4 * ah + i][2 * bh + j] = MM::mma(fb[ks][j], fa[ks][i], acc[4 * ah + i][2 * bh + j]);
+    };
+    auto step = [&](int kt, typename MM::Frag (&bx)[2][2], typename MM::Frag (&by)[2][2]) {
+        const char* ta = lds + (kt & 1) * STAGE;
+        const char* tb = ta + TA;
+        const char* na = lds + ((kt + 1) & 1) * STAGE;
+        const char* nb = na + TA;
+        rd_b(by, tb, 1);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ks = 0; ks < ST::KSTEPS; ++ks)
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = MM::mma(cur.b[ks][j], cur.a[ks][i], acc[i][j]);
+        mma(a0, bx, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        rd_a(a1, ta, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a0, by, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) issue(kt + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a1, by, 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) {
+            rd_a(a0, na, 0);
+            rd_b(by, nb, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a1, bx, 1, 0);
         __builtin_amdgcn_sched_barrier(0);
     };
-    for (int kb = 0; kb < nkb; kb += 2) {
-        step(kb, f0, f1);
-        if (kb + 1 < nkb) step(kb + 1, f1, f0);
+    issue(0);
+    if (nk > 1) issue(1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8) : "memory");       // k-tile 0 (the 8 older of this wave's 16 DMAs)
+    if (nk <= 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    rd_a(a0, lds, 0);
+    rd_b(b0, lds + TA, 0);
+    for (int kt = 0; kt < nk; kt += 2) {
+        step(kt, b0, b1);
+        if (kt + 1 < nk) step(kt + 1, b1, b0);
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __syncthreads();
-    gemm_epilogue<T, MI, NWM>(g, acc, lds, w, m0, n0, lane);
-}
 
-template <typename T>
-__global__ __launch_bounds__(512, 2) void gemm_pf_kernel(const GemmArgs g) {
-    gemm_body_pf<T>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n * g.nsplit));
+    // ---- epilogue: register r of acc[i][j] is column 16 j + 4 (lane >> 4) + r of row 16 i + (lane & 15)
+    typedef T T4 __attribute__((ext_vector_type(4)));
+    auto zrow = [&](int m) -> long long { return g.z_rpb ? (m / g.z_rpb) * g.z_bs + (m % g.z_rpb) * g.ldz : (long long)m * g.ldz; };
+    const int li = lane & 15, c4 = 4 * (lane >> 4);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + ra + 16 * i + li;
+        if (m >= g.M) continue;
+        const long long crow = g.c_rpb ? (m / g.c_rpb) * g.c_bs + (m % g.c_rpb) * g.ldc : (long long)m * g.ldc;
+        const long long zr = (g.zout || g.zin) ? zrow(m) : 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + cb + 16 * j + c4;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * g.alpha;
+            if (g.zout) {
+                T4 zv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) zv[e] = from_f<T>(v[e]);
+                *reinterpret_cast<T4*>(reinterpret_cast<T*>(g.zout) + zr + n) = zv;
+            }
+            if (g.act == A8_ACT_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+            } else if (g.act == A8_ACT_MUL_GELU_GRAD) {
+                const T4 zz = *reinterpret_cast<const T4*>(reinterpret_cast<const T*>(g.zin) + zr + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(to_f(zz[e]));
+            } else if (g.act == A8_ACT_ADD) {
+                const T4 zz = *reinterpret_cast<const T4*>(reinterpret_cast<const T*>(g.zin) + zr + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += to_f(zz[e]);
+            }
+            T4 ov;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ov[e] = from_f<T>(v[e]);
+            *reinterpret_cast<T4*>(reinterpret_cast<T*>(g.C) + crow + n) = ov;
+        }
+    }
 }
 
 template <typename T, bool AKS, bool BKS, int KB, int NST, int NWM>
@@ -625,12 +666,19 @@ extern "C" int a8_gemm(const a8_gemm_desc* d, void* stream) {
     if (int e = build_args(d, g, &grid)) return e;
     if (d->M == 0) return A8_OK;
     hipStream_t s = (hipStream_t)stream;
-    // large NT problems: the register-pipelined 256x128 kernel (a8_set_tuning key 5 = minimum number of 256x128 tiles; 0 = off)
-    if (d->dtype == A8_BF16 && d->layout == A8_GEMM_NT && g_a8_tuning[5] > 0 && g_variant == 5) {
-        const int tm = cdiv(d->M, 256);
-        if ((long long)tm * g.tiles_n >= g_a8_tuning[5]) {
-            g.tiles_m = tm;
-            hipLaunchKernelGGL(gemm_pf_kernel<bf16>, dim3(tm * g.tiles_n * g.nsplit), dim3(512), 0, s, g);
+    // large NT problems whose N is a multiple of 256 (the conv layers): the pipelined 256 x 256 kernel
+    // (a8_set_tuning key 5 = minimum number of 256 x 256 tiles; 0 = off)
+    if (d->dtype == A8_BF16 && d->layout == A8_GEMM_NT && g_a8_tuning[5] > 0 && g_variant == 5 && d->N % 256 == 0 && d->K % 64 == 0 &&
+        d->K >= 64 && !d->out_f32 && !d->bias && !d->colsum && g.nsplit == 1 && !g.atomic && d->ldc % 4 == 0 && (d->ldz % 4 == 0) &&
+        ((uintptr_t)d->C % 8) == 0) {
+        const int tm = cdiv(d->M, 256), tn = d->N / 256;
+        // 32-bit byte offsets into A and B
+        const long long a_span = ((d->a_rpb ? (long long)((d->M - 1) / d->a_rpb) * d->a_bs + (long long)((d->M - 1) % d->a_rpb) * d->lda
+                                            : (long long)(d->M - 1) * d->lda) + d->K) * 2;
+        const long long b_span = ((long long)(d->N - 1) * d->ldb + d->K) * 2;
+        if ((long long)tm * tn >= g_a8_tuning[5] && a_span < (1ll << 32) && b_span < (1ll << 32)) {
+            g.tiles_m = tm; g.tiles_n = tn;
+            hipLaunchKernelGGL(gemm_p256_kernel<bf16>, dim3(tm * tn), dim3(512), 0, s, g);
             return a8_check_launch("a8_gemm");
         }
     }

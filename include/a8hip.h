@@ -57,7 +57,7 @@ int a8_gemm(const a8_gemm_desc* d, void* stream);
 int a8_gemm_grouped(const a8_gemm_desc* descs, int n, void* stream);
 /* developer tuning knobs, never needed for correctness (defaults are the measured best): key 0 GEMM stage geometry
  * variant; 1 LayerNorm-backward geometry (waves*100 + rows per wave); 2..4 attention fwd / dK,dV / dQ geometry (waves*10 +
- * 16-row groups per wave); 5 minimum tile count for the experimental register-pipelined 256x128 NT GEMM (0 = off);
+ * 16-row groups per wave); 5 minimum number of 256x256 tiles for the experimental pipelined NT GEMM (N % 256 == 0, K % 64 == 0, no bias; 0 = off);
  * 6 positional-conv weight-gradient loop splits; 7 experimental 160-row NT GEMM tiles for 257..512-tile problems (0 = off,
  * 2..4 = LDS ring depth) */
 int a8_set_tuning(int key, int value);

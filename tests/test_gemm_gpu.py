@@ -225,9 +225,10 @@ def test_gemm_160_row_tiles_match_default(depth):
         torch.testing.assert_close(c0, c1, rtol=1e-4, atol=1e-2)       # (column sums combine in a different block order)
 
 
-def test_gemm_register_pipelined_kernel_matches_default():
-    """The 256x128 register-pipelined NT kernel (a8_set_tuning key 5) walks K in the same order as the default kernel:
-    outputs must be bit-identical across shapes with M/N/K tails, the conv row remap and every epilogue."""
+def test_gemm_pipelined_256_kernel_matches_default():
+    """The pipelined 256 x 256 NT kernel (a8_set_tuning key 5; N % 256 == 0, K % 64 == 0, no bias / column sums) walks K in
+    the same order as the default kernel: outputs must be bit-identical across M tails, single and odd k-tile counts, the
+    conv row remaps on A, C and z, and each epilogue it carries; ineligible problems must fall through to the default."""
     from audio8_amd import kernels as Kn, _lib as L
     dev, bf = "cuda", torch.bfloat16
 
@@ -245,29 +246,44 @@ def test_gemm_register_pipelined_kernel_matches_default():
         for r, g_ in zip(ref, got):
             assert torch.equal(r, g_), what
 
-    for (M, N, K) in [(781, 768, 512), (1000, 264, 72), (256, 128, 64), (300, 136, 2056), (6248, 768, 768)]:
+    for (M, N, K) in [(781, 768, 512), (256, 256, 64), (300, 512, 2048), (6248, 768, 768), (1000, 256, 192), (33, 512, 320),
+                      (1000, 264, 72), (300, 136, 2056)]:                  # the last two are not eligible
         A, B = _mk((M, K), bf, 1).to(dev), _mk((N, K), bf, 2).to(dev)
         same(*both(lambda: (Kn.gemm(L.NT, A, B, M, N, K),)), ("plain", M, N, K))
     M, N, K = 6248, 3072, 768
     A, B = _mk((M, K), bf, 3).to(dev), _mk((N, K), bf, 4).to(dev)
-    bias, z = torch.randn(N, device=dev), _mk((M, N), bf, 5).to(dev)
+    z = _mk((M, N), bf, 5).to(dev)
 
     def gelu_zout():
         zo = torch.empty(M, N, device=dev, dtype=bf)
-        return Kn.gemm(L.NT, A, B, M, N, K, bias=bias, act=L.ACT_GELU, zout=zo), zo
+        return Kn.gemm(L.NT, A, B, M, N, K, act=L.ACT_GELU, zout=zo, alpha=0.125), zo
     same(*both(gelu_zout), "gelu+zout")
-
-    def ggrad_colsum():
-        cs = torch.zeros(N, device=dev)
-        return Kn.gemm(L.NT, A, B, M, N, K, act=L.ACT_MUL_GELU_GRAD, zin=z, colsum=cs), cs
-    ref, got = both(ggrad_colsum)
-    assert torch.equal(ref[0], got[0])
-    np.testing.assert_allclose(got[1].cpu().numpy(), ref[1].cpu().numpy(), rtol=1e-4, atol=1e-2)       # atomic order differs
+    same(*both(lambda: (Kn.gemm(L.NT, A, B, M, N, K, act=L.ACT_MUL_GELU_GRAD, zin=z),)), "x gelu'(z)")
     same(*both(lambda: (Kn.gemm(L.NT, A, B, M, N, K, act=L.ACT_ADD, zin=z),)), "add")
-    same(*both(lambda: (Kn.gemm(L.NT, A, B, M, N, K, out_dtype=torch.float32),)), "f32 out")
-    # conv-as-GEMM: overlapping rows of a channels-last activation (k = 3, stride 2), row remap on A and C
-    Bn, Lin, Cc = 2, 1001, 512
+    bias = torch.randn(N, device=dev)
+    same(*both(lambda: (Kn.gemm(L.NT, A, B, M, N, K, bias=bias),)), "bias (falls through)")
+    same(*both(lambda: (Kn.gemm(L.NT, A, B, M, N, K, out_dtype=torch.float32),)), "f32 out (falls through)")
+    # conv forward as a GEMM: overlapping rows of a channels-last activation (k = 3, stride 2), utterance boundaries inside tiles
+    Bn, Lin, Cc = 3, 1001, 512
     Lout = (Lin - 3) // 2 + 1
     x = _mk((Bn * Lin * Cc,), bf, 6).to(dev)
     Wc = _mk((512, 3 * Cc), bf, 7).to(dev)
-    same(*both(lambda: (Kn.gemm(L.NT, x, Wc, Bn * Lout, 512, 3 * Cc, lda=2 * Cc, a_rpb=Lout, a_bs=Lin * Cc),)), "conv remap")
+
+    def conv_fwd():
+        zo = torch.empty(Bn * Lout, 512, device=dev, dtype=bf)
+        return Kn.gemm(L.NT, x, Wc, Bn * Lout, 512, 3 * Cc, lda=2 * Cc, a_rpb=Lout, a_bs=Lin * Cc, act=L.ACT_GELU, zout=zo), zo
+    same(*both(conv_fwd), "conv forward remap")
+    # conv data gradient, even positions: rows [dz[t-1] | dz[t]] of a zero-padded dz, output and z rows remapped into dx
+    co, cin, npad = 512, 512, 1
+    dzrows, prow = Lout + 2, 2 * Lout + 1 + 2 * npad
+    dz = _mk((Bn * dzrows, co), bf, 8).to(dev)
+    b_even = _mk((cin, 2 * co), bf, 9).to(dev)
+    zprev = _mk((Bn * (2 * Lout + 1), cin), bf, 10).to(dev)
+
+    def conv_dgrad_even():
+        dx = torch.zeros(Bn * prow, cin, device=dev, dtype=bf)
+        Kn.gemm(L.NT, dz, b_even, Bn * (Lout + 1), cin, 2 * co, out=dx, lda=co, a_rpb=Lout + 1, a_bs=dzrows * co,
+                ldc=2 * cin, c_off=npad * cin, c_rpb=Lout + 1, c_bs=prow * cin, act=L.ACT_MUL_GELU_GRAD,
+                zin=zprev, ldz=2 * cin, z_rpb=Lout + 1, z_bs=(2 * Lout + 1) * cin)
+        return (dx,)
+    same(*both(conv_dgrad_even), "conv dgrad remap")
