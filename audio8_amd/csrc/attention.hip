@@ -189,6 +189,7 @@ struct AttnP {
     const char *q, *k, *v, *o, *dout;
     char *out, *dq, *dk, *dv;
     float *lse, *delta;
+    float* dbias;                  // optional f32 [3][H*64] += column sums of dq | dk | dv (the q/k/v bias gradients)
     const uint8_t* keymask;
     int B, T, H;
     long long ld_qkv, ld_o, ld_d;
@@ -217,6 +218,34 @@ A8_DEV void block_coords(int nblk, int nbh, int& blk, int& bh) {
     } else {
         bh = L / nblk;
         blk = L % nblk;
+    }
+}
+
+// out[c] += scale * sum over the block's valid rows of acc[.][c]: acc[j][db][r] is column 16 db + 4 (lane >> 4) + r of the row
+// (lane & 15) of group j.  Rows reduce by shuffles inside each 16-lane group, waves through `red` ([NW][64] floats of free LDS),
+// then one atomic per column per block.  Call with every thread of the block (it synchronises).
+template <int G, int NW> A8_DEV void block_colsum(const f32x4 (&acc)[G][4], const bool (&valid)[G], float scale, float* __restrict__ out,
+                                                  float* red, int wv, int lane) {
+    __syncthreads();                                   // the tile buffers `red` aliases are no longer read
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = 0.f;
+#pragma unroll
+            for (int j = 0; j < G; ++j) v += valid[j] ? acc[j][db][r] : 0.f;
+            v += __shfl_xor(v, 1, 64);
+            v += __shfl_xor(v, 2, 64);
+            v += __shfl_xor(v, 4, 64);
+            v += __shfl_xor(v, 8, 64);
+            if ((lane & 15) == 0) red[wv * 64 + 16 * db + 4 * (lane >> 4) + r] = v;
+        }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) t += red[q * 64 + threadIdx.x];
+        atomicAdd(out + threadIdx.x, t * scale);
     }
 }
 
@@ -486,6 +515,15 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kv_kernel(const AttnP P) {
                 store4<T>(dvp + 16 * db, dv[j][db][0] * P.pscale, dv[j][db][1] * P.pscale, dv[j][db][2] * P.pscale, dv[j][db][3] * P.pscale);
             }
         }
+    if (P.dbias) {                                     // block-uniform: k and v bias gradients ride on this kernel
+        bool ok[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j) ok[j] = key[j] < P.T;
+        float* red = reinterpret_cast<float*>(lds);
+        const int d = P.H * DH;
+        block_colsum<G, NW>(dk, ok, P.dscale, P.dbias + d + h * DH, red, wv, lane);
+        block_colsum<G, NW>(dv, ok, P.pscale, P.dbias + 2 * d + h * DH, red, wv, lane);
+    }
 }
 
 // ================================================================== backward B: dQ (query block stationary)
@@ -573,6 +611,12 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_q_kernel(const AttnP P) {
 #pragma unroll
             for (int db = 0; db < 4; ++db) store4<T>(dqp + 16 * db, dq[j][db][0] * P.dscale, dq[j][db][1] * P.dscale, dq[j][db][2] * P.dscale, dq[j][db][3] * P.dscale);
         }
+    if (P.dbias) {                                     // block-uniform: the q bias gradient rides on this kernel
+        bool ok[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j) ok[j] = qi[j] < P.T;
+        block_colsum<G, NW>(dq, ok, P.dscale, P.dbias + h * DH, reinterpret_cast<float*>(lds), wv, lane);
+    }
 }
 
 void set_softmax_params(AttnP& P, float scale, float p, uint32_t seed) {
@@ -629,12 +673,12 @@ extern "C" int a8_attn_fwd(int dtype, const void* q, const void* k, const void* 
 }
 
 extern "C" int a8_attn_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
-                           const uint8_t* keymask, void* dq, void* dk, void* dv, float* delta, int B, int T_, int H, int64_t ld_qkv,
+                           const uint8_t* keymask, void* dq, void* dk, void* dv, float* delta, float* dbias, int B, int T_, int H, int64_t ld_qkv,
                            int64_t ld_o, int64_t ld_dqkv, float scale, float p, uint32_t seed, void* stream) {
     if (int e = check_common("a8_attn_bwd", dtype, B, T_, H, ld_qkv, ld_o, p)) return e;
     AttnP P = {};
     P.q = (const char*)q; P.k = (const char*)k; P.v = (const char*)v; P.o = (const char*)o; P.dout = (const char*)dout;
-    P.lse = (float*)lse; P.delta = delta; P.keymask = keymask;
+    P.lse = (float*)lse; P.delta = delta; P.dbias = dbias; P.keymask = keymask;
     P.dq = (char*)dq; P.dk = (char*)dk; P.dv = (char*)dv;
     P.B = B; P.T = T_; P.H = H; P.ld_qkv = ld_qkv; P.ld_o = ld_o; P.ld_d = ld_dqkv;
     set_softmax_params(P, scale, p, seed);

@@ -273,15 +273,16 @@ def attn_fwd(q, k, v, B, T, H, ld_qkv, scale, keymask=None, p=0.0, seed=0):
     return o, lse
 
 
-def attn_bwd(q, k, v, o, dout, lse, B, T, H, ld_qkv, scale, keymask=None, p=0.0, seed=0, dqkv=None):
-    """Returns dq, dk, dv as column slices of one [B*T, 3*H*64] buffer (so the q/k/v weight-gradient GEMMs read them in place)."""
+def attn_bwd(q, k, v, o, dout, lse, B, T, H, ld_qkv, scale, keymask=None, p=0.0, seed=0, dqkv=None, dbias=None):
+    """Returns dq, dk, dv as column slices of one [B*T, 3*H*64] buffer (so the q/k/v weight-gradient GEMMs read them in place).
+    dbias (optional f32 [3*H*64]) += their column sums: the q/k/v bias gradients, accumulated by the backward kernels."""
     d = H * 64
     if dqkv is None:
         dqkv = torch.empty((B * T, 3 * d), device=q.device, dtype=q.dtype)
     delta = torch.empty((B, H, T), device=q.device, dtype=torch.float32)
     dq, dk, dv = dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:]
     L.check(L.lib().a8_attn_bwd(L.dt(q), L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), L.ptr(_c(dout)), L.ptr(lse), L.ptr(keymask),
-                                L.ptr(dq), L.ptr(dk), L.ptr(dv), L.ptr(delta), B, T, H, int(ld_qkv), int(d), int(3 * d),
+                                L.ptr(dq), L.ptr(dk), L.ptr(dv), L.ptr(delta), L.ptr(dbias), B, T, H, int(ld_qkv), int(d), int(3 * d),
                                 _f(scale), _f(p), _u32(seed), L.stream()), "a8_attn_bwd")
     return dq, dk, dv, dqkv
 

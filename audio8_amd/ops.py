@@ -567,6 +567,12 @@ class PosConvFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------ transformer encoder layer (post-LN)
+# q/k/v bias gradients: a column-sum pass over dqkv (default), or accumulated by the attention backward kernels themselves
+# (a8_attn_bwd's dbias: block-level column sums, one atomic per column per block).  Same-box A/B: 13.67-13.75 ms fused vs
+# 13.64-13.69: the extra barriers and 2.4e5 atomics cost a little more than the 12 small passes they replace.
+ATTN_BIAS_FUSED = False
+
+
 class EncoderLayerFn(torch.autograd.Function):
     """One eight_mile TransformerEncoder with layer_norms_after=True:
         h = W_O attn(W_Q x, W_K x, W_V x);  x1 = ln2(x + drop(h));  x2 = ln1(x1 + drop(W_2 gelu(W_1 x1)))
@@ -668,11 +674,14 @@ class EncoderLayerFn(torch.autograd.Function):
         dwo = acc_wgrad_grouped(wg, wo, dao, o, d, d, M)
         do = _dgrad(dao, wo_c, wo_t, M, d, d)
         # attention core
-        _, _, _, dqkv = K.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, do, lse, B, T, H, 3 * d, 1.0 / math.sqrt(d // H),
-                                   keymask, p, seed_a)
         tw, tb = [_target(w) for w in (wq, wk, wv)], [_target(b) for b in (bq, bk, bv)]
-        if all(t is not None for t in tw + tb) and _adjacent(*tw) and _adjacent(*tb):
-            colsum(dqkv, _span3(tb[0], (3 * d,)))
+        direct_qkv = all(t is not None for t in tw + tb) and _adjacent(*tw) and _adjacent(*tb)
+        # the q / k / v bias gradients (column sums of dqkv) are accumulated by the attention backward kernels themselves
+        _, _, _, dqkv = K.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, do, lse, B, T, H, 3 * d, 1.0 / math.sqrt(d // H),
+                                   keymask, p, seed_a, dbias=_span3(tb[0], (3 * d,)) if (direct_qkv and ATTN_BIAS_FUSED) else None)
+        if direct_qkv:
+            if not ATTN_BIAS_FUSED:
+                colsum(dqkv, _span3(tb[0], (3 * d,)))
             _ready(bq, bk, bv)
             wspan = _span3(tw[0], (3 * d, d))
             if wg is not None:

@@ -100,6 +100,7 @@ def main():
     stepper = Stepper(model, lr=2.0e-4, weight_decay=1.0e-2, clip=1.0, bucket_mb=args.bucket_mb,
                       wgrad_side_stream=os.environ.get("A8_SIDE_WGRAD", "1") != "0")
     ops.GROUP_WGRAD = os.environ.get("A8_GROUP_WGRAD", "1") != "0"
+    ops.ATTN_BIAS_FUSED = os.environ.get("A8_ATTN_BIAS_FUSED", "0") != "0"
     prefetch = os.environ.get("A8_PREFETCH_DRAWS", "1") != "0"
     for kv in filter(None, os.environ.get("A8_TUNE", "").split(",")):       # developer knobs, e.g. A8_TUNE=5=0,1=403
         k, v = kv.split("=")

@@ -156,9 +156,11 @@ int a8_gelu_bwd_bias(int dtype, const void* dy, const void* z, void* dz, float* 
  * dropout on the attention probabilities with keep-prob 1-p (p = 0: off).  lse f32 [B,H,T] saved for backward. */
 int a8_attn_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* keymask,
                 int B, int T, int H, int64_t ld_qkv, int64_t ld_o, float scale, float p, uint32_t seed, void* stream);
-/* delta is scratch f32 [B,H,T] (rowsum(dO * O): written by the dQ kernel for its own rows, read by the dK/dV kernel) */
+/* delta is scratch f32 [B,H,T] (rowsum(dO * O): written by the dQ kernel for its own rows, read by the dK/dV kernel).
+ * dbias (optional, f32 [3][H*64]) += column sums of dq | dk | dv: the gradients of the q / k / v projection biases
+ * (eight_mile MultiHeadedAttention w_Q/w_K/w_V), one atomic per column per block -- no separate pass over dqkv. */
 int a8_attn_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
-                const uint8_t* keymask, void* dq, void* dk, void* dv, float* delta, int B, int T, int H, int64_t ld_qkv,
+                const uint8_t* keymask, void* dq, void* dk, void* dv, float* delta, float* dbias, int B, int T, int H, int64_t ld_qkv,
                 int64_t ld_o, int64_t ld_dqkv, float scale, float p, uint32_t seed, void* stream);
 
 /* ---- Gumbel-softmax product quantiser (GumbelVectorQuantizer.forward audio8/wav2vec2.py:547-576) ----

@@ -321,11 +321,15 @@ def test_attention_fwd_bwd(dtype, T, use_mask, attn_geometry):
     o, lse = K.attn_fwd(g[:, :d], g[:, d:2 * d], g[:, 2 * d:], B, T, H, 3 * d, scale, km)
     tol = 2e-5 if dtype == torch.float32 else 2e-2
     close(o.view(B, T, H, 64), oref.permute(0, 2, 1, 3), tol, "attn o")
-    dq, dk, dv, _ = K.attn_bwd(g[:, :d], g[:, d:2 * d], g[:, 2 * d:], o, dout.to(dev), lse, B, T, H, 3 * d, scale, km)
+    dbias0 = rnd((3 * d,), 9)                                           # q | k | v bias gradients accumulate (+=) here
+    dbias = dbias0.clone().to(dev)
+    dq, dk, dv, _ = K.attn_bwd(g[:, :d], g[:, d:2 * d], g[:, 2 * d:], o, dout.to(dev), lse, B, T, H, 3 * d, scale, km, dbias=dbias)
     tolb = 1e-4 if dtype == torch.float32 else 3e-2
     close(dq.reshape(B, T, H, 64), q.grad.permute(0, 2, 1, 3), tolb, "attn dq")
     close(dk.reshape(B, T, H, 64), k.grad.permute(0, 2, 1, 3), tolb, "attn dk")
     close(dv.reshape(B, T, H, 64), v.grad.permute(0, 2, 1, 3), tolb, "attn dv")
+    ref_b = torch.cat([x.grad.permute(0, 2, 1, 3).reshape(B * T, d).sum(0) for x in (q, k, v)])     # column sums of dq | dk | dv
+    close(dbias, dbias0 + ref_b, tolb, "q/k/v bias gradients from the backward kernels")
 
 
 def test_attention_dropout_mask_consistency():
