@@ -209,7 +209,51 @@ __global__ __launch_bounds__(64) void ctc_greedy_kernel(const T* __restrict__ lp
     if (lane == 0) out_len[b] = count;
 }
 
+// ---- targets[B,S] padded with PAD / EOS -> the flat label list F.ctc_loss takes (audio8/ctc.py:193-194: masked_select of
+// every entry that is neither PAD nor EOS, row-major) plus the per-utterance offsets (exclusive prefix sum of target_lengths).
+// One block: wave w counts / compacts rows w, w + 4, ...; nothing goes through the host.
+__global__ __launch_bounds__(256) void ctc_pack_kernel(const long long* __restrict__ targets, const int32_t* __restrict__ tlen,
+                                                       int32_t* __restrict__ flat, int32_t* __restrict__ off, int B, int S, int pad, int eos) {
+    extern __shared__ int cnt[];             // cnt[B]: valid entries per row, then their exclusive prefix
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int b = w; b < B; b += 4) {
+        int c = 0;
+        for (int s0 = 0; s0 < S; s0 += 64) {
+            const int s = s0 + lane;
+            const long long v = s < S ? targets[(long long)b * S + s] : pad;
+            c += __popcll(__ballot(s < S && v != pad && v != eos));
+        }
+        if (lane == 0) cnt[b] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0, lrun = 0;
+        for (int b = 0; b < B; ++b) { const int c = cnt[b]; cnt[b] = run; run += c; off[b] = lrun; lrun += tlen[b]; }
+        off[B] = lrun;
+    }
+    __syncthreads();
+    for (int b = w; b < B; b += 4) {
+        int pos = cnt[b];
+        for (int s0 = 0; s0 < S; s0 += 64) {
+            const int s = s0 + lane;
+            const long long v = s < S ? targets[(long long)b * S + s] : pad;
+            const bool keep = s < S && v != pad && v != eos;
+            const unsigned long long m = __ballot(keep);
+            if (keep) flat[pos + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)v;
+            pos += __popcll(m);
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int a8_ctc_pack_targets(const int64_t* targets, const int32_t* target_lengths, int32_t* flat, int32_t* tgt_off,
+                                   int B, int S, int pad, int eos, void* stream) {
+    A8_REQUIRE(B >= 1 && S >= 0 && B <= 8192, "a8_ctc_pack_targets: bad sizes B=%d S=%d", B, S);
+    hipLaunchKernelGGL(ctc_pack_kernel, dim3(1), dim3(256), sizeof(int) * B, (hipStream_t)stream, (const long long*)targets, target_lengths,
+                       flat, tgt_off, B, S, pad, eos);
+    return a8_check_launch("a8_ctc_pack_targets");
+}
 
 extern "C" int a8_ctc_fwd_bwd(const float* lp, const int32_t* targets, const int32_t* tgt_off, const int32_t* in_len,
                               float* nll, float* grad, float* alpha, int T_, int B, int V, int Smax, int blank, int zero_infinity,
@@ -220,6 +264,7 @@ extern "C" int a8_ctc_fwd_bwd(const float* lp, const int32_t* targets, const int
     A8_REQUIRE(Smax >= 0 && Lmax <= 64 * 16, "a8_ctc_fwd_bwd: Smax=%d exceeds the supported 511 labels", Smax);
     const int spl = (Lmax + 63) / 64;
     const size_t shm = sizeof(float) * 2 * V;
+    A8_REQUIRE(shm <= 64 * 1024, "a8_ctc_fwd_bwd: V=%d labels exceed the 8192 the per-frame LDS rows hold", V);
     hipStream_t s = (hipStream_t)stream;
 #define A8_CTC_LAUNCH(N) hipLaunchKernelGGL(ctc_kernel<N>, dim3(B), dim3(64), shm, s, lp, targets, tgt_off, in_len, nll, grad, alpha, T_, B, V, Lmax, blank, zero_infinity)
     if (spl <= 1) A8_CTC_LAUNCH(1);

@@ -412,24 +412,32 @@ __global__ void col2im_kernel(const T* __restrict__ dcol, const T* __restrict__ 
     }
 }
 
-// ------------------------------------------------------------------ log-softmax (cols <= 64), one wave per row
+// ------------------------------------------------------------------ log-softmax over the label axis, one wave per row
+// (any number of labels: a lane walks columns lane, lane + 64, ...; rows of x / dx may be padded to ldx elements)
 template <typename T>
-__global__ void log_softmax_fwd_kernel(const T* __restrict__ x, float* __restrict__ y, int rows, int cols) {
+__global__ void log_softmax_fwd_kernel(const T* __restrict__ x, float* __restrict__ y, int rows, int cols, int ldx) {
     const int lane = threadIdx.x & 63;
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
-        const float v = lane < cols ? to_f(x[(long long)row * cols + lane]) : -INFINITY;
-        const float m = wave_max(v);
-        const float s = wave_sum(lane < cols ? __expf(v - m) : 0.f);
-        if (lane < cols) y[(long long)row * cols + lane] = v - m - __logf(s);
+        const T* xr = x + (long long)row * ldx;
+        float m = -INFINITY;
+        for (int c = lane; c < cols; c += 64) m = fmaxf(m, to_f(xr[c]));
+        m = wave_max(m);
+        float s = 0.f;
+        for (int c = lane; c < cols; c += 64) s += __expf(to_f(xr[c]) - m);
+        const float lse = m + __logf(wave_sum(s));
+        for (int c = lane; c < cols; c += 64) y[(long long)row * cols + c] = to_f(xr[c]) - lse;
     }
 }
 template <typename T>
-__global__ void log_softmax_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, T* __restrict__ dx, int rows, int cols) {
+__global__ void log_softmax_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, T* __restrict__ dx, int rows, int cols, int ldx) {
     const int lane = threadIdx.x & 63;
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
-        const float g = lane < cols ? dy[(long long)row * cols + lane] : 0.f;
-        const float s = wave_sum(g);
-        if (lane < cols) dx[(long long)row * cols + lane] = from_f<T>(g - __expf(y[(long long)row * cols + lane]) * s);
+        const long long o = (long long)row * cols;
+        float s = 0.f;
+        for (int c = lane; c < cols; c += 64) s += dy[o + c];
+        s = wave_sum(s);
+        for (int c = lane; c < cols; c += 64) dx[(long long)row * ldx + c] = from_f<T>(dy[o + c] - __expf(y[o + c]) * s);
+        for (int c = cols + lane; c < ldx; c += 64) dx[(long long)row * ldx + c] = from_f<T>(0.f);      // padding columns carry no gradient
     }
 }
 
@@ -449,7 +457,9 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
 
 __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                              long long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s,
-                             const float* __restrict__ gnorm_sq, float max_norm, float grad_scale, int zero_grad) {
+                             const float* __restrict__ gnorm_sq, float max_norm, float grad_scale, const long long* __restrict__ grad_denom,
+                             int zero_grad) {
+    if (grad_denom) grad_scale /= (float)grad_denom[0];       // scale_grads(world / sum of batch sizes), audio8/train.py:320-323
     float clip = grad_scale;
     if (gnorm_sq && max_norm > 0.f) {
         const float nrm = sqrtf(gnorm_sq[0]) * grad_scale;
@@ -604,16 +614,16 @@ extern "C" int a8_col2im_gelu_grad(int dtype, const void* dcol, const void* z, v
                                          (const T*)dcol, (const T*)z, (T*)dx, B, Lin, Lout, C_, k, stride));
     return a8_check_launch("a8_col2im_gelu_grad");
 }
-extern "C" int a8_log_softmax_fwd(const void* x, int dtype, float* y, int rows, int cols, void* stream) {
-    A8_REQUIRE(cols >= 1 && cols <= 64, "a8_log_softmax_fwd: cols=%d must be in [1,64]", cols);
+extern "C" int a8_log_softmax_fwd(const void* x, int dtype, float* y, int rows, int cols, int ldx, void* stream) {
+    A8_REQUIRE(cols >= 1 && ldx >= cols, "a8_log_softmax_fwd: cols=%d must be >= 1 and ldx=%d >= cols", cols, ldx);
     if (rows == 0) return A8_OK;
-    DISPATCH_T(dtype, hipLaunchKernelGGL(log_softmax_fwd_kernel<T>, dim3(grid_for(rows, 4)), dim3(256), 0, (hipStream_t)stream, (const T*)x, y, rows, cols));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(log_softmax_fwd_kernel<T>, dim3(grid_for(rows, 4)), dim3(256), 0, (hipStream_t)stream, (const T*)x, y, rows, cols, ldx));
     return a8_check_launch("a8_log_softmax_fwd");
 }
-extern "C" int a8_log_softmax_bwd(const float* y, const float* dy, void* dx, int dtype, int rows, int cols, void* stream) {
-    A8_REQUIRE(cols >= 1 && cols <= 64, "a8_log_softmax_bwd: cols=%d must be in [1,64]", cols);
+extern "C" int a8_log_softmax_bwd(const float* y, const float* dy, void* dx, int dtype, int rows, int cols, int ldx, void* stream) {
+    A8_REQUIRE(cols >= 1 && ldx >= cols, "a8_log_softmax_bwd: cols=%d must be >= 1 and ldx=%d >= cols", cols, ldx);
     if (rows == 0) return A8_OK;
-    DISPATCH_T(dtype, hipLaunchKernelGGL(log_softmax_bwd_kernel<T>, dim3(grid_for(rows, 4)), dim3(256), 0, (hipStream_t)stream, y, dy, (T*)dx, rows, cols));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(log_softmax_bwd_kernel<T>, dim3(grid_for(rows, 4)), dim3(256), 0, (hipStream_t)stream, y, dy, (T*)dx, rows, cols, ldx));
     return a8_check_launch("a8_log_softmax_bwd");
 }
 extern "C" int a8_sumsq(const float* x, int64_t n, float* out, void* stream) {
@@ -623,12 +633,13 @@ extern "C" int a8_sumsq(const float* x, int64_t n, float* out, void* stream) {
     return a8_check_launch("a8_sumsq");
 }
 extern "C" int a8_adamw(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                        float weight_decay, int step, const float* gnorm_sq, float max_norm, float grad_scale, int zero_grad, void* stream) {
+                        float weight_decay, int step, const float* gnorm_sq, float max_norm, float grad_scale, const int64_t* grad_denom,
+                        int zero_grad, void* stream) {
     A8_REQUIRE(step >= 1, "a8_adamw: step counts from 1");
     if (n == 0) return A8_OK;
     const float bc1 = 1.0f - powf(beta1, (float)step);
     const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n, lr, beta1, beta2, eps,
-                       weight_decay, bc1, bc2s, gnorm_sq, max_norm, grad_scale, zero_grad);
+                       weight_decay, bc1, bc2s, gnorm_sq, max_norm, grad_scale, (const long long*)grad_denom, zero_grad);
     return a8_check_launch("a8_adamw");
 }

@@ -401,7 +401,9 @@ extern "C" int a8_contrastive_bwd(int dtype, const void* ctx, const void* lat, c
     A8_REQUIRE(dtype == A8_BF16 || dtype == A8_F32, "a8_contrastive_bwd: bad dtype");
     if (rows == 0) return A8_OK;
     const int rpg = rows_per_group;
-    const bool grouped = rpg > 0 && rows % rpg == 0 && (dtype != A8_BF16 || rpg <= 504);   // (the bf16 copy of W reuses the Cf slab)
+    // (the bf16 copy of W reuses the Cf slab; below 8 rows per group the padded G slab [rows/rpg][rpg4][256] would outgrow the
+    // 2*256 floats per row the scratch macro reserves -- such tiny groups take the scatter path)
+    const bool grouped = rpg >= 8 && rows % rpg == 0 && (dtype != A8_BF16 || rpg <= 504);
     const int rpg4 = (rpg + 7) & ~7;                     // the TN GEMM wants M % 4 (f32) / % 8 (bf16) == 0: W rows are padded with zero columns
     // scratch: ic[rows] il[rows] wA[rows*(N+1)] wU[rows*(N+1)] | U[rows] W[rows*rpg] Cf[rows*256] G[rows*256]
     auto al4 = [](size_t n) { return (n + 3) & ~(size_t)3; };              // sub-buffers start 16-byte aligned (GEMM operands)

@@ -6,6 +6,7 @@ import numpy as np
 import torch
 import torch.nn
 
+from . import kernels as K
 from . import ops
 
 
@@ -89,18 +90,31 @@ class CTCLoss(torch.nn.Module):
 
     def forward(self, log_prob, input_lengths, targets, target_lengths):
         dev = log_prob.device
-        t = targets.detach().cpu().numpy()
-        flat = t[(t != Offsets.PAD) & (t != Offsets.EOS)]                      # audio8/ctc.py:193-194
-        tl = np.asarray(target_lengths.detach().cpu().numpy() if torch.is_tensor(target_lengths) else target_lengths).astype(np.int64)
-        if int(tl.sum()) != flat.size:
-            raise RuntimeError("CTCLoss: sum(target_lengths) does not match the number of non-PAD/EOS targets")
-        off = np.concatenate([[0], np.cumsum(tl)])
         in_len = input_lengths.to(device=dev, dtype=torch.int32) if torch.is_tensor(input_lengths) else ops.host_i32(input_lengths, dev)
-        nll = ops.CTCFn.apply(log_prob, ops.host_i32(flat, dev), ops.host_i32(off, dev), in_len.contiguous(),
-                              int(max(1, tl.max() if tl.size else 1)), Offsets.GO, self.zero_infinity)
+        if torch.is_tensor(targets) and targets.is_cuda and targets.dim() == 2:
+            # device targets (audio8/train.py:35): PAD/EOS stripping and the offsets stay on the device -- no host round trip
+            # (the reference's masked_select is one).  The label bound is the padded width of `targets`.
+            if torch.is_tensor(target_lengths):
+                tl_dev = target_lengths.to(device=dev, dtype=torch.int32) if target_lengths.is_cuda else ops.host_i32(target_lengths.numpy(), dev)
+            else:
+                tl_dev = ops.host_i32(np.asarray(target_lengths), dev)
+            flat, off = K.ctc_pack_targets(targets.to(torch.int64).contiguous(), tl_dev.contiguous(), Offsets.PAD, Offsets.EOS)
+            smax = max(1, int(targets.shape[1]))
+            tl = None
+        else:
+            t = np.asarray(targets.detach().cpu().numpy() if torch.is_tensor(targets) else targets)
+            flat_np = t[(t != Offsets.PAD) & (t != Offsets.EOS)]                  # audio8/ctc.py:193-194
+            tl = np.asarray(target_lengths.detach().cpu().numpy() if torch.is_tensor(target_lengths) else target_lengths).astype(np.int64)
+            if int(tl.sum()) != flat_np.size:
+                raise RuntimeError("CTCLoss: sum(target_lengths) does not match the number of non-PAD/EOS targets")
+            flat, off = ops.host_i32(flat_np, dev), ops.host_i32(np.concatenate([[0], np.cumsum(tl)]), dev)
+            smax = int(max(1, tl.max() if tl.size else 1))
+        nll = ops.CTCFn.apply(log_prob, flat, off, in_len.contiguous(), smax, Offsets.GO, self.zero_infinity)
         if self.reduction_type == "sum":
             return nll.sum()
         if self.reduction_type == "mean":                                     # ATen: mean over batch of nll / clamp(target_len, 1)
+            if tl is None:
+                tl = np.asarray(target_lengths.detach().cpu().numpy() if torch.is_tensor(target_lengths) else target_lengths).astype(np.int64)
             denom = torch.from_numpy(np.maximum(tl, 1)).to(device=dev, dtype=nll.dtype)
             return (nll / denom).mean()
         return nll

@@ -374,6 +374,17 @@ def ctc_greedy_decode(lprobs, in_len_i32, blank=0):
 
 
 
+def ctc_pack_targets(targets_i64, tlen_i32, pad, eos):
+    """targets [B,S] int64 (device) -> (flat i32 [B*S] with the non-PAD/EOS entries in front, offsets i32 [B+1])."""
+    L.require_cuda(targets_i64, tlen_i32)
+    B, S = targets_i64.shape
+    flat = torch.empty((max(1, B * S),), device=targets_i64.device, dtype=torch.int32)
+    off = torch.empty((B + 1,), device=targets_i64.device, dtype=torch.int32)
+    L.check(L.lib().a8_ctc_pack_targets(L.ptr(_c(targets_i64)), L.ptr(tlen_i32), L.ptr(flat), L.ptr(off), B, S, int(pad), int(eos), L.stream()),
+            "a8_ctc_pack_targets")
+    return flat, off
+
+
 def ctc_fwd_bwd(lp, targets_flat_i32, tgt_off_i32, in_len_i32, Smax, blank=0, zero_infinity=True):
     T, B, V = lp.shape
     nll = torch.empty((B,), device=lp.device, dtype=torch.float32)
@@ -384,17 +395,20 @@ def ctc_fwd_bwd(lp, targets_flat_i32, tgt_off_i32, in_len_i32, Smax, blank=0, ze
     return nll, grad
 
 
-def log_softmax_fwd(x2d):
-    rows, cols = x2d.shape
+def log_softmax_fwd(x2d, cols=None):
+    """x2d [rows, ldx]: log_softmax over the first `cols` columns (the rest is GEMM padding) -> f32 [rows, cols]."""
+    rows, ldx = x2d.shape
+    cols = ldx if cols is None else cols
     y = torch.empty((rows, cols), device=x2d.device, dtype=torch.float32)
-    L.check(L.lib().a8_log_softmax_fwd(L.ptr(_c(x2d)), L.dt(x2d), L.ptr(y), rows, cols, L.stream()), "a8_log_softmax_fwd")
+    L.check(L.lib().a8_log_softmax_fwd(L.ptr(_c(x2d)), L.dt(x2d), L.ptr(y), rows, cols, ldx, L.stream()), "a8_log_softmax_fwd")
     return y
 
 
-def log_softmax_bwd(y, dy, dtype):
+def log_softmax_bwd(y, dy, dtype, ldx=None):
     rows, cols = y.shape
-    dx = torch.empty((rows, cols), device=y.device, dtype=dtype)
-    L.check(L.lib().a8_log_softmax_bwd(L.ptr(y), L.ptr(_c(dy)), L.ptr(dx), L.dt(dx), rows, cols, L.stream()), "a8_log_softmax_bwd")
+    ldx = cols if ldx is None else ldx
+    dx = torch.empty((rows, ldx), device=y.device, dtype=dtype)
+    L.check(L.lib().a8_log_softmax_bwd(L.ptr(y), L.ptr(_c(dy)), L.ptr(dx), L.dt(dx), rows, cols, ldx, L.stream()), "a8_log_softmax_bwd")
     return dx
 
 
@@ -403,9 +417,12 @@ def sumsq_(x, out):
     L.check(L.lib().a8_sumsq(L.ptr(x), int(x.numel()), L.ptr(out), L.stream()), "a8_sumsq")
 
 
-def adamw_(p, g, m, v, lr, beta1, beta2, eps, wd, step, gnorm_sq=None, max_norm=0.0, grad_scale=1.0, zero_grad=False):
+def adamw_(p, g, m, v, lr, beta1, beta2, eps, wd, step, gnorm_sq=None, max_norm=0.0, grad_scale=1.0, zero_grad=False, grad_denom=None):
+    """grad_denom: optional int64 device tensor; gradients are divided by its first element on the device."""
+    if grad_denom is not None and (grad_denom.dtype != torch.int64 or not grad_denom.is_cuda):
+        raise RuntimeError("a8hip adamw_: grad_denom must be an int64 device tensor")
     L.check(L.lib().a8_adamw(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), int(p.numel()), _f(lr), _f(beta1), _f(beta2), _f(eps), _f(wd),
-                             int(step), L.ptr(gnorm_sq), _f(max_norm), _f(grad_scale), 1 if zero_grad else 0, L.stream()), "a8_adamw")
+                             int(step), L.ptr(gnorm_sq), _f(max_norm), _f(grad_scale), L.ptr(grad_denom), 1 if zero_grad else 0, L.stream()), "a8_adamw")
 
 
 # ----------------------------------------------------------------------------- weight preparation

@@ -42,6 +42,43 @@ def host_to_device(a, dtype):
 
 
 
+# bench.py's per-component roofline: when a dict, the coarse Functions bracket their launch sequences with HIP events on
+# the current stream, PHASE_EVENTS[name] = [(start, end), ...]  (conv_fwd, conv0_fwd, conv_bwd, conv0_bwd, enc_fwd, enc_bwd, ...)
+PHASE_EVENTS = None
+
+
+class _Phase:
+    __slots__ = ("name", "ev")
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        self.ev = torch.cuda.Event(enable_timing=True)
+        self.ev.record()
+
+    def __exit__(self, *exc):
+        end = torch.cuda.Event(enable_timing=True)
+        end.record()
+        PHASE_EVENTS.setdefault(self.name, []).append((self.ev, end))
+        return False
+
+
+class _NoPhase:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_PHASE = _NoPhase()
+
+
+def phase(name):
+    return _NO_PHASE if PHASE_EVENTS is None else _Phase(name)
+
+
 def set_compute_dtype(dtype):
     """torch.bfloat16 (throughput mode: bf16 activations, f32 accumulate/statistics) or
     torch.float32 (parity mode: exact-f32 MFMA everywhere)."""
@@ -403,10 +440,21 @@ class ConvStackFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gn_w, gn_b, feats, *ws):
+        with phase("conv_fwd"):
+            return ConvStackFn._forward(ctx, x, gn_w, gn_b, feats, *ws)
+
+    @staticmethod
+    def backward(ctx, dout):
+        with phase("conv_bwd"):
+            return ConvStackFn._backward(ctx, dout)
+
+    @staticmethod
+    def _forward(ctx, x, gn_w, gn_b, feats, *ws):
         dtype = compute_dtype()
         B, Ls = x.shape
         x = x.contiguous().float()
-        a, stats = K.conv0_gn_gelu_fwd(x, ws[0].detach().contiguous(), gn_w.detach(), gn_b.detach(), dtype)
+        with phase("conv0_fwd"):
+            a, stats = K.conv0_gn_gelu_fwd(x, ws[0].detach().contiguous(), gn_w.detach(), gn_b.detach(), dtype)
         acts, zs, wcs, lens, wcTs = [a], [None], [None], [a.shape[1]], [None]
         for i in range(1, len(ws)):
             co, k, s = feats[i]
@@ -435,7 +483,7 @@ class ConvStackFn(torch.autograd.Function):
         return acts[-1]
 
     @staticmethod
-    def backward(ctx, dout):
+    def _backward(ctx, dout):
         nl, B, feats, lens = ctx.nl, ctx.B, ctx.feats, ctx.lens
         sv = ctx.saved_tensors
         x, gn_w, gn_b, stats, w0 = sv[:5]
@@ -512,7 +560,8 @@ class ConvStackFn(torch.autograd.Function):
         dw0 = t0 if direct else torch.zeros_like(w0, dtype=torch.float32)
         dgw = t1 if direct else torch.zeros_like(gn_w, dtype=torch.float32)
         dgb = t2 if direct else torch.zeros_like(gn_b, dtype=torch.float32)
-        K.conv0_gn_gelu_bwd(x, w0.detach().contiguous(), gn_w.detach(), gn_b.detach(), stats, dz.view(B, lens[0], -1), dw0, dgw, dgb)
+        with phase("conv0_bwd"):
+            K.conv0_gn_gelu_bwd(x, w0.detach().contiguous(), gn_w.detach(), gn_b.detach(), stats, dz.view(B, lens[0], -1), dw0, dgw, dgb)
         if direct:
             _ready(pw0, pgw, pgb)
             dw0 = dgw = dgb = None
@@ -527,7 +576,17 @@ class PosConvFn(torch.autograd.Function):
     part of this node (a8_weightnorm_pack / a8_weightnorm_bwd), not of the tape."""
 
     @staticmethod
-    def forward(ctx, x, v, g, bias, groups, pad_left):
+    def forward(ctx, *args):
+        with phase("posconv_fwd"):
+            return PosConvFn._forward(ctx, *args)
+
+    @staticmethod
+    def backward(ctx, dy):
+        with phase("posconv_bwd"):
+            return PosConvFn._backward(ctx, dy)
+
+    @staticmethod
+    def _forward(ctx, x, v, g, bias, groups, pad_left):
         B, T, d = x.shape
         k = v.shape[2]
         wf, wt, inv_norm = K.weightnorm_pack(v.detach(), g.detach(), groups, x.dtype)
@@ -538,7 +597,7 @@ class PosConvFn(torch.autograd.Function):
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def _backward(ctx, dy):
         x, z, wt, inv_norm = ctx.saved_tensors
         B, T, d = x.shape
         G, k = ctx.groups, ctx.k
@@ -579,7 +638,17 @@ class EncoderLayerFn(torch.autograd.Function):
     12 kernel launches forward, 21 backward; QKV run as one N = 3d GEMM on a concatenated working copy."""
 
     @staticmethod
-    def forward(ctx, x, keymask, B, T, H, p, eps, wq, bq, wk, bk, wv, bv, wo, bo, w1, b1, w2, b2, g1, be1, g2, be2):
+    def forward(ctx, *args):
+        with phase("enc_fwd"):
+            return EncoderLayerFn._forward(ctx, *args)
+
+    @staticmethod
+    def backward(ctx, dx2):
+        with phase("enc_bwd"):
+            return EncoderLayerFn._backward(ctx, dx2)
+
+    @staticmethod
+    def _forward(ctx, x, keymask, B, T, H, p, eps, wq, bq, wk, bk, wv, bv, wo, bo, w1, b1, w2, b2, g1, be1, g2, be2):
         M, d = x.shape
         dt = x.dtype
         dff = w1.shape[0]
@@ -614,7 +683,7 @@ class EncoderLayerFn(torch.autograd.Function):
         return x2
 
     @staticmethod
-    def backward(ctx, dx2):
+    def _backward(ctx, dx2):
         (x, keymask, qkv, o, lse, ao, x1, mean2, rstd2, z1, h, f, mean1, rstd1, wqkv_c, wo_c, w1_c, w2_c, g1, g2) = ctx.saved_tensors
         B, T, H, p, seed_a, seed1, seed2 = ctx.cfg
         M, d = x.shape
@@ -802,18 +871,21 @@ class PretrainLossFn(torch.autograd.Function):
 
 # ------------------------------------------------------------------ log-softmax head + CTC
 class LogSoftmaxFn(torch.autograd.Function):
+    """f32 log_softmax over the first `cols` entries of the last axis (the remainder is the head GEMM's padding)."""
+
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, cols=None):
         shp = x.shape
-        y = K.log_softmax_fwd(x.reshape(-1, shp[-1]).contiguous())
+        cols = shp[-1] if cols is None else cols
+        y = K.log_softmax_fwd(x.reshape(-1, shp[-1]).contiguous(), cols)
         ctx.save_for_backward(y)
-        ctx.dt = x.dtype
-        return y.view(shp)
+        ctx.dt, ctx.shp = x.dtype, shp
+        return y.view(*shp[:-1], cols)
 
     @staticmethod
     def backward(ctx, dy):
         (y,) = ctx.saved_tensors
-        return K.log_softmax_bwd(y, dy.reshape(y.shape).contiguous().float(), ctx.dt).view(dy.shape)
+        return K.log_softmax_bwd(y, dy.reshape(y.shape).contiguous().float(), ctx.dt, ctx.shp[-1]).view(ctx.shp), None
 
 
 class CTCFn(torch.autograd.Function):

@@ -10,6 +10,7 @@
   * Stepper       -- zero_grad / clip_grad_norm_ / AdamW of audio8/pretrain.py:171-186 as two kernel
                      launches (global sum of squares, fused clip+AdamW), no host sync.
 """
+import contextlib
 import os
 
 import torch
@@ -197,15 +198,25 @@ class GradReducer:
         self.handles = []
         self.next_bucket = 0
         self.marked = [False] * len(state.params)
+        # touched[i]: parameter i received a gradient since the last optimizer step (any backward pass of the accumulation
+        # window).  The optimizer skips the others, like torch's AdamW skips `p.grad is None` (frozen encoder / feature
+        # extractor of audio8/train.py:296-297, layer-dropped blocks).
+        self.touched = [False] * len(state.params)
+        self.n_touched = 0
+        self.suspended = False              # no_sync(): gradients accumulate locally, nothing is exchanged
         self.extra_streams = []
         self.compute_stream = None
         self.index_of = {id(p): i for i, p in enumerate(state.params)}
-        if self.enabled:
-            for i, p in enumerate(state.params):
-                p.register_post_accumulate_grad_hook(self._make_hook(i))
+        for i, p in enumerate(state.params):
+            p.register_post_accumulate_grad_hook(self._make_hook(i))
 
     def _mark(self, i):
-        # idempotent per step: a parameter whose gradient a backward kernel wrote directly is reported through
+        if not self.touched[i]:
+            self.touched[i] = True
+            self.n_touched += 1
+        if not self.enabled or self.suspended:
+            return
+        # idempotent per backward pass: a parameter whose gradient a backward kernel wrote directly is reported through
         # ops.GRAD_READY_HOOK, and autograd's post-accumulate hook fires for it as well (with an undefined gradient);
         # counting both would release the bucket before its other members' gradients are enqueued
         if self.marked[i]:
@@ -227,10 +238,9 @@ class GradReducer:
 
     def param_ready(self, p):
         """ops.GRAD_READY_HOOK: a backward kernel has enqueued p's gradient directly into the flat buffer."""
-        if self.enabled:
-            i = self.index_of.get(id(p))
-            if i is not None:
-                self._mark(i)
+        i = self.index_of.get(id(p))
+        if i is not None:
+            self._mark(i)
 
     def _launch(self, bk):
         view = self.state.flat_g[bk["lo"]:bk["hi"]]
@@ -255,7 +265,8 @@ class GradReducer:
         self.handles.append(h)
         bk["launched"] = True
 
-    def begin_step(self):
+    def begin_pass(self):
+        """Before a backward pass whose gradients will be exchanged: every bucket waits for all of its members again."""
         if self.on_gpu:
             self.compute_stream = torch.cuda.current_stream()
         for bk in self.buckets:
@@ -264,6 +275,26 @@ class GradReducer:
         self.marked = [False] * len(self.state.params)
         self.handles = []
         self.next_bucket = 0
+
+    def begin_step(self):
+        """After an optimizer step (zero_grad): a new accumulation window."""
+        self.touched = [False] * len(self.state.params)
+        self.n_touched = 0
+        self.begin_pass()
+
+    def all_reduce_counts(self, counts):
+        """SUM over ranks of a small device tensor (the batch-size / token counters of audio8/train.py:320-321, as ONE
+        collective) on the exchange stream, behind the gradient buckets; finish() makes the compute stream wait for it."""
+        if not self.enabled:
+            return counts
+        if self.on_gpu:
+            self.side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.side):
+                self.handles.append(dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            counts.record_stream(self.side)
+        else:
+            self.handles.append(dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        return counts
 
     def finish(self):
         """Issue any bucket whose parameters produced no gradient this step (frozen encoder, audio8/train.py:266-268),
@@ -280,17 +311,35 @@ class GradReducer:
             torch.cuda.current_stream().wait_stream(self.side)
 
 
-class Stepper:
-    """clip_grad_norm_(max_norm) + AdamW on the flat buffers; gradients are averaged over ranks inside the update."""
+ACTIVE_STEPPER = None        # the Stepper that currently owns audio8_amd.ops' global hooks (driver.PassThroughDDP.no_sync finds it here)
 
-    def __init__(self, model, lr=2.0e-4, weight_decay=1.0e-2, betas=(0.9, 0.999), eps=1e-8, clip=1.0, bucket_mb=32.0, lr_function=None, wgrad_side_stream=True):
+
+class Stepper:
+    """zero_grad / clip_grad_norm_(max_norm) / AdamW on the flat buffers, plus the data-parallel contract of the two drivers:
+
+      pretrain.py (audio8/pretrain.py:171-186)   zero_grad(); backward; step()            gradients = mean over ranks (DDP)
+      train.py    (audio8/train.py:292-326)      with no_sync(): backward   (grad_accum - 1 times)
+                                                 backward; step(batch_size=, num_tokens=)
+                                                 gradients = SUM over ranks and micro-batches / all-reduced batch size
+                                                 (DDP's mean followed by `scale_grads(num_gpus / batch_size)`)
+
+    Parameters that received no gradient since the last step (frozen encoder / feature extractor, layer-dropped blocks) are
+    left untouched and keep their own step count, as torch's AdamW does for `p.grad is None`."""
+
+    def __init__(self, model, lr=2.0e-4, weight_decay=1.0e-2, betas=(0.9, 0.999), eps=1e-8, clip=1.0, bucket_mb=32.0, lr_function=None,
+                 wgrad_side_stream=True, process_group=None, global_step=0):
         self.state = FlatState(model)
-        self.reducer = GradReducer(self.state, bucket_mb)
+        self.reducer = GradReducer(self.state, bucket_mb, process_group)
+        if self.reducer.enabled:                         # C1 of SURVEY 2.2: rank 0's parameters everywhere -- BEFORE anything
+            dist.broadcast(self.state.flat_p, src=0, group=process_group)      # is derived from them (the bf16 working copies below)
         self.lr, self.wd, self.betas, self.eps, self.clip = lr, weight_decay, betas, eps, clip
         self.lr_function = lr_function
-        self.global_step = 0
+        self.global_step = global_step
+        self.param_steps = [0] * len(self.state.params)
+        self._uniform_steps = True
         self.gnorm_sq = torch.zeros(1, device=self.state.flat_p.device, dtype=torch.float32)
         self._grads_clean = False
+        self._grad_ptrs = [self.state.flat_g.data_ptr() + 4 * o for o in self.state.offsets]
         ops.DIRECT_GRADS = True
         ops.GRAD_READY_HOOK = self.reducer.param_ready
         self.wgrad_stream = torch.cuda.Stream() if (wgrad_side_stream and self.state.flat_p.is_cuda) else None
@@ -303,8 +352,8 @@ class Stepper:
             ops.WEIGHT_CACHE, ops.WEIGHT_CACHE_DTYPE = self.wcache.cache, torch.bfloat16
             ops.CONV_DGRAD_CACHE = self.wcache.conv_dgrad
         self._versions = [p._version for p in self.state.params]
-        if self.reducer.enabled:                         # C1 of SURVEY 2.2: rank 0's parameters everywhere
-            dist.broadcast(self.state.flat_p, src=0)
+        global ACTIVE_STEPPER
+        ACTIVE_STEPPER = self
 
     @property
     def current_lr(self):
@@ -323,6 +372,17 @@ class Stepper:
         self._grads_clean = False
         self.reducer.begin_step()
 
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Backward passes inside accumulate into the flat gradient buffer without any exchange (DDP.no_sync of
+        audio8/train.py:300-301); the next backward outside it exchanges the accumulated sums bucket by bucket."""
+        self.reducer.suspended = True
+        try:
+            yield
+        finally:
+            self.reducer.suspended = False
+            self.reducer.begin_pass()
+
     def close(self):
         """Detach the global hooks this Stepper installed in audio8_amd.ops."""
         ops.DIRECT_GRADS = False
@@ -331,20 +391,68 @@ class Stepper:
         ops.WEIGHT_CACHE = None
         ops.WEIGHT_CACHE_DTYPE = None
         ops.CONV_DGRAD_CACHE = None
+        global ACTIVE_STEPPER
+        if ACTIVE_STEPPER is self:
+            ACTIVE_STEPPER = None
 
-    def step(self):
+    def _active_runs(self):
+        """Contiguous flat ranges [lo, hi) of parameters that got a gradient, each with the AdamW step count it is at."""
+        st, red = self.state, self.reducer
+        n = len(st.params)
+        if red.n_touched == n and self._uniform_steps:
+            s = self.param_steps[0] + 1
+            self.param_steps = [s] * n
+            return [(0, st.total, s)]
+        runs, i = [], 0
+        ends = st.offsets[1:] + [st.total]
+        while i < n:
+            if not red.touched[i]:
+                i += 1
+                continue
+            s, j = self.param_steps[i] + 1, i
+            while j < n and red.touched[j] and self.param_steps[j] + 1 == s:
+                self.param_steps[j] = s
+                j += 1
+            runs.append((st.offsets[i], ends[j - 1], s))
+            i = j
+        self._uniform_steps = len(set(self.param_steps)) == 1
+        return runs
+
+    def step(self, batch_size=None, num_tokens=None):
+        """Exchange what is still pending, clip, AdamW.  With `batch_size` (int or 0-dim integer tensor; `num_tokens` likewise)
+        the gradients are divided by the batch size summed over ranks instead of by the world size; returns the all-reduced
+        int64 device tensor [batch_size, num_tokens] (train.py logs both), else None."""
+        st = self.state
+        for p, want in zip(st.params, self._grad_ptrs):
+            g = p.grad
+            if g is None or g.data_ptr() != want:
+                raise RuntimeError("a8hip Stepper: a parameter's .grad no longer aliases the flat gradient buffer -- use "
+                                   "stepper.zero_grad(), not model.zero_grad(set_to_none=True), between steps")
         if self.wgrad_stream is not None:                # join the weight-gradient stream before gradients are read
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
+        counts = None
+        if batch_size is not None:
+            vals = [batch_size, 0 if num_tokens is None else num_tokens]
+            if any(torch.is_tensor(v) for v in vals):
+                counts = torch.stack([torch.as_tensor(v, device=st.flat_p.device).to(torch.int64).reshape(()) for v in vals])
+            elif st.flat_p.is_cuda:
+                counts = ops.host_to_device([int(v) for v in vals], "int64")
+            else:
+                counts = torch.tensor([int(v) for v in vals], dtype=torch.int64)
+            counts = self.reducer.all_reduce_counts(counts)
         self.reducer.finish()
         self.global_step += 1
-        scale = 1.0 / self.reducer.world
+        scale = 1.0 if counts is not None else 1.0 / self.reducer.world
         self.gnorm_sq.zero_()
-        K.sumsq_(self.state.flat_g, self.gnorm_sq)
-        K.adamw_(self.state.flat_p, self.state.flat_g, self.state.flat_m, self.state.flat_v, self.current_lr, self.betas[0], self.betas[1],
-                 self.eps, self.wd, self.global_step, self.gnorm_sq, self.clip, scale, zero_grad=True)
+        K.sumsq_(st.flat_g, self.gnorm_sq)
+        lr = self.current_lr
+        for lo, hi, nstep in self._active_runs():
+            K.adamw_(st.flat_p[lo:hi], st.flat_g[lo:hi], st.flat_m[lo:hi], st.flat_v[lo:hi], lr, self.betas[0], self.betas[1],
+                     self.eps, self.wd, nstep, self.gnorm_sq, self.clip, scale, zero_grad=True, grad_denom=counts)
         self._grads_clean = True
         if self.wcache is not None:
             self.wcache.refresh()
+        return counts
 
 
 def init_distributed_from_env():

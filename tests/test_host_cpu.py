@@ -131,3 +131,79 @@ def test_crop_to_min_batching_matches_oracle_incl_dropped_sample_quirk():
     s = [np.full(100, i, dtype=np.float32) for i in range(6)]
     b = [np.stack(x) for x in crop_to_min_batches(iter(s), 100, 200)]
     assert [sorted(set(x[:, 0].tolist())) for x in b] == [[0.0, 1.0], [3.0, 4.0]]
+
+
+def test_driver_surface_schedules_checkpoint_names_and_aliases(tmp_path):
+    """The eight_mile names the unchanged drivers import (audio8/pretrain.py:17-23, train.py:15-19), the warm-up/cosine LR
+    composite of audio8/utils.py:5-15, and the checkpoint naming that pretrain.py:135-137 parses the step back from."""
+    import importlib
+    import sys
+    import torch
+    from audio8_amd import driver as D
+    lr = 2e-4
+    s = D.create_lrs(lr, 1000, warmup_steps=100, plateau_steps=50)
+    assert s(0) == 0.0 and abs(s(50) - lr / 2) < 1e-12 and s(100) == lr and s(149) == lr            # linear warm-up, plateau
+    assert s(150) == lr and abs(s(650) - lr / 2) < 1e-12 and abs(s(1150)) < 1e-12 and abs(s(10 ** 6)) < 1e-12      # cosine, held at the end
+    assert abs(D.create_lrs(lr, 1000, alpha=0.1, warmup_steps=0)(1000) - 0.1 * lr) < 1e-12
+    m = torch.nn.Linear(3, 2)
+    base = str(tmp_path / "ckpt" / "checkpoint")
+    for step in (10, 250, 90):
+        D.save_checkpoint(m, base, step, tick_type="step")
+    name, step = D.find_latest_checkpoint(str(tmp_path / "ckpt"))
+    assert name.endswith("checkpoint-step-250.pth") and step == 250
+    assert int(name.split("-")[-1].split(".")[0]) == 250                    # the parse of audio8/pretrain.py:135-137
+    sd = torch.load(name)
+    assert sorted(sd) == ["bias", "weight"] and torch.equal(sd["weight"], m.weight.detach())
+    wrapped = D.PassThroughDDP(m)                                            # `.module` is unwrapped like DDP's
+    D.save_checkpoint(wrapped, base, 300, tick_type="step")
+    assert sorted(torch.load(base + "-step-300.pth")) == ["bias", "weight"]
+    a = D.Average("average_train_loss")
+    a.update(2.0); a.update(4.0)
+    assert a.avg == 3.0 and "average_train_loss" in str(a)
+    assert D.str2bool("True") is True and D.str2bool("0") is False and D.revlut({"a": 1}) == {1: "a"}
+    saved = {k: v for k, v in sys.modules.items() if k.split(".")[0] in ("eight_mile", "audio8")}
+    ddp = torch.nn.parallel.DistributedDataParallel
+    try:
+        D.install_aliases()
+        want = {"eight_mile.utils": ["str2bool", "Average", "get_num_gpus_multiworker", "Offsets", "revlut"],
+                "eight_mile.pytorch.optz": ["OptimizerManager"],
+                "eight_mile.pytorch.layers": ["save_checkpoint", "init_distributed", "sequence_mask", "find_latest_checkpoint", "Dense",
+                                              "TransformerEncoderStack", "Conv1DSame", "pytorch_conv1d", "pytorch_linear"],
+                "eight_mile.optz": ["create_lr_scheduler", "CompositeLRScheduler"],
+                "audio8.utils": ["create_lrs"],
+                "audio8.wav2vec2": ["create_loss", "create_model", "load_fairseq_bin", "create_acoustic_model"],
+                "audio8.ctc": ["CTCLoss", "ctc_metrics", "postproc_bpe", "postproc_letters"]}
+        for modname, names in want.items():
+            mod = importlib.import_module(modname)
+            for n in names:
+                assert hasattr(mod, n), (modname, n)
+        ns = {}
+        exec("from eight_mile.pytorch.optz import *", ns)                    # audio8/pretrain.py:20
+        assert "OptimizerManager" in ns
+        assert torch.nn.parallel.DistributedDataParallel is D.PassThroughDDP
+    finally:
+        torch.nn.parallel.DistributedDataParallel = ddp
+        for k in [k for k in sys.modules if k.split(".")[0] in ("eight_mile", "audio8")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+
+
+def test_g9_key_maps_and_convert_keys_equal_the_reference(golden_dir):
+    """G9: audio8_amd.wav2vec2's fairseq key maps are generated programmatically; they must equal the reference's literal
+    tables (audio8/wav2vec2.py:39-151) entry for entry, and convert_keys must rename / order / pass through exactly as the
+    reference's (audio8/wav2vec2.py:154-168)."""
+    import os
+    import numpy as np
+    from audio8_amd import wav2vec2 as W
+    g = np.load(os.path.join(golden_dir, "g9_keymaps.npz"))
+    for name in ("W2V_CTC_NESTED_MAP", "W2V2_CTC_FLAT_MAP_16", "W2V2_CTC_FLAT_MAP_8", "W2V_NESTED_MAP", "W2V2_FLAT_MAP"):
+        want = dict(zip((str(k) for k in g[name + "_src"]), (str(v) for v in g[name + "_dst"])))
+        assert getattr(W, name) == want, name
+    for tag, cm in (("pretrain", W.W2V_MAP), ("ctc16", W.W2V_CTC_MAP[16]), ("ctc8", W.W2V_CTC_MAP[8])):
+        src = {str(k): i for i, k in enumerate(g[f"{tag}_in_keys"])}
+        out = W.convert_keys(int(g[f"{tag}_layers"]), dict(src), cm.nested, cm.flat)
+        assert sorted(out.items()) == sorted(zip((str(k) for k in g[f"{tag}_out_keys"]), (int(v) for v in g[f"{tag}_out_vals"]))), tag
+        broken = dict(src)
+        broken.pop(next(iter(cm.flat)))
+        with pytest.raises(KeyError):
+            W.convert_keys(int(g[f"{tag}_layers"]), broken, cm.nested, cm.flat)

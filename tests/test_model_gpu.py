@@ -35,11 +35,11 @@ def restore_dtype():
     ops.set_compute_dtype(old)
 
 
-def _pretrain_pair(dtype, num_layers=2, B=2, L=16000, seed=0):
+def _pretrain_pair(dtype, num_layers=2, B=2, L=16000, seed=0, d_model=768, num_heads=12, d_ff=None):
     from audio8_amd import ops, wav2vec2 as W
     from oracle import ref_cpu as R
     ops.set_compute_dtype(dtype)
-    sd = R.init_state_dict(seed=seed, num_layers=num_layers)
+    sd = R.init_state_dict(seed=seed, num_layers=num_layers, d_model=d_model, num_heads=num_heads, d_ff=d_ff)
     x = synth(B, L)
     T = R.conv_out_lengths(L)[-1]
     np.random.seed(seed)
@@ -48,10 +48,11 @@ def _pretrain_pair(dtype, num_layers=2, B=2, L=16000, seed=0):
     # oracle
     sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     np.random.seed(seed)
-    loss_ref, aux = R.pretrain_loss(x, sdg, num_layers=num_layers, training=True, gumbel=gum)
+    loss_ref, aux = R.pretrain_loss(x, sdg, num_layers=num_layers, num_heads=num_heads, training=True, gumbel=gum)
     loss_ref.backward()
     # product
-    model = W.create_model(num_layers=num_layers, dropout=0.0, dropout_input=0.0, dropout_features=0.0)
+    model = W.create_model(num_layers=num_layers, d_model=d_model, num_heads=num_heads, d_ff=d_ff, dropout=0.0, dropout_input=0.0,
+                           dropout_features=0.0)
     model.load_state_dict(sd, strict=True)
     model = model.cuda().train()
     model.quantizer.gumbel_override = gum.cuda()
@@ -63,10 +64,8 @@ def _pretrain_pair(dtype, num_layers=2, B=2, L=16000, seed=0):
     return model, loss, loss_fn, sdg, loss_ref, aux
 
 
-def test_pretrain_step_parity_f32(restore_dtype):
-    """north_star tolerance: bit-exact mask/negative indices for a fixed seed; f32 logits/loss within 1e-4 rtol."""
+def _check_f32_parity(model, loss, loss_fn, sdg, loss_ref, aux, grad_tol):
     from oracle import ref_cpu as R
-    model, loss, loss_fn, sdg, loss_ref, aux = _pretrain_pair(torch.float32)
     np.testing.assert_allclose(loss.item(), loss_ref.item(), rtol=1e-4)
     # logits: product rows are (b, t), oracle rows are (t, b)
     B, Tm = aux["q"].shape[:2]
@@ -74,24 +73,54 @@ def test_pretrain_step_parity_f32(restore_dtype):
     ref_logits = R.contrastive_logits(om, aux["q"], torch.from_numpy(aux["neg_idx"])).view(Tm, B, -1).transpose(0, 1).reshape(B * Tm, -1)
     np.testing.assert_allclose(loss_fn.last_logits.cpu().numpy(), ref_logits.detach().numpy(), rtol=1e-4, atol=1e-5)
     got = dict(model.named_parameters())
-    worst = 0.0
+    worst, worst_k = 0.0, None
     for k, ref in sdg.items():
         assert got[k].grad is not None, k
+        if k.endswith("w_K.layer.bias"):      # exactly zero in exact arithmetic (softmax shift invariance): rounding noise on both sides
+            qn = got[k.replace("w_K", "w_Q")].grad.norm().item()
+            assert got[k].grad.norm().item() < 1e-3 * qn and ref.grad.norm().item() < 1e-3 * qn, k
+            continue
         e = rel_err(got[k].grad, ref.grad)
-        worst = max(worst, e)
-        assert e < 2e-3, f"{k}: rel grad err {e}"
-    print("worst relative gradient error (f32):", worst)
+        if e > worst:
+            worst, worst_k = e, k
+        assert e < grad_tol, f"{k}: rel grad err {e}"
+    print("worst relative gradient error (f32):", worst, worst_k)
+    return worst
+
+
+def test_pretrain_step_parity_f32(restore_dtype):
+    """north_star tolerance: bit-exact mask/negative indices for a fixed seed; f32 logits/loss within 1e-4 rtol; every
+    parameter gradient within 1e-4 (relative L2) of the oracle's."""
+    _check_f32_parity(*_pretrain_pair(torch.float32), grad_tol=1e-4)
+
+
+def test_pretrain_step_parity_f32_full_depth_base(restore_dtype):
+    """cfg1 as BASELINE.json names it: wav2vec2-BASE (12 encoder layers), 2 x 16 000 samples, one contrastive step."""
+    _check_f32_parity(*_pretrain_pair(torch.float32, num_layers=12, seed=3), grad_tol=3e-4)
+
+
+def test_pretrain_step_parity_f32_large_geometry(restore_dtype):
+    """cfg4's geometry (d_model 1024, 16 heads, d_ff 4096) at two layers."""
+    _check_f32_parity(*_pretrain_pair(torch.float32, num_layers=2, seed=4, d_model=1024, num_heads=16, d_ff=4096), grad_tol=1e-4)
 
 
 def test_pretrain_step_parity_bf16(restore_dtype):
-    """Throughput mode (bf16 activations, f32 accumulate/statistics): stated, looser tolerance."""
+    """Throughput mode (bf16 activations, f32 accumulate/statistics): stated, looser tolerance -- loss within 3e-2, and EVERY
+    parameter gradient pointing the oracle's way (cosine > 0.97; > 0.9 for the few vectors that are sums of many
+    cancelling bf16-rounded terms)."""
     model, loss, loss_fn, sdg, loss_ref, aux = _pretrain_pair(torch.bfloat16)
     np.testing.assert_allclose(loss.item(), loss_ref.item(), rtol=3e-2)
     got = dict(model.named_parameters())
-    for k in ("encoder.transformer.encoders.0.ffn.0.layer.weight", "encoder.transformer.encoders.1.self_attn.w_Q.layer.weight",
-              "feature_extractor.conv_layers.3.0.weight", "proj_to_input.layer.weight", "final_proj.layer.weight"):
-        c = cosine(got[k].grad, sdg[k].grad)
-        assert c > 0.97, f"{k}: gradient cosine {c}"
+    low = {}
+    for k, ref in sdg.items():
+        if k.endswith("w_K.layer.bias"):
+            continue
+        c = cosine(got[k].grad, ref.grad)
+        if c <= 0.97:
+            low[k] = c
+        assert c > 0.9, f"{k}: gradient cosine {c}"
+    print("bf16 gradient cosines below 0.97:", low)
+    assert len(low) <= 4, low
 
 
 def test_eval_mode_forward_f32(restore_dtype):

@@ -179,3 +179,89 @@ def test_model_forward_shapes_and_keys():
     pm = R.sequence_mask(torch.tensor([16000, 9000]), 16000)
     lp, pm2 = R.acoustic_model_forward(x, pm, sdc, num_layers=1)
     assert lp.shape == (2, 49, 32) and pm2.shape == (2, 49) and pm2[1].sum() == 9000 // (16000 // 49)
+
+
+def test_g7_end_to_end_cfg1_restatement_is_stable(golden_dir):
+    """G7: the whole cfg1 step (wav2vec2-base, 12 layers, 2 x 16 000) through the restatement.  The fixture comes from the
+    restatement itself (the reference model cannot be built without eight_mile): it pins the oracle against drift, and
+    its mask / negative indices are the reference-pinned samplers' (G1, G2)."""
+    g = _load(golden_dir, "g7_e2e_cfg1.npz")
+    sd = {k: v.clone().requires_grad_(True) for k, v in R.init_state_dict(seed=int(g["state_seed"]), num_layers=12).items()}
+    x = (0.1 * torch.randn(2, 16000, generator=torch.Generator().manual_seed(int(g["x_seed"])))).clamp_(-1, 1)
+    np.random.seed(int(g["numpy_seed"]))
+    Tm = int(R.create_mask((2, R.conv_out_lengths(16000)[-1]), 0.65, 10)[0].sum())
+    gum = -torch.empty(2 * Tm * 2, 320).exponential_(generator=torch.Generator().manual_seed(int(g["gumbel_seed"]))).log()
+    np.random.seed(int(g["numpy_seed"]))
+    loss, aux = R.pretrain_loss(x, sd, num_layers=12, training=True, gumbel=gum)
+    loss.backward()
+    assert np.array_equal(aux["time_mask"], g["time_mask"]) and np.array_equal(aux["neg_idx"], g["neg_idx"])
+    np.testing.assert_allclose(loss.item(), float(g["loss"]), rtol=1e-5)
+    np.testing.assert_allclose(aux["ppl"].item(), float(g["ppl"]), rtol=1e-5)
+    np.testing.assert_allclose(aux["ctx"].detach().numpy().reshape(-1)[::53], g["ctx_sub"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(aux["q"].detach().numpy().reshape(-1)[::53], g["q_sub"], rtol=1e-4, atol=1e-5)
+    norms = np.array([float(sd[str(k)].grad.double().norm()) for k in g["grad_names"]])
+    big = g["grad_norms"] > 1e-6 * g["grad_norms"].max()
+    np.testing.assert_allclose(norms[big], g["grad_norms"][big], rtol=2e-3)
+    np.testing.assert_allclose(sd["feature_extractor.conv_layers.0.0.weight"].grad.numpy().reshape(-1), g["grad_sub_conv0_w"], rtol=2e-3, atol=1e-6)
+
+
+def test_g8_ctc_metrics_against_reference(golden_dir):
+    """G8: greedy decode + strip + post-processing + word splitting of audio8/ctc.py:139-183 (oracle restatement AND the
+    product's host path), including the reference's slice by SAMPLE length."""
+    from audio8_amd import ctc as Cc
+    g = _load(golden_dir, "g8_ctc_metrics.npz")
+    lp, targets = torch.from_numpy(g["lp"]), torch.from_numpy(g["targets"])
+    i2v = {i: str(c) for i, c in enumerate(g["vocab"])}
+    names = ["wv_errors", "w_errors", "w_total", "c_errors", "c_total"]
+    for tag in ("frames", "samples"):
+        for pn, fn_o, fn_p in (("letters", R.postproc_letters, Cc.postproc_letters), ("bpe", None, Cc.postproc_bpe)):
+            il = torch.from_numpy(g[f"{tag}_{pn}_il"])
+            want = dict(zip(names, (int(v) for v in g[f"{tag}_{pn}"])))
+            assert Cc.ctc_metrics(lp, targets, il, i2v, postproc_fn=fn_p) == want, (tag, pn)
+            if fn_o is not None:
+                assert R.ctc_metrics(lp, targets, il, i2v, postproc_fn=fn_o) == want, (tag, pn)
+    assert R.edit_distance("kitten", "sitting") == 3 and R.edit_distance([1, 2, 3], []) == 3 and R.edit_distance("flaw", "lawn") == 2
+
+
+def test_encoder_layer_restatement_agrees_with_hf_wav2vec2_layer():
+    """Independent witness for row a5 (eight_mile's post-LN encoder block is restated from memory: no reference fixture can pin
+    it).  HF transformers' Wav2Vec2EncoderLayer -- built from a local config object, nothing downloaded -- is fairseq's
+    post-LN wav2vec2 block: attention -> +residual -> LayerNorm -> FFN(GELU) -> +residual -> LayerNorm.  With shared weights
+    and eps matched it must equal oracle.encoder_layer under the reference's fairseq key map (self_attn_layer_norm -> ln2,
+    final_layer_norm -> ln1, fc1 -> ffn.0, fc2 -> ffn.3; audio8/wav2vec2.py:109-127)."""
+    transformers = pytest.importorskip("transformers")
+    from transformers import Wav2Vec2Config
+    from transformers.models.wav2vec2.modeling_wav2vec2 import Wav2Vec2EncoderLayer
+    d, H, dff, eps = 768, 12, 3072, 1e-6
+    cfg = Wav2Vec2Config(hidden_size=d, num_attention_heads=H, intermediate_size=dff, hidden_act="gelu", hidden_dropout=0.0,
+                         attention_dropout=0.0, activation_dropout=0.0, layer_norm_eps=eps, attn_implementation="eager")
+    layer = Wav2Vec2EncoderLayer(cfg).eval()
+    full = R.init_state_dict(seed=9, num_layers=1)
+    pfx = "encoder.transformer.encoders.0."
+    sd = {k[len(pfx):]: v for k, v in full.items() if k.startswith(pfx)}
+    rs = np.random.RandomState(1)
+    for k in list(sd):                      # non-trivial biases / LN affine so that every term is exercised
+        if k.endswith("bias") or "ln" in k:
+            sd[k] = sd[k] + torch.from_numpy(0.1 * rs.standard_normal(tuple(sd[k].shape)).astype(np.float32))
+    hf_map = {"attention.q_proj": "self_attn.w_Q.layer", "attention.k_proj": "self_attn.w_K.layer", "attention.v_proj": "self_attn.w_V.layer",
+              "attention.out_proj": "self_attn.w_O.layer", "layer_norm": "ln2", "feed_forward.intermediate_dense": "ffn.0.layer",
+              "feed_forward.output_dense": "ffn.3.layer", "final_layer_norm": "ln1"}
+    hsd = {}
+    for hk, ok in hf_map.items():
+        for leaf in ("weight", "bias"):
+            hsd[f"{hk}.{leaf}"] = sd[f"{ok}.{leaf}"]
+    missing = layer.load_state_dict(hsd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    x = torch.from_numpy(rs.standard_normal((2, 37, d)).astype(np.float32))
+    with torch.no_grad():
+        want = layer(x)[0]
+        got = R.encoder_layer(x, sd, "", H, ln_eps=eps)
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=2e-5, atol=2e-5)
+    # key-padding mask: the oracle's -1e9 fill vs HF's additive large-negative mask on the same keys
+    keep = torch.ones(2, 37, dtype=torch.bool)
+    keep[1, 30:] = False
+    add = torch.zeros(2, 1, 37, 37).masked_fill(~keep[:, None, None, :], torch.finfo(torch.float32).min)
+    with torch.no_grad():
+        want_m = layer(x, attention_mask=add)[0]
+        got_m = R.encoder_layer(x, sd, "", H, mask=keep[:, None, None, :], ln_eps=eps)
+    np.testing.assert_allclose(got_m.numpy()[keep.numpy()], want_m.numpy()[keep.numpy()], rtol=2e-5, atol=2e-5)

@@ -15,6 +15,9 @@ top-level definitions that do not need eight_mile:
         weight is overwritten with the fixture's own weights before use)
     CTCLoss                audio8/ctc.py:186-206 (needs Offsets.{GO,PAD,EOS} = 0,1,2, the
         values audio8/train.py:22-23 installs)
+    ctc_metrics, postproc_*  audio8/ctc.py:139-183, 63-72 (G8; `editdistance` supplied as a plain DP)
+    key maps, convert_keys   audio8/wav2vec2.py:39-168 (G9)
+G7 (end-to-end cfg1) comes from the CPU restatement, not from the reference (see gen_e2e).
 
 No reference source text or bytecode is written anywhere: the outputs are .npz files of
 inputs and expected outputs only (tests/golden/*.npz).
@@ -38,7 +41,9 @@ WANTED_W2V = {
     "create_mask", "Sampler", "GumbelVectorQuantizer", "Wav2Vec2Loss", "ConvFeatureExtractionModel",
     "CONV_FEATURES", "START_TEMP", "END_TEMP", "TEMP_DECAY_FACTOR", "XE_WGT", "DIVERSITY_WGT",
 }
-WANTED_CTC = {"CTCLoss"}
+WANTED_CTC = {"CTCLoss", "ctc_metrics", "postproc_letters", "postproc_bpe"}
+WANTED_MAPS = {"CheckpointMapping", "W2V_CTC_NESTED_MAP", "W2V2_CTC_FLAT_MAP_16", "W2V2_CTC_FLAT_MAP_8", "W2V_NESTED_MAP", "W2V2_FLAT_MAP",
+               "W2V_MAP", "W2V_CTC_MAP_16", "W2V_CTC_MAP_8", "W2V_CTC_MAP", "convert_keys"}
 
 
 def _extract(path, wanted, ns):
@@ -68,9 +73,10 @@ def load_reference(ref_root):
     def pytorch_conv1d(in_channels, out_channels, fsz, unif=0, padding=0, initializer=None, stride=1, bias=True, groups=1):
         return nn.Conv1d(in_channels, out_channels, fsz, padding=padding, stride=stride, bias=bias, groups=groups)
 
+    from collections import namedtuple
     ns = dict(torch=torch, nn=nn, F=F, np=np, math=math, Tuple=Tuple, List=List, Optional=Optional, Dict=Dict,
-              contextlib=contextlib, Offsets=Offsets, pytorch_conv1d=pytorch_conv1d)
-    _extract(os.path.join(ref_root, "audio8", "wav2vec2.py"), WANTED_W2V, ns)
+              contextlib=contextlib, Offsets=Offsets, pytorch_conv1d=pytorch_conv1d, namedtuple=namedtuple)
+    _extract(os.path.join(ref_root, "audio8", "wav2vec2.py"), WANTED_W2V | WANTED_MAPS, ns)
     _extract(os.path.join(ref_root, "audio8", "ctc.py"), WANTED_CTC, ns)
     return types.SimpleNamespace(**ns)
 
@@ -305,6 +311,106 @@ def gen_ctc(ref, out):
     np.savez_compressed(os.path.join(out, "g6_ctc.npz"), **d)
 
 
+def _own_levenshtein(a, b):
+    a, b = list(a), list(b)
+    prev = list(range(len(b) + 1))
+    for i, x in enumerate(a, 1):
+        cur = [i]
+        for j, y in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (x != y)))
+        prev = cur
+    return prev[-1]
+
+
+def gen_e2e(out):
+    """G7: one cfg1 pretrain step (wav2vec2-base, 12 layers, 2 x 16 000 samples) through the CPU restatement (oracle/ref_cpu.py).
+    NOT produced by the reference (its model cannot be built without eight_mile): pins the restatement against drift;
+    the eight_mile-owned semantics inside it stay "parity unpinned"."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from oracle import ref_cpu as R
+    sd = {k: v.clone().requires_grad_(True) for k, v in R.init_state_dict(seed=0, num_layers=12).items()}
+    x = (0.1 * torch.randn(2, 16000, generator=torch.Generator().manual_seed(1234))).clamp_(-1, 1)
+    np.random.seed(0)
+    T = R.conv_out_lengths(16000)[-1]
+    Tm = int(R.create_mask((2, T), 0.65, 10)[0].sum())
+    gum = -torch.empty(2 * Tm * 2, 320).exponential_(generator=torch.Generator().manual_seed(5)).log()
+    np.random.seed(0)
+    loss, aux = R.pretrain_loss(x, sd, num_layers=12, training=True, gumbel=gum)
+    loss.backward()
+    d = dict(loss=t2n(loss), ppl=t2n(aux["ppl"]), time_mask=aux["time_mask"], neg_idx=aux["neg_idx"].astype(np.int32),
+             ctx_sub=t2n(aux["ctx"]).reshape(-1)[::53].copy(), q_sub=t2n(aux["q"]).reshape(-1)[::53].copy(),
+             state_seed=np.array(0), x_seed=np.array(1234), gumbel_seed=np.array(5), numpy_seed=np.array(0))
+    names = sorted(sd)
+    d["grad_names"] = np.array(names)
+    d["grad_norms"] = np.array([float(sd[k].grad.double().norm()) for k in names])
+    d["grad_sub_final_proj_w"] = t2n(sd["final_proj.layer.weight"].grad).reshape(-1)[::97].copy()
+    d["grad_sub_conv0_w"] = t2n(sd["feature_extractor.conv_layers.0.0.weight"].grad).reshape(-1).copy()
+    np.savez_compressed(os.path.join(out, "g7_e2e_cfg1.npz"), **d)
+
+
+def gen_metrics(ref, out):
+    """G8: ctc_metrics greedy path (audio8/ctc.py:139-183) on a tiny letter vocabulary.  `editdistance` (third-party, absent)
+    is supplied by this script as a plain Levenshtein DP; what the fixture pins is the reference's decode / strip /
+    post-processing / word-splitting around it, including the slice by SAMPLE length (`lp[:inp_l]`)."""
+    fake = types.ModuleType("editdistance")
+    fake.eval = _own_levenshtein
+    sys.modules["editdistance"] = fake
+    try:
+        vocab = ['<s>', '<pad>', '</s>', '<unk>', '|'] + [chr(97 + i) for i in range(27)]
+        i2v = {i: c for i, c in enumerate(vocab)}
+        g = torch.Generator().manual_seed(8)
+        B, T, V = 6, 40, 32
+        lp = torch.randn(B, T, V, generator=g)
+        # make decodes look like text: long runs of a few symbols, blanks and word separators
+        path = torch.randint(0, V, (B, T // 4), generator=g).repeat_interleave(4, 1)
+        path[:, ::7] = 0
+        path[:, 5::9] = 4
+        lp.scatter_(2, path.unsqueeze(-1), 9.0)
+        lp = lp.log_softmax(-1)
+        tl = torch.tensor([9, 5, 0, 12, 3, 7])
+        targets = torch.full((B, 14), 1, dtype=torch.long)
+        for b in range(B):
+            targets[b, : tl[b]] = torch.randint(4, V, (int(tl[b]),), generator=g)
+            if b % 2 == 0:
+                targets[b, 2:tl[b]:3] = 4
+            targets[b, tl[b]] = 2
+        d = dict(lp=t2n(lp), targets=t2n(targets), vocab=np.array(vocab))
+        for tag, il in (("frames", torch.tensor([40, 33, 20, 40, 7, 1])), ("samples", torch.tensor([12800, 10560, 6400, 12800, 2240, 320]))):
+            for pn, fn in (("letters", ref.postproc_letters), ("bpe", ref.postproc_bpe)):
+                m = ref.ctc_metrics(lp, targets, il, i2v, postproc_fn=fn)
+                d[f"{tag}_{pn}_il"] = t2n(il)
+                d[f"{tag}_{pn}"] = np.array([m["wv_errors"], m["w_errors"], m["w_total"], m["c_errors"], m["c_total"]])
+        np.savez_compressed(os.path.join(out, "g8_ctc_metrics.npz"), **d)
+    finally:
+        del sys.modules["editdistance"]
+
+
+def gen_keymaps(ref, out):
+    """G9: the reference's fairseq -> audio8 key maps (audio8/wav2vec2.py:39-151) as (source, destination) string tables, and
+    convert_keys (audio8/wav2vec2.py:154-168) run on synthetic fairseq-named dicts: the output key ORDER and which value
+    lands under which key (values are tagged integers)."""
+    d = {}
+    for name in ("W2V_CTC_NESTED_MAP", "W2V2_CTC_FLAT_MAP_16", "W2V2_CTC_FLAT_MAP_8", "W2V_NESTED_MAP", "W2V2_FLAT_MAP"):
+        m = getattr(ref, name)
+        d[name + "_src"] = np.array(list(m.keys()))
+        d[name + "_dst"] = np.array(list(m.values()))
+    for tag, cm, nl in (("pretrain", ref.W2V_MAP, 3), ("ctc16", ref.W2V_CTC_MAP[16], 2), ("ctc8", ref.W2V_CTC_MAP[8], 2)):
+        src = {}
+        for i in range(nl):
+            for k in cm.nested:
+                src[k.format(i)] = len(src)
+        for k in cm.flat:
+            src[k] = len(src)
+        src["some.unmapped.key"] = len(src)
+        src["another_unmapped"] = len(src)
+        d[f"{tag}_in_keys"] = np.array(list(src.keys()))
+        outd = ref.convert_keys(nl, dict(src), cm.nested, cm.flat)
+        d[f"{tag}_out_keys"] = np.array(list(outd.keys()))
+        d[f"{tag}_out_vals"] = np.array(list(outd.values()))
+        d[f"{tag}_layers"] = np.array(nl)
+    np.savez_compressed(os.path.join(out, "g9_keymaps.npz"), **d)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -319,6 +425,9 @@ def main():
     gen_vq(ref, args.out)
     gen_loss(ref, args.out)
     gen_ctc(ref, args.out)
+    gen_e2e(args.out)
+    gen_metrics(ref, args.out)
+    gen_keymaps(ref, args.out)
     for f in sorted(os.listdir(args.out)):
         print(f, os.path.getsize(os.path.join(args.out, f)))
 
