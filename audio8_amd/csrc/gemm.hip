@@ -224,16 +224,16 @@ A8_DEV void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MI][4], char* lds, con
 
 // Main loop: NST-deep ring of LDS stages filled by LDS-DMA (global_load_lds, 16 B per lane), NST-1 k-tiles in
 // flight per block; one raw s_barrier and one counted s_waitcnt vmcnt per k-tile; no register staging.
-template <typename T, bool AKS, bool BKS, int KB, int NST, int NWM>
+template <typename T, bool AKS, bool BKS, int KB, int NST, int NWM, int MIP = 0>
 A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
     typedef StageTile<T, KB> ST;
     typedef KcGeom<KB> G;
     typedef Mma<T> MM;
     constexpr int BK = ST::BK, EPC = 16 / (int)sizeof(T), SZ = (int)sizeof(T);
     constexpr int NW = 2 * NWM;                   // waves per block: NWM along M x 2 along N
-    constexpr int MI = NWM == 2 ? 4 : 2;          // 16-row fragments per wave along M: a wave owns (16 MI) x 64 of the tile
-    constexpr int BM = 16 * MI * NWM;             // tile rows: 128, or 160 with 10 waves (NWM = 5, both operands K-contiguous only)
-    static_assert(BM == 128 || !(AKS || BKS), "the 160-row tile is built for K-contiguous operands");
+    constexpr int MI = MIP ? MIP : (NWM == 2 ? 4 : 2);   // 16-row fragments per wave along M: a wave owns (16 MI) x 64 of the tile
+    constexpr int BM = 16 * MI * NWM;             // tile rows: 128; 160 with 10 waves (NWM = 5); 192 / 256 with 8 waves of 48 / 64 rows (MIP = 3 / 4)
+    static_assert(BM == 128 || !(AKS || BKS), "tiles taller than 128 rows are built for K-contiguous operands");
     constexpr int TA = BM * G::KROW, TB = G::OPBYTES, STAGE = TA + TB;
     constexpr int NPA = TA / 1024, NPB = TB / 1024;                        // 1 KB LDS-DMA pieces per operand per stage
     constexpr int PPA = (NPA + NW - 1) / NW, PPB = (NPB + NW - 1) / NW;    // ... per wave (the last may be missing when NW does not divide)
@@ -399,6 +399,15 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
     __syncthreads();
 
     gemm_epilogue<T, MI, NWM, NP>(g, acc, lds, w, m0, n0, lane);
+}
+
+// ---- tall tiles for the products that would put between one and two 128 x 128 tiles on a CU (M = 6248, N = 768: 294 tiles on
+// 256 CUs -- the launch lasts as long as the 38 CUs that got two): 192 x 128 (198 tiles) or 256 x 128 with the same 8 waves
+// (4 x 2, each 48 / 64 rows x 64 columns: 0.58 / 0.5 KB of fragment reads and 0.21 / 0.19 LDS-DMA instructions per MFMA instead of
+// 0.75 / 0.25), ONE block per CU, 3-deep ring (two k-tiles in flight: a lone block has no co-resident block to hide a DMA behind).
+template <typename T, int MIP>
+__global__ __launch_bounds__(512, 2) void gemm_tall_kernel(const GemmArgs g) {
+    gemm_body<T, false, false, 2, 3, 4, MIP>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n * g.nsplit));
 }
 
 // ---- pipelined 256 x 256 main loop for large NT problems with N % 256 == 0 and K % 64 == 0 (the conv layers: N = 512):
@@ -679,6 +688,21 @@ extern "C" int a8_gemm(const a8_gemm_desc* d, void* stream) {
         if ((long long)tm * tn >= g_a8_tuning[5] && a_span < (1ll << 32) && b_span < (1ll << 32)) {
             g.tiles_m = tm; g.tiles_n = tn;
             hipLaunchKernelGGL(gemm_p256_kernel<bf16>, dim3(tm * tn), dim3(512), 0, s, g);
+            return a8_check_launch("a8_gemm");
+        }
+    }
+    // Tall tiles (a8_set_tuning key 8: 0 = never, 1 = by the tile-count rule below, 3 / 4 = always 192 / 256 rows).
+    if (d->dtype == A8_BF16 && d->layout == A8_GEMM_NT && g_variant == 5 && g_a8_tuning[8] > 0 && d->K % 64 == 0) {
+        const int mode = g_a8_tuning[8];
+        const long long t128 = grid, t192 = (long long)cdiv(d->M, 192) * g.tiles_n * g.nsplit, t256 = (long long)cdiv(d->M, 256) * g.tiles_n * g.nsplit;
+        int mi = 0;
+        if (mode == 3 || mode == 4) mi = mode;
+        else if (t128 > 256 && t128 <= 512) mi = t192 <= 256 ? 3 : (t256 <= 256 ? 4 : 0);
+        if (mi) {
+            g.tiles_m = cdiv(d->M, 64 * mi);
+            const int gr = (int)(mi == 3 ? t192 : t256);
+            if (mi == 3) hipLaunchKernelGGL((gemm_tall_kernel<bf16, 3>), dim3(gr), dim3(512), 0, s, g);
+            else hipLaunchKernelGGL((gemm_tall_kernel<bf16, 4>), dim3(gr), dim3(512), 0, s, g);
             return a8_check_launch("a8_gemm");
         }
     }

@@ -110,14 +110,18 @@ def conv_out_len(L, k, s):
 
 
 # ----------------------------------------------------------------------------- conv layer 0
-def conv0_gn_gelu_fwd(x, w, gn_w, gn_b, out_dtype, eps=1e-5):
-    """x f32 [B,L]; w f32 [512,1,10] -> (out [B,L0,512] channels-last, stats f32 [B,512,2])."""
-    L.require_cuda(x, w, gn_w, gn_b)
+def conv0_gn_gelu_fwd(x, w, gn_w, gn_b, out_dtype, eps=1e-5, out=None, stats=None):
+    """x f32 [B,L]; w f32 [512,1,10] -> (out [B,L0,512] channels-last, stats f32 [B,512,2]); out / stats may be preallocated."""
+    L.require_cuda(x, w, gn_w, gn_b, out, stats)
     B, Ls = x.shape
     Cn = w.shape[0]
     L0 = conv_out_len(Ls, 10, 5)
-    out = torch.empty((B, L0, Cn), device=x.device, dtype=out_dtype)
-    stats = torch.empty((B, Cn, 2), device=x.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((B, L0, Cn), device=x.device, dtype=out_dtype)
+    if stats is None:
+        stats = torch.empty((B, Cn, 2), device=x.device, dtype=torch.float32)
+    if out.dtype != out_dtype or tuple(out.shape) != (B, L0, Cn) or tuple(stats.shape) != (B, Cn, 2) or not (out.is_contiguous() and stats.is_contiguous()):
+        raise RuntimeError("a8hip conv0_gn_gelu_fwd: bad preallocated out / stats")
     part = torch.empty((B * ((L0 + 511) // 512) * 65,), device=x.device, dtype=torch.float64)      # A8_CONV0_FWD_SCRATCH_FLOATS
     L.check(L.lib().a8_conv0_gn_gelu_fwd(L.dt(out), L.ptr(_c(x)), L.ptr(_c(w)), L.ptr(gn_w), L.ptr(gn_b), L.ptr(out), L.ptr(stats),
                                          L.ptr(part), B, Ls, Cn, _f(eps), L.stream()), "a8_conv0_gn_gelu_fwd")

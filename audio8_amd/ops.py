@@ -452,11 +452,18 @@ class ConvStackFn(torch.autograd.Function):
     def _forward(ctx, x, gn_w, gn_b, feats, *ws):
         dtype = compute_dtype()
         B, Ls = x.shape
+        nl = len(ws)
         x = x.contiguous().float()
-        with phase("conv0_fwd"):
-            a, stats = K.conv0_gn_gelu_fwd(x, ws[0].detach().contiguous(), gn_w.detach(), gn_b.detach(), dtype)
-        acts, zs, wcs, lens, wcTs = [a], [None], [None], [a.shape[1]], [None]
-        for i in range(1, len(ws)):
+        dev = x.device
+        lens, n = [], Ls
+        for co, k, s in feats:
+            n = (n - k) // s + 1
+            lens.append(n)
+        acts = [torch.empty((B, lens[i], feats[i][0]), device=dev, dtype=dtype) for i in range(nl)]
+        zs = [None] + [torch.empty((B * lens[i], feats[i][0]), device=dev, dtype=dtype) for i in range(1, nl)]
+        stats = torch.empty((B, feats[0][0], 2), device=dev, dtype=torch.float32)
+        wcs, wcTs = [None], [None]
+        for i in range(1, nl):
             co, k, s = feats[i]
             cin = ws[i].shape[1]
             e = cached_weights(ws[i], dtype)
@@ -465,21 +472,31 @@ class ConvStackFn(torch.autograd.Function):
             else:
                 w2 = ws[i].detach().permute(0, 2, 1).reshape(co, k * cin)        # [co][kk*cin + ci]
                 wc, wcT = (w2.contiguous() if dtype == torch.float32 else K.cast(w2.contiguous(), dtype)), None
-            wcTs.append(wcT)
-            Lin = lens[-1]
-            Lout = (Lin - k) // s + 1
-            z = torch.empty((B * Lout, co), device=x.device, dtype=dtype)
-            y = K.gemm(L.NT, acts[-1], wc, B * Lout, co, k * cin, lda=s * cin, a_rpb=Lout, a_bs=Lin * cin, act=L.ACT_GELU, zout=z)
-            acts.append(y.view(B, Lout, co))
-            zs.append(z)
             wcs.append(wc)
-            lens.append(Lout)
+            wcTs.append(wcT)
+        w0c, gw, gb = ws[0].detach().contiguous(), gn_w.detach(), gn_b.detach()
+
+        def run_layers(b0, b1, lo, hi):                # layers lo .. hi-1 on utterances [b0, b1)
+            for i in range(lo, hi):
+                if i == 0:
+                    with phase("conv0_fwd"):
+                        K.conv0_gn_gelu_fwd(x[b0:b1], w0c, gw, gb, dtype, out=acts[0][b0:b1], stats=stats[b0:b1])
+                    continue
+                co, k, s = feats[i]
+                cin, Lin, Lout = feats[i - 1][0], lens[i - 1], lens[i]
+                K.gemm(L.NT, acts[i - 1][b0:b1], wcs[i], (b1 - b0) * Lout, co, k * cin, lda=s * cin, a_rpb=Lout, a_bs=Lin * cin, act=L.ACT_GELU,
+                       zout=zs[i][b0 * Lout:b1 * Lout], out=acts[i][b0:b1].view(-1, co))
+
+        ch, nlc = _conv_chunking(B, nl)
+        for b0 in range(0, B, ch):                     # the big leading layers utterance-chunk by utterance-chunk: each layer's
+            run_layers(b0, min(B, b0 + ch), 0, nlc)    # output is consumed by the next one while it still sits in the Infinity Cache
+        run_layers(0, B, nlc, nl)
         ctx.feats, ctx.lens, ctx.B = feats, lens, B
         ctx.wcTs = wcTs
         ctx.ws = ws
         ctx.params = (ws[0], gn_w, gn_b)
         ctx.save_for_backward(x, gn_w, gn_b, stats, ws[0], *acts[:-1], *zs[1:], *wcs[1:])
-        ctx.nl = len(ws)
+        ctx.nl = nl
         return acts[-1]
 
     @staticmethod
@@ -500,73 +517,104 @@ class ConvStackFn(torch.autograd.Function):
         ws = ctx.ws
         fusable = (CONV_DGRAD_CACHE is not None and WEIGHT_CACHE_DTYPE == dtype and feats[-1][1] == 2 and all(f[2] == 2 and f[1] in (2, 3) for f in feats[1:])
                    and all(ctx.wcTs[i] is not None for i in range(1, nl)) and all(feats[i][1] == 2 or id(ws[i]) in CONV_DGRAD_CACHE for i in range(1, nl)))
-        pad = 0                                   # dz of layer i is stored with `pad` zero rows around each utterance
-        for i in range(nl - 1, 0, -1):
-            co, k, s = feats[i]
-            cin = acts[i - 1].shape[-1]
-            Lin, Lout = lens[i - 1], lens[i]
-            M = B * Lout
-            dzrows = Lout + 2 * pad
-            akw = dict(a_off=pad * co, a_rpb=Lout, a_bs=dzrows * co) if pad else {}
-            tgt = _target(ws[i])
-            if tgt is not None:
-                # off the critical path: wgrad GEMM + re-layout [co][k][cin] -> [co][cin][k] + accumulate on the side stream
-                def run(dz=dz, a=acts[i - 1], co=co, k=k, cin=cin, M=M, s=s, Lout=Lout, Lin=Lin, akw=akw, tgt=tgt, p=ws[i]):
-                    dw2 = wgrad(dz, a, co, k * cin, M, ldb=s * cin, b_rpb=Lout, b_bs=Lin * cin, lda=co, **akw)
-                    tgt.add_(dw2.view(co, k, cin).permute(0, 2, 1))
-                    _ready(p)
-                _on_side(run, dz, acts[i - 1])
-                grads[i] = None
-            else:
-                dw2 = wgrad(dz, acts[i - 1], co, k * cin, M, ldb=s * cin, b_rpb=Lout, b_bs=Lin * cin, lda=co, **akw)
-                grads[i] = dw2.view(co, k, cin).permute(0, 2, 1).contiguous()
-            zprev = zs[i - 1] if i - 1 >= 1 else None
-            if not fusable:
-                dcol = _dgrad(dz, wcs[i], ctx.wcTs[i], M, k * cin, co)
-                dz = K.col2im_gelu_grad(dcol, zprev, B, Lin, Lout, cin, k, s).view(-1, cin)
-                del dcol
-                continue
-            # fused data gradient: write dx[b, p, :] (* gelu'(z)) straight from the GEMM epilogues
-            npad = 1 if (i - 1 >= 1 and feats[i - 1][1] == 3) else 0          # the layer below reads dz[t-1], dz[t]
-            prow = Lin + 2 * npad
-            dx = torch.empty((B * prow, cin), device=dz.device, dtype=dtype)
-            written = 2 * Lout + (1 if k == 3 else 0)          # the GEMMs below write positions 0 .. written-1 of every utterance
-            dxv = dx.view(B, prow, cin)
-            if npad:
-                dxv[:, :npad].zero_()                          # only the pad rows and the uncovered tail need clearing
-            if npad + written < prow:
-                dxv[:, npad + written:].zero_()
-            act = L.ACT_MUL_GELU_GRAD if zprev is not None else L.ACT_NONE
-            zk = dict(zin=zprev, ldz=2 * cin, z_bs=Lin * cin) if zprev is not None else {}
-            if k == 2:
-                K.gemm(L.NT, dz, ctx.wcTs[i], M, 2 * cin, co, out=dx, lda=co, ldc=2 * cin, c_off=npad * cin, c_rpb=Lout, c_bs=prow * cin,
-                       act=act, **akw, **(dict(zk, z_rpb=Lout) if zk else {}))
-            else:
-                assert pad == 1
-                b_even, b_odd = CONV_DGRAD_CACHE[id(ws[i])]
-                # even positions p = 2t, t = 0..Lout: rows [dz[t-1] | dz[t]] of the zero-padded dz (K = 2 co)
-                K.gemm(L.NT, dz, b_even, B * (Lout + 1), cin, 2 * co, out=dx, lda=co, a_rpb=Lout + 1, a_bs=dzrows * co,
-                       ldc=2 * cin, c_off=npad * cin, c_rpb=Lout + 1, c_bs=prow * cin, act=act,
-                       **(dict(zk, z_rpb=Lout + 1) if zk else {}))
-                # odd positions p = 2t + 1, t = 0..Lout-1
-                K.gemm(L.NT, dz, b_odd, M, cin, co, out=dx, lda=co, a_off=co, a_rpb=Lout, a_bs=dzrows * co,
-                       ldc=2 * cin, c_off=(npad + 1) * cin, c_rpb=Lout, c_bs=prow * cin, act=act,
-                       **(dict(zk, z_rpb=Lout, z_off=cin) if zk else {}))
-            dz, pad = dx, npad
-        assert pad == 0
+
+        def bwd_range(b0, b1, dz, pad, hi, lo, last):
+            """Layers hi .. lo (descending, lo >= 1) for utterances [b0, b1): dz = gradient w.r.t. layer hi's pre-activation, stored with
+            `pad` zero rows around each utterance.  Returns the same pair for layer lo - 1."""
+            nb = b1 - b0
+            for i in range(hi, lo - 1, -1):
+                co, k, s = feats[i]
+                cin = acts[i - 1].shape[-1]
+                Lin, Lout = lens[i - 1], lens[i]
+                M = nb * Lout
+                dzrows = Lout + 2 * pad
+                akw = dict(a_off=pad * co, a_rpb=Lout, a_bs=dzrows * co) if pad else {}
+                a_prev = acts[i - 1][b0:b1]
+                tgt = _target(ws[i])
+                if tgt is not None:
+                    # off the critical path: wgrad GEMM + re-layout [co][k][cin] -> [co][cin][k] + accumulate on the side stream
+                    def run(dz=dz, a=a_prev, co=co, k=k, cin=cin, M=M, s=s, Lout=Lout, Lin=Lin, akw=akw, tgt=tgt, p=ws[i]):
+                        dw2 = wgrad(dz, a, co, k * cin, M, ldb=s * cin, b_rpb=Lout, b_bs=Lin * cin, lda=co, **akw)
+                        tgt.add_(dw2.view(co, k, cin).permute(0, 2, 1))
+                        if last:                       # the gradient is complete once the last chunk's share is enqueued
+                            _ready(p)
+                    _on_side(run, dz, a_prev)
+                else:
+                    dw2 = wgrad(dz, a_prev, co, k * cin, M, ldb=s * cin, b_rpb=Lout, b_bs=Lin * cin, lda=co, **akw)
+                    gi = dw2.view(co, k, cin).permute(0, 2, 1).contiguous()
+                    grads[i] = gi if grads[i] is None else grads[i] + gi
+                zprev = zs[i - 1][b0 * Lin:b1 * Lin] if i - 1 >= 1 else None
+                if not fusable:
+                    dcol = _dgrad(dz, wcs[i], ctx.wcTs[i], M, k * cin, co)
+                    dz = K.col2im_gelu_grad(dcol, zprev, nb, Lin, Lout, cin, k, s).view(-1, cin)
+                    del dcol
+                    continue
+                # fused data gradient: write dx[b, p, :] (* gelu'(z)) straight from the GEMM epilogues
+                npad = 1 if (i - 1 >= 1 and feats[i - 1][1] == 3) else 0          # the layer below reads dz[t-1], dz[t]
+                prow = Lin + 2 * npad
+                dx = torch.empty((nb * prow, cin), device=dz.device, dtype=dtype)
+                written = 2 * Lout + (1 if k == 3 else 0)          # the GEMMs below write positions 0 .. written-1 of every utterance
+                dxv = dx.view(nb, prow, cin)
+                if npad:
+                    dxv[:, :npad].zero_()                          # only the pad rows and the uncovered tail need clearing
+                if npad + written < prow:
+                    dxv[:, npad + written:].zero_()
+                act = L.ACT_MUL_GELU_GRAD if zprev is not None else L.ACT_NONE
+                zk = dict(zin=zprev, ldz=2 * cin, z_bs=Lin * cin) if zprev is not None else {}
+                if k == 2:
+                    K.gemm(L.NT, dz, ctx.wcTs[i], M, 2 * cin, co, out=dx, lda=co, ldc=2 * cin, c_off=npad * cin, c_rpb=Lout, c_bs=prow * cin,
+                           act=act, **akw, **(dict(zk, z_rpb=Lout) if zk else {}))
+                else:
+                    assert pad == 1
+                    b_even, b_odd = CONV_DGRAD_CACHE[id(ws[i])]
+                    # even positions p = 2t, t = 0..Lout: rows [dz[t-1] | dz[t]] of the zero-padded dz (K = 2 co)
+                    K.gemm(L.NT, dz, b_even, nb * (Lout + 1), cin, 2 * co, out=dx, lda=co, a_rpb=Lout + 1, a_bs=dzrows * co,
+                           ldc=2 * cin, c_off=npad * cin, c_rpb=Lout + 1, c_bs=prow * cin, act=act,
+                           **(dict(zk, z_rpb=Lout + 1) if zk else {}))
+                    # odd positions p = 2t + 1, t = 0..Lout-1
+                    K.gemm(L.NT, dz, b_odd, M, cin, co, out=dx, lda=co, a_off=co, a_rpb=Lout, a_bs=dzrows * co,
+                           ldc=2 * cin, c_off=(npad + 1) * cin, c_rpb=Lout, c_bs=prow * cin, act=act,
+                           **(dict(zk, z_rpb=Lout, z_off=cin) if zk else {}))
+                dz, pad = dx, npad
+            return dz, pad
+
         pw0, pgw, pgb = ctx.params
         t0, t1, t2 = _target(pw0), _target(pgw), _target(pgb)
         direct = t0 is not None and t1 is not None and t2 is not None
         dw0 = t0 if direct else torch.zeros_like(w0, dtype=torch.float32)
         dgw = t1 if direct else torch.zeros_like(gn_w, dtype=torch.float32)
         dgb = t2 if direct else torch.zeros_like(gn_b, dtype=torch.float32)
-        with phase("conv0_bwd"):
-            K.conv0_gn_gelu_bwd(x, w0.detach().contiguous(), gn_w.detach(), gn_b.detach(), stats, dz.view(B, lens[0], -1), dw0, dgw, dgb)
+        w0c, gw, gb = w0.detach().contiguous(), gn_w.detach(), gn_b.detach()
+        ch, nlc = _conv_chunking(B, nl)
+        nlc = max(nlc, 1)
+        dz, pad = bwd_range(0, B, dz, 0, nl - 1, nlc, True)          # the small trailing layers on the whole batch
+        rows = dz.shape[0] // B                                       # rows per utterance of layer (nlc - 1)'s gradient, pad included
+        dzv = dz.view(B, rows, -1)
+        for b0 in range(0, B, ch):
+            b1 = min(B, b0 + ch)
+            dzc, padc = bwd_range(b0, b1, dzv[b0:b1].reshape(-1, dzv.shape[-1]), pad, nlc - 1, 1, b1 == B)
+            assert padc == 0
+            with phase("conv0_bwd"):
+                K.conv0_gn_gelu_bwd(x[b0:b1], w0c, gw, gb, stats[b0:b1], dzc.view(b1 - b0, lens[0], -1), dw0, dgw, dgb)
         if direct:
             _ready(pw0, pgw, pgb)
             dw0 = dgw = dgb = None
         grads[0] = dw0
         return (None, dgw, dgb, None, *grads)
+
+
+# Utterance chunking of the conv stack's big leading layers (layer 0's output is 51 MB per utterance at 250 k samples): with
+# CONV_CHUNK_UTTS utterances per chunk, layers 0 .. CONV_CHUNK_LAYERS-1 run chunk by chunk so that a layer reads its input
+# while it is still resident in the 256 MB Infinity Cache; the remaining (small) layers run on the whole batch.  0 = off.
+CONV_CHUNK_UTTS = 0
+CONV_CHUNK_LAYERS = 3
+
+
+def _conv_chunking(B, nl):
+    ch = CONV_CHUNK_UTTS
+    if ch <= 0 or ch >= B:
+        return B, 0
+    return ch, max(1, min(CONV_CHUNK_LAYERS, nl - 1))
 
 
 # ------------------------------------------------------------------ positional conv

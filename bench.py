@@ -145,6 +145,11 @@ def main():
     ops.GROUP_WGRAD = os.environ.get("A8_GROUP_WGRAD", "1") != "0"
     ops.ATTN_BIAS_FUSED = os.environ.get("A8_ATTN_BIAS_FUSED", "0") != "0"
     prefetch = os.environ.get("A8_PREFETCH_DRAWS", "1") != "0"
+    if os.environ.get("A8_CONV_CHUNK"):                                      # developer knob: "utterances[,layers]"
+        cc = [int(v) for v in os.environ["A8_CONV_CHUNK"].split(",")]
+        ops.CONV_CHUNK_UTTS = cc[0]
+        if len(cc) > 1:
+            ops.CONV_CHUNK_LAYERS = cc[1]
     for kv in filter(None, os.environ.get("A8_TUNE", "").split(",")):       # developer knobs, e.g. A8_TUNE=5=0,1=403
         k, v = kv.split("=")
         L.check(L.lib().a8_set_tuning(int(k), int(v)), "a8_set_tuning")

@@ -152,7 +152,8 @@ st.close()
 if dist.is_initialized():
     dist.barrier()
     dist.destroy_process_group()
-print("RANK%d " % rank + json.dumps(out))
+sys.stdout.write("\nRANK%d " % rank + json.dumps(out) + "\n")
+sys.stdout.flush()
 '''
 
 
@@ -163,10 +164,8 @@ def test_two_ranks_on_one_gpu_broadcast_order_and_train_semantics(tmp_path):
            "--master-port", str(_free_port()), str(script)]
     r = subprocess.run(cmd, env=_clean_env(A8_REPO=ROOT), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    outs = {}
-    for ln in r.stdout.splitlines():
-        if ln.startswith("RANK"):
-            outs[int(ln[4])] = json.loads(ln[6:])
+    import re
+    outs = {int(m.group(1)): json.loads(m.group(2)) for m in re.finditer(r"RANK(\d) (\{[^\n]*?\})(?=\s|RANK|$)", r.stdout)}
     assert sorted(outs) == [0, 1], r.stdout[-2000:]
     for rank, o in outs.items():
         assert o["params_equal_rank0"], rank                     # C1: rank 0's parameters everywhere ...
