@@ -12,8 +12,10 @@
 //  * Softmax statistics are lane-local per query (query = lane&15) + two xor-shuffles over the 4 key groups.
 //  * One LDS image per 64x64 tile serves both the row reads (b128, XOR-swizzled) and the transposed reads.
 //  * Dropout regenerates its keep-mask from a counter hash of (b,h,query,key) in all three kernels: one 32-bit
-//    word per PAIR of adjacent keys, h = fin((pair_index + seed) * C1), a 16-bit field per key.  The pair index
-//    is affine in the tile / fragment coordinates, so the product is carried as a running sum (one add per word).
+//    word per QUAD of adjacent keys, h = fin((quad_index + seed) * C1), an 8-bit field per key (the drop probability
+//    is realised in 1/256 steps and the 1/(1-p) scale uses the realised value).  The quad index is affine in the tile /
+//    fragment coordinates, so the product is carried as a running sum (one add per word): the forward and dQ kernels,
+//    whose lanes hold 4 adjacent keys of one query per accumulator, hash once per accumulator.
 //  * The softmax inner loops are VALU-bound at head dim 64, so they are written for instruction count: scores stay
 //    raw, exp2(fma(s, scale, -max)) with the bare v_exp_f32; the running max is only raised when a tile exceeds it
 //    by more than 2^8 (probabilities stay <= 256, exact same result after the final 1/l); the constant factors
@@ -195,13 +197,13 @@ struct AttnP {
     long long ld_qkv, ld_o, ld_d;
     float scale, pscale, dscale;   // scale = softmax scale * log2(e) (scores and lse live in the log2 domain); dscale = softmax scale
     float lazy;                    // raise the running max only past this margin (log2 units)
-    uint32_t thr, seed;            // thr: 16-bit keep threshold (0 = dropout off)
-    int Th;                        // key pairs per query row = ceil(T / 2)
+    uint32_t thr, seed;            // thr: 8-bit keep threshold (0 = dropout off)
+    int Th;                        // key quads per query row = ceil(T / 4)
 };
 
 constexpr uint32_t HC1 = 0x9E3779B1u, HC2 = 0x2C1B3C6Du;
 constexpr float MASKED_LOG2 = -1.4426950408889634e9f;      // masked_fill(-1e9) in the log2 domain
-// dropout word of key pair `idx`: fin((idx + seed) * HC1); callers carry the product as a running sum
+// dropout word of key quad `idx`: fin((idx + seed) * HC1); callers carry the product as a running sum
 A8_DEV uint32_t hfin(uint32_t h) { h ^= h >> 15; return h * HC2; }
 A8_DEV uint32_t pair_base(int bh, int T, int Th, int q) { return ((uint32_t)bh * (uint32_t)T + (uint32_t)q) * (uint32_t)Th; }
 A8_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -291,8 +293,8 @@ template <> A8_DEV void store4<float>(float* p, float a, float b, float c, float
 
 // ================================================================== forward
 // block = NW waves, each wave owns G groups of 16 queries (query = 16*group + lane&15)
-template <typename T, int NW, int G>
-__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnP P) {
+template <typename T, int NW, int G, int MW = 1>
+__global__ __launch_bounds__(NW * 64, MW) void attn_fwd_kernel(const AttnP P) {
     constexpr int NT = NW * 64, BQ = NW * G * 16, TB = ATile<T>::BYTES, NBUF = attn_nbuf<T>();
     __shared__ __attribute__((aligned(16))) char lds[NBUF * 2 * TB];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnP P) {
         qi[j] = blk * BQ + (wv * G + j) * 16 + li;
         qf[j].load(qb + (long long)qi[j] * P.ld_qkv, qi[j] < P.T, lane);
         m[j] = -INFINITY; l[j] = 0.f;
-        hb[j] = (pair_base(bh, P.T, P.Th, qi[j]) + (uint32_t)(2 * g) + P.seed) * HC1;
+        hb[j] = (pair_base(bh, P.T, P.Th, qi[j]) + (uint32_t)g + P.seed) * HC1;
 #pragma unroll
         for (int i = 0; i < 4; ++i) oacc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
@@ -374,14 +376,14 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnP P) {
             l[j] += ls;
             if (P.thr) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint32_t h0 = hfin(hb[j] + (uint32_t)(8 * i) * HC1), h1 = hfin(hb[j] + (uint32_t)(8 * i + 1) * HC1);
-                    s[j][i][0] = (h0 & 0xFFFFu) >= P.thr ? s[j][i][0] : 0.f;
-                    s[j][i][1] = (h0 >> 16) >= P.thr ? s[j][i][1] : 0.f;
-                    s[j][i][2] = (h1 & 0xFFFFu) >= P.thr ? s[j][i][2] : 0.f;
-                    s[j][i][3] = (h1 >> 16) >= P.thr ? s[j][i][3] : 0.f;
+                for (int i = 0; i < 4; ++i) {        // keys 16i + 4g + r, r = 0..3: one quad, one word
+                    const uint32_t h0 = hfin(hb[j] + (uint32_t)(4 * i) * HC1);
+                    s[j][i][0] = (h0 & 0xFFu) >= P.thr ? s[j][i][0] : 0.f;
+                    s[j][i][1] = ((h0 >> 8) & 0xFFu) >= P.thr ? s[j][i][1] : 0.f;
+                    s[j][i][2] = ((h0 >> 16) & 0xFFu) >= P.thr ? s[j][i][2] : 0.f;
+                    s[j][i][3] = (h0 >> 24) >= P.thr ? s[j][i][3] : 0.f;
                 }
-                hb[j] += (uint32_t)(BT / 2) * HC1;
+                hb[j] += (uint32_t)(BT / 4) * HC1;
             }
             pf[j][0] = ATile<T>::pfrag(s[j][0], s[j][1]);
             pf[j][1] = ATile<T>::pfrag(s[j][2], s[j][3]);
@@ -404,8 +406,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnP P) {
 
 // ================================================================== backward A: dK, dV (key block stationary)
 // block = NW waves, each wave owns G groups of 16 keys; streams Q / dO tiles (+ lse, delta of the tile's queries)
-template <typename T, int NW, int G>
-__global__ __launch_bounds__(NW * 64) void attn_bwd_kv_kernel(const AttnP P) {
+template <typename T, int NW, int G, int MW = 1>
+__global__ __launch_bounds__(NW * 64, MW) void attn_bwd_kv_kernel(const AttnP P) {
     constexpr int NT = NW * 64, BK = NW * G * 16, TB = ATile<T>::BYTES, NBUF = attn_nbuf<T>();
     __shared__ __attribute__((aligned(16))) char lds[NBUF * 2 * TB];
     __shared__ __attribute__((aligned(16))) float s_stat[NBUF][2][BT];     // [buffer][lse | delta][query in tile]
@@ -424,8 +426,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kv_kernel(const AttnP P) {
     f32x4 dk[G][4], dv[G][4];
     int key[G];
     bool key_masked[G];
-    uint32_t hk[G], hc2[G];       // dropout word of (query qq, key): fin(hk + (qq - tile base - 4g) * ThC), field (key & 1);
-                                  // the final multiplier is HC2 << 16 for even keys, which moves their field to the top half
+    uint32_t hk[G], hc2[G];       // dropout word of (query qq, key): fin(hk + (qq - tile base - 4g) * ThC), field (key & 3);
+                                  // the final multiplier is HC2 << 8 (3 - field), which moves the key's byte to the top
 #pragma unroll
     for (int j = 0; j < G; ++j) {
         key[j] = blk * BK + (wv * G + j) * 16 + li;
@@ -433,8 +435,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kv_kernel(const AttnP P) {
         kf[j].load(kb + (long long)key[j] * P.ld_qkv, ok, lane);
         vf[j].load(vb + (long long)key[j] * P.ld_qkv, ok, lane);
         key_masked[j] = P.keymask && ok && !P.keymask[(long long)b * P.T + key[j]];
-        hk[j] = (pair_base(bh, P.T, P.Th, 4 * g) + (uint32_t)(key[j] >> 1) + P.seed) * HC1;
-        hc2[j] = (key[j] & 1) ? HC2 : (HC2 << 16);
+        hk[j] = (pair_base(bh, P.T, P.Th, 4 * g) + (uint32_t)(key[j] >> 2) + P.seed) * HC1;
+        hc2[j] = HC2 << (8 * (3 - (key[j] & 3)));
 #pragma unroll
         for (int i = 0; i < 4; ++i) { dk[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     }
@@ -485,8 +487,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kv_kernel(const AttnP P) {
                     float pdrop = p, dpv = dp[j][i][r];
                     if (P.thr) {
                         uint32_t hh = hk[j] + (uint32_t)(16 * i + r) * ThC;
-                        hh = (hh ^ (hh >> 15)) * hc2[j];                  // = hfin() with the key's 16-bit field in bits 31..16
-                        const bool keep = hh >= (P.thr << 16);
+                        hh = (hh ^ (hh >> 15)) * hc2[j];                  // = hfin() with the key's 8-bit field in bits 31..24
+                        const bool keep = hh >= (P.thr << 24);
                         pdrop = keep ? p : 0.f;
                         dpv = keep ? dpv : 0.f;
                     }
@@ -527,8 +529,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kv_kernel(const AttnP P) {
 }
 
 // ================================================================== backward B: dQ (query block stationary)
-template <typename T, int NW, int G>
-__global__ __launch_bounds__(NW * 64) void attn_bwd_q_kernel(const AttnP P) {
+template <typename T, int NW, int G, int MW = 1>
+__global__ __launch_bounds__(NW * 64, MW) void attn_bwd_q_kernel(const AttnP P) {
     constexpr int NT = NW * 64, BQ = NW * G * 16, TB = ATile<T>::BYTES, NBUF = attn_nbuf<T>();
     __shared__ __attribute__((aligned(16))) char lds[NBUF * 2 * TB];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
@@ -563,7 +565,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_q_kernel(const AttnP P) {
             ndelta[j] = -dl;
             if (ok && g == 0) P.delta[(long long)bh * P.T + qi[j]] = dl;
         }
-        hb[j] = (pair_base(bh, P.T, P.Th, qi[j]) + (uint32_t)(2 * g) + P.seed) * HC1;
+        hb[j] = (pair_base(bh, P.T, P.Th, qi[j]) + (uint32_t)g + P.seed) * HC1;
 #pragma unroll
         for (int i = 0; i < 4; ++i) dq[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
@@ -579,8 +581,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_q_kernel(const AttnP P) {
         for (int j = 0; j < G; ++j) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                uint32_t h0 = 0, h1 = 0;
-                if (P.thr) { h0 = hfin(hb[j] + (uint32_t)(8 * i) * HC1); h1 = hfin(hb[j] + (uint32_t)(8 * i + 1) * HC1); }
+                uint32_t h0 = 0;
+                if (P.thr) h0 = hfin(hb[j] + (uint32_t)(4 * i) * HC1);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float x = __builtin_fmaf(s[j][i][r], P.scale, nlse[j]);
@@ -590,14 +592,11 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_q_kernel(const AttnP P) {
                     }
                     const float p = fast_exp2(x);
                     float dpv = dp[j][i][r];
-                    if (P.thr) {
-                        const uint32_t hh = (r < 2) ? h0 : h1;
-                        dpv = (((r & 1) ? (hh >> 16) : (hh & 0xFFFFu)) >= P.thr) ? dpv : 0.f;
-                    }
+                    if (P.thr) dpv = (((h0 >> (8 * r)) & 0xFFu) >= P.thr) ? dpv : 0.f;
                     s[j][i][r] = p * __builtin_fmaf(dpv, P.pscale, ndelta[j]);      // dS^T[key][q] / softmax scale
                 }
             }
-            hb[j] += (uint32_t)(BT / 2) * HC1;
+            hb[j] += (uint32_t)(BT / 4) * HC1;
             pf[j][0] = ATile<T>::pfrag(s[j][0], s[j][1]);
             pf[j][1] = ATile<T>::pfrag(s[j][2], s[j][3]);
         }
@@ -623,12 +622,12 @@ void set_softmax_params(AttnP& P, float scale, float p, uint32_t seed) {
     P.scale = scale * 1.4426950408889634f;
     P.dscale = scale;
     P.lazy = 8.0f;
-    P.Th = (P.T + 1) / 2;
-    uint32_t thr = p > 0.f ? (uint32_t)(p * 65536.0f + 0.5f) : 0u;
+    P.Th = (P.T + 3) / 4;
+    uint32_t thr = p > 0.f ? (uint32_t)(p * 256.0f + 0.5f) : 0u;      // the drop probability is realised as thr / 256
     if (p > 0.f && thr == 0) thr = 1;
-    if (thr > 65535u) thr = 65535u;
+    if (thr > 255u) thr = 255u;
     P.thr = thr;
-    P.pscale = thr ? 65536.0f / (65536.0f - (float)thr) : 1.0f;      // unbiased for the realised keep probability
+    P.pscale = thr ? 256.0f / (256.0f - (float)thr) : 1.0f;            // unbiased for the realised keep probability
     P.seed = seed;
 }
 
@@ -638,17 +637,20 @@ int check_common(const char* what, int dtype, int B, int T_, int H, long long ld
     const int epc = dtype == A8_BF16 ? 8 : 4;
     A8_REQUIRE(ld_qkv % epc == 0 && ld_o % epc == 0 && ld_qkv >= (long long)H * DH && ld_o >= (long long)H * DH, "%s: bad leading dimensions", what);
     A8_REQUIRE(p >= 0.f && p < 1.f, "%s: bad dropout p", what);
-    A8_REQUIRE((long long)B * H * T_ * ((T_ + 1) / 2) < (1ll << 32), "%s: B*H*T*T/2 exceeds the dropout counter range", what);
+    A8_REQUIRE((long long)B * H * T_ * ((T_ + 3) / 4) < (1ll << 32), "%s: B*H*T*T/4 exceeds the dropout counter range", what);
     return A8_OK;
 }
 
 // launch geometry (a8_set_tuning keys 2 = forward, 3 = dK/dV, 4 = dQ): value = waves_per_block * 10 + row groups per wave
+// (+ 100 * W: the 4 x 1 geometry compiled for at least W = 4 or 5 waves per SIMD, i.e. a 128 / 96 register cap)
 #define A8_ATTN_LAUNCH(KERN, key, what)                                                                                       \
     {                                                                                                                          \
-        const int geo = g_a8_tuning[key], nw = geo / 10, grp = geo % 10, rows = nw * grp * 16;                                 \
+        const int geo = g_a8_tuning[key] % 100, mw = g_a8_tuning[key] / 100, nw = geo / 10, grp = geo % 10, rows = nw * grp * 16; \
         const dim3 grid(cdiv(T_, rows) * B * H), blk(nw * 64);                                                                 \
         if (dtype == A8_BF16) {                                                                                                \
-            if (geo == 41) hipLaunchKernelGGL((KERN<bf16, 4, 1>), grid, blk, 0, s, P);                                        \
+            if (geo == 41 && mw == 5) hipLaunchKernelGGL((KERN<bf16, 4, 1, 5>), grid, blk, 0, s, P);                          \
+            else if (geo == 41 && mw == 4) hipLaunchKernelGGL((KERN<bf16, 4, 1, 4>), grid, blk, 0, s, P);                     \
+            else if (geo == 41) hipLaunchKernelGGL((KERN<bf16, 4, 1>), grid, blk, 0, s, P);                                   \
             else if (geo == 22) hipLaunchKernelGGL((KERN<bf16, 2, 2>), grid, blk, 0, s, P);                                   \
             else if (geo == 42) hipLaunchKernelGGL((KERN<bf16, 4, 2>), grid, blk, 0, s, P);                                   \
             else return a8_set_error(A8_ERR_ARG, "%s: bad tuning %d", what, geo);                                             \

@@ -180,6 +180,82 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restric
     }
 }
 
+// ---- forward pass 3 on the matrix cores (16-bit output).  The VALU form above spends 10 of its ~27 instructions per output on
+// the taps and one on the GroupNorm affine; here both come out of ONE v_mfma_f32_16x16x32_bf16 per 16 frames x 16 channels:
+//   u[c][t] = sum_k W'[c][k] X[k][t],   32 k-slots =  x_hi . w'_hi (10)  +  x_lo . w'_hi (10)  +  x_hi . w'_lo (10)  +  1 . sh_hi + 1 . sh_lo
+// with w' = w * rstd * gamma and sh = beta - mean * rstd * gamma folded per (b, c), and every f32 operand split into two bf16
+// (hi + lo, ~16 significand bits: the x_lo . w'_lo term that is dropped is 2^-18 of a product).  What is left for the VALU is
+// the exact GELU and the pack.  Weights are the MFMA's row operand with the channels of one 64-channel super-block dealt
+// c = 64 S + 16 (i >> 2) + 4 j + (i & 3) over the rows i of its four MFMAs j, so a lane ends up with 16 CONSECUTIVE channels of one
+// frame (32 contiguous bytes of the channels-last row).
+constexpr int MFR = 256;                          // frames per block (one per thread when the images are built)
+__global__ __launch_bounds__(256) void conv0_apply_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wg,
+                                                               const float* __restrict__ gn_w, const float* __restrict__ gn_b,
+                                                               const float* __restrict__ stats, bf16* __restrict__ out, int L, int L0) {
+    __shared__ __attribute__((aligned(16))) bf16 xim[MFR][32];     // per frame: the 32 k-slots of the x operand
+    __shared__ __attribute__((aligned(16))) bf16 wim[CC][32];      // per channel: the 32 k-slots of the weight operand
+    const int b = blockIdx.y, t0 = blockIdx.x * MFR, tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6, g = lane >> 4, li = lane & 15;
+    auto split = [](float v, bf16& hi, bf16& lo) { hi = (bf16)v; lo = (bf16)(v - (float)hi); };
+    {   // x image of frame t0 + tid
+        const float* xb = x + (long long)b * L;
+        const int s0 = ST * (t0 + tid);
+        bf16 hi[KW], lo[KW];
+#pragma unroll
+        for (int k = 0; k < KW; ++k) split(s0 + k < L ? xb[s0 + k] : 0.f, hi[k], lo[k]);
+        const bf16 one = (bf16)1.0f;
+        bf16x8* row = reinterpret_cast<bf16x8*>(&xim[tid][0]);
+        row[0] = (bf16x8){hi[0], hi[1], hi[2], hi[3], hi[4], hi[5], hi[6], hi[7]};
+        row[1] = (bf16x8){hi[8], hi[9], lo[0], lo[1], lo[2], lo[3], lo[4], lo[5]};
+        row[2] = (bf16x8){lo[6], lo[7], lo[8], lo[9], hi[0], hi[1], hi[2], hi[3]};
+        row[3] = (bf16x8){hi[4], hi[5], hi[6], hi[7], hi[8], hi[9], one, one};
+    }
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {   // weight image of channels tid, tid + 256
+        const int c = tid + 256 * cc;
+        const float mu = stats[((long long)b * CC + c) * 2], rs = stats[((long long)b * CC + c) * 2 + 1];
+        const float sc = rs * gn_w[c], sh = gn_b[c] - mu * sc;
+        bf16 hi[KW], lo[KW], shh, shl;
+#pragma unroll
+        for (int k = 0; k < KW; ++k) split(wg[c * KW + k] * sc, hi[k], lo[k]);
+        split(sh, shh, shl);
+        bf16x8* row = reinterpret_cast<bf16x8*>(&wim[c][0]);
+        row[0] = (bf16x8){hi[0], hi[1], hi[2], hi[3], hi[4], hi[5], hi[6], hi[7]};
+        row[1] = (bf16x8){hi[8], hi[9], hi[0], hi[1], hi[2], hi[3], hi[4], hi[5]};
+        row[2] = (bf16x8){hi[6], hi[7], hi[8], hi[9], lo[0], lo[1], lo[2], lo[3]};
+        row[3] = (bf16x8){lo[4], lo[5], lo[6], lo[7], lo[8], lo[9], shh, shl};
+    }
+    __syncthreads();
+    // wave wv: frames t0 + 64 wv + 16 ft + li, ft = 0..3
+    bf16x8 xf[4];
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) xf[ft] = *reinterpret_cast<const bf16x8*>(&xim[64 * wv + 16 * ft + li][8 * g]);
+    const int crow = 16 * (li >> 2) + (li & 3);                    // this lane's weight row within a super-block, + 4 j
+    for (int S = 0; S < CC / 64; ++S) {
+        bf16x8 wf[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(&wim[64 * S + crow + 4 * j][8 * g]);
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) {
+            f32x4 u[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) u[j] = Mma<bf16>::mma(wf[j], xf[ft], (f32x4){0.f, 0.f, 0.f, 0.f});
+            const int t = t0 + 64 * wv + 16 * ft + li;
+            bf16x8 o0, o1;                                         // channels 64 S + 16 g + 4 j + r
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                o0[r] = (bf16)gelu_f(u[0][r]); o0[4 + r] = (bf16)gelu_f(u[1][r]);
+                o1[r] = (bf16)gelu_f(u[2][r]); o1[4 + r] = (bf16)gelu_f(u[3][r]);
+            }
+            if (t < L0) {
+                bf16* op = out + ((long long)b * L0 + t) * CC + 64 * S + 16 * g;
+                *reinterpret_cast<bf16x8*>(op) = o0;
+                *reinterpret_cast<bf16x8*>(op + 8) = o1;
+            }
+        }
+    }
+}
+
 // ---- backward: ONE pass over dout.
 // With u = gamma*xh + beta, xh = (conv - mean)*rstd, dU = dout*gelu'(u), the GroupNorm backward is
 //   dV = rstd*gamma*(dU - m1 - xh*m2),  m1 = mean_t dU, m2 = mean_t dU*xh,      dw[c][k] = sum_t dV[t] x[5t+k]
@@ -328,7 +404,9 @@ extern "C" int a8_conv0_gn_gelu_fwd(int dtype, const float* x, const float* w, c
     double* mpart = reinterpret_cast<double*>(part);          // [B][nmom][65] doubles
     hipLaunchKernelGGL(conv0_moments_kernel, dim3(nmom, B), dim3(256), 0, s, x, mpart, L, L0, nmom);
     hipLaunchKernelGGL(conv0_finalize_kernel, dim3(B), dim3(CC), 0, s, (const double*)mpart, w, stats, nmom, L0, eps);
-    if (dtype == A8_BF16)
+    if (dtype == A8_BF16 && g_a8_tuning[9] == 0)       // (a8_set_tuning key 9 = 1: the VALU form, for A/B runs)
+        hipLaunchKernelGGL(conv0_apply_mfma_kernel, dim3(cdiv(L0, MFR), B), dim3(256), 0, s, x, w, gn_w, gn_b, stats, (bf16*)out, L, L0);
+    else if (dtype == A8_BF16)
         hipLaunchKernelGGL(conv0_apply_kernel<bf16>, dim3(nchunk, B), dim3(256), 0, s, x, w, gn_w, gn_b, stats, (bf16*)out, L, L0);
     else
         hipLaunchKernelGGL(conv0_apply_kernel<float>, dim3(nchunk, B), dim3(256), 0, s, x, w, gn_w, gn_b, stats, (float*)out, L, L0);

@@ -171,12 +171,13 @@ def test_stepper_leaves_gradless_parameters_alone(restore_dtype):
                     a, bq = p.detach().cpu().numpy(), q.detach().cpu().numpy()
                     bad = np.abs(a - bq) > 2e-4 + 1e-4 * np.abs(bq)
                     assert bad.mean() < 1e-4 and np.abs(a - bq).max() <= 2.1e-2 * (step + 1), (step, k, int(bad.sum()))
-        steps = dict(zip([n for n, _ in model.named_parameters()], st.param_steps))
+        pos = {id(q): i for i, q in enumerate(st.state.params)}                 # FlatState order (q/k/v made adjacent), not module order
+        named = dict(model.named_parameters())
+        steps = {n: st.param_steps[pos[id(q)]] for n, q in named.items()}
         assert steps["proj.weight"] == 3 and steps["encoder.encoder.ln.weight"] == 1
         assert steps["encoder.feature_extractor.conv_layers.1.0.weight"] == 0
-        i = [n for n, _ in model.named_parameters()].index("encoder.feature_extractor.conv_layers.1.0.weight")
-        o = st.state.offsets[st.state.params.index(dict(model.named_parameters())["encoder.feature_extractor.conv_layers.1.0.weight"])]
-        assert float(st.state.flat_m[o:o + 100].abs().sum()) == 0.0 and i >= 0
+        o = st.state.offsets[pos[id(named["encoder.feature_extractor.conv_layers.1.0.weight"])]]
+        assert float(st.state.flat_m[o:o + 100].abs().sum()) == 0.0
         # a caller that drops the flat gradient views (model.zero_grad(set_to_none=True) instead of stepper.zero_grad()) is told so
         model.zero_grad(set_to_none=True)
         run(model).backward()

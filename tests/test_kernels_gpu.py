@@ -279,7 +279,7 @@ def _attn_ref(q, k, v, keymask, scale, drop_keep=None, p=0.0):
         s = s.masked_fill(keymask[:, None, None, :] == 0, -1e9)
     a = s.softmax(-1)
     if drop_keep is not None:
-        a = a * drop_keep / (1 - p)
+        a = a * drop_keep / (1 - round(p * 256) / 256)       # the kernels realise the drop probability in 1/256 steps
     return torch.matmul(a, v)
 
 

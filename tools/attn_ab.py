@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Attention launch-geometry / register-cap A/B at the cfg2 shape (interleaved rounds, one process).
+a8_set_tuning keys 2 (fwd), 3 (dK/dV), 4 (dQ): value = W*100 + waves*10 + groups."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from audio8_amd import _lib as L, kernels as K  # noqa: E402
+from tools.micro_bench import timeit  # noqa: E402
+
+B, T, H = 8, 781, 12
+dm = H * 64
+bf = torch.bfloat16
+qkv = (torch.randn(B * T, 3 * dm, device="cuda") * 0.5).to(bf)
+dout = torch.randn(B * T, dm, device="cuda").to(bf)
+p = 0.1
+o, lse = K.attn_fwd(qkv[:, :dm], qkv[:, dm:2 * dm], qkv[:, 2 * dm:], B, T, H, 3 * dm, 0.125, None, p=p, seed=3)
+dq = torch.empty(B * T, 3 * dm, device="cuda", dtype=bf)
+
+
+def tune(k, v):
+    L.check(L.lib().a8_set_tuning(k, v), "tune")
+
+
+def fwd():
+    return K.attn_fwd(qkv[:, :dm], qkv[:, dm:2 * dm], qkv[:, 2 * dm:], B, T, H, 3 * dm, 0.125, None, p=p, seed=3)
+
+
+def bwd():
+    return K.attn_bwd(qkv[:, :dm], qkv[:, dm:2 * dm], qkv[:, 2 * dm:], o, dout, lse, B, T, H, 3 * dm, 0.125, None, p=p, seed=3, dqkv=dq)
+
+
+ref_o = fwd()[0].clone()
+ref_d = bwd()[3].clone()
+for rnd in range(3):
+    out = []
+    for v in (41, 441, 541, 42):
+        tune(2, v)
+        assert torch.equal(fwd()[0], ref_o), v
+        out.append("fwd %d: %.1f" % (v, timeit(fwd, iters=30)))
+    tune(2, 41)
+    for kq in (41, 441):
+        for kk in (41, 441):
+            tune(4, kq); tune(3, kk)
+            assert torch.equal(bwd()[3], ref_d), (kq, kk)
+            out.append("bwd dq=%d kv=%d: %.1f" % (kq, kk, timeit(bwd, iters=30)))
+    tune(3, 41); tune(4, 41)
+    print("round %d | " % rnd + " | ".join(out), flush=True)
