@@ -188,28 +188,21 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restric
 // the exact GELU and the pack.  Weights are the MFMA's row operand with the channels of one 64-channel super-block dealt
 // c = 64 S + 16 (i >> 2) + 4 j + (i & 3) over the rows i of its four MFMAs j, so a lane ends up with 16 CONSECUTIVE channels of one
 // frame (32 contiguous bytes of the channels-last row).
-constexpr int MFR = 256;                          // frames per block (one per thread when the images are built)
+constexpr int MFR = 256;                          // frames per image build (one per thread)
+// frames per block so that the grid is (just under) one round of `slots` co-resident blocks: a multiple of 16
+static int conv0_frames_per_block(int B, int L0, int slots) {
+    const int per_utt = slots / B > 0 ? slots / B : 1;
+    const int fpb = (cdiv(L0, per_utt) + 15) / 16 * 16;
+    return fpb < 16 ? 16 : fpb;
+}
 __global__ __launch_bounds__(256) void conv0_apply_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wg,
                                                                const float* __restrict__ gn_w, const float* __restrict__ gn_b,
-                                                               const float* __restrict__ stats, bf16* __restrict__ out, int L, int L0) {
+                                                               const float* __restrict__ stats, bf16* __restrict__ out, int L, int L0, int fpb) {
     __shared__ __attribute__((aligned(16))) bf16 xim[MFR][32];     // per frame: the 32 k-slots of the x operand
     __shared__ __attribute__((aligned(16))) bf16 wim[CC][32];      // per channel: the 32 k-slots of the weight operand
-    const int b = blockIdx.y, t0 = blockIdx.x * MFR, tid = threadIdx.x;
+    const int b = blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6, g = lane >> 4, li = lane & 15;
     auto split = [](float v, bf16& hi, bf16& lo) { hi = (bf16)v; lo = (bf16)(v - (float)hi); };
-    {   // x image of frame t0 + tid
-        const float* xb = x + (long long)b * L;
-        const int s0 = ST * (t0 + tid);
-        bf16 hi[KW], lo[KW];
-#pragma unroll
-        for (int k = 0; k < KW; ++k) split(s0 + k < L ? xb[s0 + k] : 0.f, hi[k], lo[k]);
-        const bf16 one = (bf16)1.0f;
-        bf16x8* row = reinterpret_cast<bf16x8*>(&xim[tid][0]);
-        row[0] = (bf16x8){hi[0], hi[1], hi[2], hi[3], hi[4], hi[5], hi[6], hi[7]};
-        row[1] = (bf16x8){hi[8], hi[9], lo[0], lo[1], lo[2], lo[3], lo[4], lo[5]};
-        row[2] = (bf16x8){lo[6], lo[7], lo[8], lo[9], hi[0], hi[1], hi[2], hi[3]};
-        row[3] = (bf16x8){hi[4], hi[5], hi[6], hi[7], hi[8], hi[9], one, one};
-    }
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) {   // weight image of channels tid, tid + 256
         const int c = tid + 256 * cc;
@@ -225,32 +218,50 @@ __global__ __launch_bounds__(256) void conv0_apply_mfma_kernel(const float* __re
         row[2] = (bf16x8){hi[6], hi[7], hi[8], hi[9], lo[0], lo[1], lo[2], lo[3]};
         row[3] = (bf16x8){lo[4], lo[5], lo[6], lo[7], lo[8], lo[9], shh, shl};
     }
-    __syncthreads();
-    // wave wv: frames t0 + 64 wv + 16 ft + li, ft = 0..3
-    bf16x8 xf[4];
-#pragma unroll
-    for (int ft = 0; ft < 4; ++ft) xf[ft] = *reinterpret_cast<const bf16x8*>(&xim[64 * wv + 16 * ft + li][8 * g]);
+    const int tb = blockIdx.x * fpb, te = min(L0, tb + fpb);
+    const float* xb = x + (long long)b * L;
     const int crow = 16 * (li >> 2) + (li & 3);                    // this lane's weight row within a super-block, + 4 j
-    for (int S = 0; S < CC / 64; ++S) {
-        bf16x8 wf[4];
+    for (int t0 = tb; t0 < te; t0 += MFR) {
+        __syncthreads();                                           // the previous x image is no longer read (and wim is complete)
+        {   // x image of frame t0 + tid
+            const int s0 = ST * (t0 + tid);
+            bf16 hi[KW], lo[KW];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(&wim[64 * S + crow + 4 * j][8 * g]);
+            for (int k = 0; k < KW; ++k) split(s0 + k < L ? xb[s0 + k] : 0.f, hi[k], lo[k]);
+            const bf16 one = (bf16)1.0f;
+            bf16x8* row = reinterpret_cast<bf16x8*>(&xim[tid][0]);
+            row[0] = (bf16x8){hi[0], hi[1], hi[2], hi[3], hi[4], hi[5], hi[6], hi[7]};
+            row[1] = (bf16x8){hi[8], hi[9], lo[0], lo[1], lo[2], lo[3], lo[4], lo[5]};
+            row[2] = (bf16x8){lo[6], lo[7], lo[8], lo[9], hi[0], hi[1], hi[2], hi[3]};
+            row[3] = (bf16x8){hi[4], hi[5], hi[6], hi[7], hi[8], hi[9], one, one};
+        }
+        __syncthreads();
+        if (t0 + 64 * wv >= te) continue;                          // wave-uniform; barriers are outside this part
+        // wave wv: frames t0 + 64 wv + 16 ft + li, ft = 0..3
+        bf16x8 xf[4];
 #pragma unroll
-        for (int ft = 0; ft < 4; ++ft) {
-            f32x4 u[4];
+        for (int ft = 0; ft < 4; ++ft) xf[ft] = *reinterpret_cast<const bf16x8*>(&xim[64 * wv + 16 * ft + li][8 * g]);
+        for (int S = 0; S < CC / 64; ++S) {
+            bf16x8 wf[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) u[j] = Mma<bf16>::mma(wf[j], xf[ft], (f32x4){0.f, 0.f, 0.f, 0.f});
-            const int t = t0 + 64 * wv + 16 * ft + li;
-            bf16x8 o0, o1;                                         // channels 64 S + 16 g + 4 j + r
+            for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(&wim[64 * S + crow + 4 * j][8 * g]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                o0[r] = (bf16)gelu_f(u[0][r]); o0[4 + r] = (bf16)gelu_f(u[1][r]);
-                o1[r] = (bf16)gelu_f(u[2][r]); o1[4 + r] = (bf16)gelu_f(u[3][r]);
-            }
-            if (t < L0) {
-                bf16* op = out + ((long long)b * L0 + t) * CC + 64 * S + 16 * g;
-                *reinterpret_cast<bf16x8*>(op) = o0;
-                *reinterpret_cast<bf16x8*>(op + 8) = o1;
+            for (int ft = 0; ft < 4; ++ft) {
+                f32x4 u[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) u[j] = Mma<bf16>::mma(wf[j], xf[ft], (f32x4){0.f, 0.f, 0.f, 0.f});
+                const int t = t0 + 64 * wv + 16 * ft + li;
+                bf16x8 o0, o1;                                     // channels 64 S + 16 g + 4 j + r
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    o0[r] = (bf16)gelu_f(u[0][r]); o0[4 + r] = (bf16)gelu_f(u[1][r]);
+                    o1[r] = (bf16)gelu_f(u[2][r]); o1[4 + r] = (bf16)gelu_f(u[3][r]);
+                }
+                if (t < te) {
+                    bf16* op = out + ((long long)b * L0 + t) * CC + 64 * S + 16 * g;
+                    *reinterpret_cast<bf16x8*>(op) = o0;
+                    *reinterpret_cast<bf16x8*>(op + 8) = o1;
+                }
             }
         }
     }
@@ -352,6 +363,159 @@ __global__ __launch_bounds__(256) void conv0_bwd_main_kernel(const float* __rest
     if (threadIdx.x < NXR) atomicAdd(xr + (long long)b * NXR + threadIdx.x, (double)xr_s[threadIdx.x]);
 }
 
+// ---- the same backward pass on the matrix cores (16-bit dout).  Per 16 frames x 128 channels of a wave:
+//   xh  = conv~ (taps * rstd, shift -mean * rstd folded: the forward's hi/lo-split product)       8 MFMA, frames on registers
+//   dU  = dout * gelu'(gamma xh + beta);  s1 += dU;  s2 += dU xh                                    VALU (~29 instructions per element, was ~51)
+//   A[c][k] += sum_frames dU[frame][c] x[5 frame + k]                                               8 MFMA: the dU accumulators ARE the operand
+// Wave w owns channels 128 w .. 128 w + 127 (so per-(b,c) sums never cross waves); lane li of channel block j holds channel
+// 128 w + 8 li + j, i.e. 8 consecutive channels across j: one 16-byte dout load per frame.
+constexpr int BSUB = 256;                                        // frames per image rebuild
+__global__ __launch_bounds__(256, 2) void conv0_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wg,
+                                                             const float* __restrict__ gn_w, const float* __restrict__ gn_b,
+                                                             const float* __restrict__ stats, const bf16* __restrict__ dout,
+                                                             float* __restrict__ acc, double* __restrict__ xr, int L, int L0, int fpb) {
+    __shared__ __attribute__((aligned(16))) float xs[ST * BSUB + 8];
+    __shared__ __attribute__((aligned(16))) bf16 xim[BSUB][32];           // per frame: the 32 k-slots of the conv operand (as in the forward)
+    __shared__ __attribute__((aligned(16))) bf16 x2im[BSUB / 16][64][8];  // per 16-frame step and lane: x[5 frame(slot) + tap], tap = lane & 15
+    __shared__ __attribute__((aligned(16))) bf16 wim[CC][32];             // per channel: taps * rstd (hi, hi, lo), -mean * rstd (hi, lo)
+    __shared__ float xr_s[NXR];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6, g = lane >> 4, li = lane & 15;
+    auto split = [](float v, bf16& hi, bf16& lo) { hi = (bf16)v; lo = (bf16)(v - (float)hi); };
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+        const int c = tid + 256 * cc;
+        const float mu = stats[((long long)b * CC + c) * 2], rs = stats[((long long)b * CC + c) * 2 + 1];
+        bf16 hi[KW], lo[KW], shh, shl;
+#pragma unroll
+        for (int k = 0; k < KW; ++k) split(wg[c * KW + k] * rs, hi[k], lo[k]);
+        split(-mu * rs, shh, shl);
+        bf16x8* row = reinterpret_cast<bf16x8*>(&wim[c][0]);
+        row[0] = (bf16x8){hi[0], hi[1], hi[2], hi[3], hi[4], hi[5], hi[6], hi[7]};
+        row[1] = (bf16x8){hi[8], hi[9], hi[0], hi[1], hi[2], hi[3], hi[4], hi[5]};
+        row[2] = (bf16x8){hi[6], hi[7], hi[8], hi[9], lo[0], lo[1], lo[2], lo[3]};
+        row[3] = (bf16x8){lo[4], lo[5], lo[6], lo[7], lo[8], lo[9], shh, shl};
+    }
+    if (tid < NXR) xr_s[tid] = 0.f;
+    const int cbase = 128 * wv + 8 * li;                 // this lane's 8 channels (one per channel block j)
+    float gw[8], gb[8], s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { gw[j] = gn_w[cbase + j]; gb[j] = gn_b[cbase + j]; s1[j] = 0.f; s2[j] = 0.f; }
+    f32x4 accA[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) accA[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* xb = x + (long long)b * L;
+    const int tb = blockIdx.x * fpb, te = min(L0, tb + fpb);
+    for (int t0 = tb; t0 < te; t0 += BSUB) {             // block-uniform bounds
+        __syncthreads();                                 // the previous images are no longer read
+        {
+            const int s0 = ST * t0;
+            for (int i = tid; i < ST * BSUB + (KW - ST); i += 256) xs[i] = (s0 + i < L) ? xb[s0 + i] : 0.f;
+        }
+        __syncthreads();
+        const int nfr = min(BSUB, te - t0);
+        {   // images: conv operand of frame tid; tap operand of (step tid >> 6 and + 4, lane tid & 63)
+            bf16 hi[KW], lo[KW];
+#pragma unroll
+            for (int k = 0; k < KW; ++k) split(xs[ST * tid + k], hi[k], lo[k]);
+            const bf16 one = (bf16)1.0f;
+            bf16x8* row = reinterpret_cast<bf16x8*>(&xim[tid][0]);
+            row[0] = (bf16x8){hi[0], hi[1], hi[2], hi[3], hi[4], hi[5], hi[6], hi[7]};
+            row[1] = (bf16x8){hi[8], hi[9], lo[0], lo[1], lo[2], lo[3], lo[4], lo[5]};
+            row[2] = (bf16x8){lo[6], lo[7], lo[8], lo[9], hi[0], hi[1], hi[2], hi[3]};
+            row[3] = (bf16x8){hi[4], hi[5], hi[6], hi[7], hi[8], hi[9], one, one};
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const int st = (tid >> 6) + 4 * h, ln = tid & 63, gg = ln >> 4, tap = ln & 15;
+                bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {            // slot e < 4 of lane group gg <-> frame 4 gg + e of the step; slots 4 .. 7 stay zero
+                    const int fr = 16 * st + 4 * gg + e;
+                    v[e] = (tap < KW && fr < nfr) ? (bf16)xs[ST * fr + tap] : (bf16)0.f;
+                }
+                *reinterpret_cast<bf16x8*>(&x2im[st][ln][0]) = v;
+            }
+        }
+        {   // waveform moments of these frames: thread-strided, LDS atomics (65 values)
+            float sx[KW], rx[KW * (KW + 1) / 2];
+#pragma unroll
+            for (int k = 0; k < KW; ++k) sx[k] = 0.f;
+#pragma unroll
+            for (int i = 0; i < KW * (KW + 1) / 2; ++i) rx[i] = 0.f;
+            if (tid < nfr) {
+                float xv[KW];
+#pragma unroll
+                for (int k = 0; k < KW; ++k) xv[k] = xs[ST * tid + k];
+                int n = 0;
+#pragma unroll
+                for (int j = 0; j < KW; ++j) {
+                    sx[j] += xv[j];
+#pragma unroll
+                    for (int k = j; k < KW; ++k) { rx[n] = xv[j] * xv[k]; ++n; }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KW; ++k) { const float t = wave_sum(sx[k]); if (lane == 0) atomicAdd(&xr_s[k], t); }
+#pragma unroll
+            for (int i = 0; i < KW * (KW + 1) / 2; ++i) { const float t = wave_sum(rx[i]); if (lane == 0) atomicAdd(&xr_s[KW + i], t); }
+        }
+        __syncthreads();
+        bf16x8 wf[8];                                    // conv weights of this lane's 8 channels: the MFMA's column operand
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(&wim[cbase + j][8 * g]);
+        const int nstep = (nfr + 15) / 16;
+        // dout of frames 16 st + 4 g + r, channels cbase .. cbase + 7 (rows beyond the utterance read as zero); the next step's
+        // rows are requested before this step's arithmetic starts
+        auto load_dg = [&](int st, bf16x8 (&d)[4]) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int fr = 16 * st + 4 * g + r;
+                d[r] = fr < nfr ? *reinterpret_cast<const bf16x8*>(dout + ((long long)b * L0 + t0 + fr) * CC + cbase) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        };
+        bf16x8 dg[4], dn[4];
+        load_dg(0, dg);
+        for (int st = 0; st < nstep; ++st) {
+            if (st + 1 < nstep) load_dg(st + 1, dn);
+            const bf16x8 xf0 = *reinterpret_cast<const bf16x8*>(&xim[16 * st + li][8 * g]);
+            const bf16x8 x2 = *reinterpret_cast<const bf16x8*>(&x2im[st][lane][0]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                // xh[frame 4 g + r][channel cbase + j]: frames are the MFMA's rows, channels its columns
+                const f32x4 h0 = Mma<bf16>::mma(xf0, wf[j], (f32x4){0.f, 0.f, 0.f, 0.f});
+                bf16x8 du = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float d0 = (float)dg[r][j] * gelu_grad_f(fmaf(h0[r], gw[j], gb[j]));
+                    s1[j] += d0;
+                    s2[j] = fmaf(d0, h0[r], s2[j]);
+                    du[r] = (bf16)d0;
+                }
+                // A[channel 8 i + j][tap] += sum over the 16 frames (k-slots 4 .. 7 of every lane group are zero on both sides)
+                accA[j] = Mma<bf16>::mma(du, x2, accA[j]);
+                if (j & 1) __builtin_amdgcn_sched_barrier(0);      // two channel blocks in flight at a time: bounds the live registers
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dg[r] = dn[r];
+        }
+    }
+    // ---- per-(b,c) sums out: s1, s2 over the 4 lane groups (same li = same channels), A from the accumulators
+    float* ga = acc + (long long)b * CC * NACC;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float a = s1[j], q = s2[j];
+        a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+        q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+        if (g == 0) { atomicAdd(ga + (cbase + j) * NACC, a); atomicAdd(ga + (cbase + j) * NACC + 1, q); }
+        if (li < KW) {                                   // accA[j][r]: channel 128 wv + 8 (4 g + r) + j, tap li
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(ga + (128 * wv + 8 * (4 * g + r) + j) * NACC + 2 + li, accA[j][r]);
+        }
+    }
+    __syncthreads();
+    if (tid < NXR) atomicAdd(xr + (long long)b * NXR + tid, (double)xr_s[tid]);
+}
+
 // ---- finalize: dw[c][k] += sum_b rstd*gamma*(A - m1*S - m2*C); dgn_w[c] += sum_b s2; dgn_b[c] += sum_b s1
 __global__ void conv0_bwd_finalize_kernel(const float* __restrict__ wg, const float* __restrict__ gn_w, const float* __restrict__ stats,
                                           const float* __restrict__ acc, const double* __restrict__ xr,
@@ -404,8 +568,11 @@ extern "C" int a8_conv0_gn_gelu_fwd(int dtype, const float* x, const float* w, c
     double* mpart = reinterpret_cast<double*>(part);          // [B][nmom][65] doubles
     hipLaunchKernelGGL(conv0_moments_kernel, dim3(nmom, B), dim3(256), 0, s, x, mpart, L, L0, nmom);
     hipLaunchKernelGGL(conv0_finalize_kernel, dim3(B), dim3(CC), 0, s, (const double*)mpart, w, stats, nmom, L0, eps);
-    if (dtype == A8_BF16 && g_a8_tuning[9] == 0)       // (a8_set_tuning key 9 = 1: the VALU form, for A/B runs)
-        hipLaunchKernelGGL(conv0_apply_mfma_kernel, dim3(cdiv(L0, MFR), B), dim3(256), 0, s, x, w, gn_w, gn_b, stats, (bf16*)out, L, L0);
+    if (dtype == A8_BF16 && g_a8_tuning[9] == 0) {     // (a8_set_tuning key 9 = 1: the VALU form, for A/B runs)
+        const int fpb = g_a8_tuning[10] > 0 ? g_a8_tuning[10] : MFR;   // one image build per block measured best (1568 small blocks at cfg2:
+                                                                       // 133-138 us; 760 blocks sized to one resident round: 151 us)
+        hipLaunchKernelGGL(conv0_apply_mfma_kernel, dim3(cdiv(L0, fpb), B), dim3(256), 0, s, x, w, gn_w, gn_b, stats, (bf16*)out, L, L0, fpb);
+    }
     else if (dtype == A8_BF16)
         hipLaunchKernelGGL(conv0_apply_kernel<bf16>, dim3(nchunk, B), dim3(256), 0, s, x, w, gn_w, gn_b, stats, (bf16*)out, L, L0);
     else
@@ -428,7 +595,11 @@ extern "C" int a8_conv0_gn_gelu_bwd(int dtype, const float* x, const float* w, c
     static_assert(NXR == 65 && NACC == 12, "keep A8_CONV0_BWD_SCRATCH_FLOATS in a8hip.h in sync");
     if (hipMemsetAsync(red, 0, sizeof(float) * A8_CONV0_BWD_SCRATCH_FLOATS(B), s) != hipSuccess)
         return a8_set_error(A8_ERR_LAUNCH, "a8_conv0_gn_gelu_bwd: memset failed");
-    if (dtype == A8_BF16)
+    if (dtype == A8_BF16 && g_a8_tuning[9] == 0) {
+        const int fpb = conv0_frames_per_block(B, L0, 512);        // 256 registers: two blocks per CU
+        hipLaunchKernelGGL(conv0_bwd_mfma_kernel, dim3(cdiv(L0, fpb), B), dim3(256), 0, s, x, w, gn_w, gn_b, stats, (const bf16*)dout, acc, xr, L, L0, fpb);
+    }
+    else if (dtype == A8_BF16)
         hipLaunchKernelGGL(conv0_bwd_main_kernel<bf16>, dim3(nchunk, B), dim3(256), 0, s, x, w, gn_w, gn_b, stats, (const bf16*)dout, acc, xr, L, L0);
     else
         hipLaunchKernelGGL(conv0_bwd_main_kernel<float>, dim3(nchunk, B), dim3(256), 0, s, x, w, gn_w, gn_b, stats, (const float*)dout, acc, xr, L, L0);
