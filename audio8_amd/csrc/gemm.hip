@@ -574,6 +574,139 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs g) {
     }
 }
 
+// ---- full-width tile for the conv layers (NT, N a multiple of 512, K a multiple of 64): one block computes 128 rows x ALL 512 columns,
+// so every A row (the 0.4 GB conv activations) is fetched from HBM exactly once -- with 128-column tiles the four blocks that share a
+// row panel drift apart in K and the panel is re-fetched (2.3x measured on conv layer 1); the 1.5 MB weight matrix streams from L2.
+// 8 waves of 64 x 128 (0.375 KB of fragment reads and 0.16 LDS-DMA instructions per MFMA), one PERSISTENT block per CU walking its row
+// panels; k-tiles of 64 (128-byte LDS rows: whole cache lines per DMA row) through a 2-deep ring (2 x 80 KB: all of the LDS) that keeps
+// running ACROSS tiles: the DMAs of the next tile's first k-tile are in flight while this tile's accumulators go through the
+// epilogue (straight from registers, no LDS).  Walks K in the order of the default kernel (bit-identical results).
+template <typename T>
+__global__ __launch_bounds__(512, 2) void gemm_w512_kernel(const GemmArgs g) {
+    static_assert(sizeof(T) == 2, "16-bit operands");
+    typedef Mma<T> MM;
+    constexpr int KROW = 128, TA = 128 * KROW, TB = 512 * KROW, STAGE = TA + TB, SZ = 2;
+    __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6), wr = w >> 2, wc = w & 3;
+    const int nk = g.K / 64, ntiles = g.tiles_m * g.tiles_n;
+
+    // LDS-DMA sources: a piece = 8 rows x 128 B; lane -> row lane >> 3, 16-byte slot lane & 7 holding k-chunk slot ^ (row & 7)
+    const int prow = lane >> 3, pch = ((lane & 7) ^ prow) << 4;          // (piece rows start at multiples of 8: row & 7 = lane >> 3)
+    unsigned a_off[2] = {0, 0}, b_off[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto tile_offsets = [&](int tile) {
+        const int m0 = (tile / g.tiles_n) * 128, n0 = (tile % g.tiles_n) * 512;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) a_off[j] = (unsigned)(outer_off(g.A, min(m0 + 8 * (w + 8 * j) + prow, g.M - 1)) * SZ + pch);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b_off[j] = (unsigned)((long long)(n0 + 8 * (w + 8 * j) + prow) * g.B.ld * SZ + pch);
+    };
+    // producer cursor: (ptile, pk) = the k-tile the next issue() stages; it runs one k-tile ahead of the consumer, across tiles
+    int ptile = blockIdx.x, pk = 0, pslot = 0;
+    if (ptile < ntiles) tile_offsets(ptile);
+    auto issue = [&]() {
+        if (ptile >= ntiles) return;
+        char* ta = lds + pslot * STAGE;
+        char* tb = ta + TA;
+        const unsigned ko = (unsigned)pk * KROW;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16(g.A.p + (a_off[j] + ko), ta + (w + 8 * j) * 1024);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) glds16(g.B.p + (b_off[j] + ko), tb + (w + 8 * j) * 1024);
+        pslot ^= 1;
+        if (++pk == nk) {
+            pk = 0;
+            ptile += gridDim.x;
+            if (ptile < ntiles) tile_offsets(ptile);
+        }
+    };
+    auto frag = [&](const char* tl, int rb, int ks) {      // 16 rows x 32 k: lane & 15 = row, lane >> 4 = 16-byte chunk of the k-step
+        const int row = rb + (lane & 15);
+        return *reinterpret_cast<const typename MM::Frag*>(tl + row * KROW + (((ks * 4 + (lane >> 4)) ^ (row & 7)) << 4));
+    };
+    typedef T T4 __attribute__((ext_vector_type(4)));
+    auto zrow = [&](int m) -> long long { return g.z_rpb ? (m / g.z_rpb) * g.z_bs + (m % g.z_rpb) * g.ldz : (long long)m * g.ldz; };
+
+    issue();
+    int cslot = 0;
+    int stores_pending = 0;                                // the previous tile's epilogue stores (1: 32 of them, 2: 64) are younger than the DMAs waited for
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int m0 = (tile / g.tiles_n) * 128, n0 = (tile % g.tiles_n) * 512;
+        f32x4 acc[4][8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < nk; ++kt) {
+            // this k-tile's 10 DMAs are the oldest outstanding operations; right after an epilogue its stores (exactly 32, or 64 with zout,
+            // when no row was skipped) are younger and need not be waited for.  vmcnt counts DMAs and stores together, in issue order;
+            // its range ends at 63, where "all but 63" of 74 still covers the 10 DMAs.
+            if (kt == 0 && stores_pending == 2) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+            else if (kt == 0 && stores_pending == 1) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            issue();                                       // refills the slot every wave finished reading in the previous k-tile
+            const char* ta = lds + cslot * STAGE;
+            const char* tb = ta + TA;
+            cslot ^= 1;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                typename MM::Frag fa[4], fb[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[i] = frag(ta, 64 * wr + 16 * i, ks);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) fb[j] = frag(tb, 128 * wc + 16 * j, ks);
+                // swapped operands: accumulator register r <-> 4 consecutive n, lane & 15 <-> m
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[i][j] = MM::mma(fb[j], fa[i], acc[i][j]);
+            }
+        }
+        // ---- epilogue straight from the accumulators: register r of acc[i][j] is column 16 j + 4 (lane >> 4) + r of row 16 i + (lane & 15)
+        const int li = lane & 15, c4 = 4 * (lane >> 4);
+        const bool full = m0 + 64 * wr + 64 <= g.M;        // wave-uniform: every store below executes
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + 64 * wr + 16 * i + li;
+            if (m >= g.M) continue;
+            const long long crow = g.c_rpb ? (m / g.c_rpb) * g.c_bs + (m % g.c_rpb) * g.ldc : (long long)m * g.ldc;
+            const long long zr = (g.zout || g.zin) ? zrow(m) : 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int n = n0 + 128 * wc + 16 * j + c4;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * g.alpha;
+                if (g.zout) {
+                    T4 zv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) zv[e] = from_f<T>(v[e]);
+                    *reinterpret_cast<T4*>(reinterpret_cast<T*>(g.zout) + zr + n) = zv;
+                }
+                if (g.act == A8_ACT_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+                } else if (g.act == A8_ACT_MUL_GELU_GRAD) {
+                    const T4 zz = *reinterpret_cast<const T4*>(reinterpret_cast<const T*>(g.zin) + zr + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(to_f(zz[e]));
+                } else if (g.act == A8_ACT_ADD) {
+                    const T4 zz = *reinterpret_cast<const T4*>(reinterpret_cast<const T*>(g.zin) + zr + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += to_f(zz[e]);
+                }
+                T4 ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] = from_f<T>(v[e]);
+                *reinterpret_cast<T4*>(reinterpret_cast<T*>(g.C) + crow + n) = ov;
+            }
+        }
+        // tail waves (rows skipped: fewer stores) and epilogues that load zin (the compiler drains for the loaded values) wait for everything
+        stores_pending = (full && !g.zin) ? (g.zout ? 2 : 1) : 0;
+    }
+}
+
 template <typename T, bool AKS, bool BKS, int KB, int NST, int NWM>
 __global__ __launch_bounds__(128 * NWM, NWM == 5 ? 3 : (KB == 1 && NST == 2) ? 4 : (NST * 2 * 8192 * KB <= 65536) ? NWM : NWM / 2) void gemm_kernel(const GemmArgs g) {
     gemm_body<T, AKS, BKS, KB, NST, NWM>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n * g.nsplit));
@@ -688,6 +821,20 @@ extern "C" int a8_gemm(const a8_gemm_desc* d, void* stream) {
         if ((long long)tm * tn >= g_a8_tuning[5] && a_span < (1ll << 32) && b_span < (1ll << 32)) {
             g.tiles_m = tm; g.tiles_n = tn;
             hipLaunchKernelGGL(gemm_p256_kernel<bf16>, dim3(tm * tn), dim3(512), 0, s, g);
+            return a8_check_launch("a8_gemm");
+        }
+    }
+    // Full-width persistent tiles for the conv GEMMs (a8_set_tuning key 11 = minimum M; 0 = off)
+    if (d->dtype == A8_BF16 && d->layout == A8_GEMM_NT && g_variant == 5 && g_a8_tuning[11] > 0 && d->M >= g_a8_tuning[11] && d->N % 512 == 0 &&
+        d->K % 64 == 0 && d->K >= 64 && !d->out_f32 && !d->bias && !d->colsum && g.nsplit == 1 && !g.atomic && d->ldc % 4 == 0 && d->ldz % 4 == 0 &&
+        ((uintptr_t)d->C % 8) == 0 && ((uintptr_t)d->zout % 8) == 0 && ((uintptr_t)d->zin % 8) == 0) {
+        const long long a_span = ((d->a_rpb ? (long long)((d->M - 1) / d->a_rpb) * d->a_bs + (long long)((d->M - 1) % d->a_rpb) * d->lda
+                                            : (long long)(d->M - 1) * d->lda) + d->K) * 2;
+        const long long b_span = ((long long)(d->N - 1) * d->ldb + d->K) * 2;
+        if (a_span < (1ll << 32) && b_span < (1ll << 32)) {
+            g.tiles_m = cdiv(d->M, 128); g.tiles_n = d->N / 512;
+            const int nt = g.tiles_m * g.tiles_n;
+            hipLaunchKernelGGL(gemm_w512_kernel<bf16>, dim3(nt < 256 ? nt : 256), dim3(512), 0, s, g);
             return a8_check_launch("a8_gemm");
         }
     }

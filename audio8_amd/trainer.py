@@ -163,7 +163,17 @@ class GradReducer:
         # a rehearsal of the N > 1 code on a one-GPU box (an all-reduce over one rank leaves the data unchanged)
         self.enabled = self.world > 1 or (dist.is_initialized() and os.environ.get("A8_FORCE_REDUCER", "0") == "1")
         self.on_gpu = state.flat_g.is_cuda
-        self.side = torch.cuda.Stream() if (self.enabled and self.on_gpu) else None
+        self.side = torch.cuda.Stream() if self.on_gpu else None     # exchange + per-bucket gradient-norm stream
+        # RCCL enqueues a collective on the stream it is issued from, so kernels behind it on that stream see the reduced data;
+        # gloo (CPU rehearsals of the GPU path) completes on its own threads: only wait() orders it
+        self.stream_ordered = True
+        if self.enabled:
+            try:
+                self.stream_ordered = dist.get_backend(process_group) == "nccl"
+            except Exception:                # (a stubbed collective in tests: runs on the issuing stream)
+                pass
+        self.norm_sq = None                  # f32 [1] device accumulator of sum g^2 (set by the Stepper): each bucket adds its share as it
+                                             # completes (after its all-reduce), under the rest of backward
         cap = int(bucket_mb * 1024 * 1024 / 4)
         # buckets over contiguous flat ranges; built from the LAST parameter backwards (gradients of late
         # layers are ready first), each bucket = [lo, hi) in elements plus the parameter indices it holds
@@ -214,7 +224,7 @@ class GradReducer:
         if not self.touched[i]:
             self.touched[i] = True
             self.n_touched += 1
-        if not self.enabled or self.suspended:
+        if self.suspended or not (self.enabled or self.norm_sq is not None):
             return
         # idempotent per backward pass: a parameter whose gradient a backward kernel wrote directly is reported through
         # ops.GRAD_READY_HOOK, and autograd's post-accumulate hook fires for it as well (with an undefined gradient);
@@ -244,6 +254,7 @@ class GradReducer:
 
     def _launch(self, bk):
         view = self.state.flat_g[bk["lo"]:bk["hi"]]
+        h = None
         if self.on_gpu:
             # the bucket's gradients were enqueued on the compute stream and/or the wgrad side stream, and this call may
             # come from either context (the last parameter of a bucket decides): wait for all of them
@@ -259,10 +270,14 @@ class GradReducer:
                 ev.record(st)
                 self.side.wait_event(ev)
             with torch.cuda.stream(self.side):
-                h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-        else:                                            # gloo on CPU (tests): same bucket schedule, no streams
+                if self.enabled:
+                    h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                if self.norm_sq is not None and self.stream_ordered:      # stream order: behind this bucket's collective
+                    K.sumsq_(view, self.norm_sq)
+        elif self.enabled:                               # gloo on CPU (tests): same bucket schedule, no streams
             h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-        self.handles.append(h)
+        if h is not None:
+            self.handles.append(h)
         bk["launched"] = True
 
     def begin_pass(self):
@@ -298,8 +313,9 @@ class GradReducer:
 
     def finish(self):
         """Issue any bucket whose parameters produced no gradient this step (frozen encoder, audio8/train.py:266-268),
-        then make the compute stream wait for the exchange.  Gradients hold the SUM over ranks afterwards."""
-        if not self.enabled:
+        then make the compute stream wait for the exchange.  Gradients hold the SUM over ranks afterwards (and norm_sq
+        the sum of their squares)."""
+        if not (self.enabled or self.norm_sq is not None):
             return
         for bk in self.buckets[self.next_bucket:]:       # in index order, like the ones already out
             if not bk.get("launched"):
@@ -309,6 +325,8 @@ class GradReducer:
             h.wait()
         if self.on_gpu:
             torch.cuda.current_stream().wait_stream(self.side)
+            if self.norm_sq is not None and not self.stream_ordered:
+                K.sumsq_(self.state.flat_g, self.norm_sq)         # (gloo rehearsals: the reduced values exist only after wait())
 
 
 ACTIVE_STEPPER = None        # the Stepper that currently owns audio8_amd.ops' global hooks (driver.PassThroughDDP.no_sync finds it here)
@@ -338,6 +356,8 @@ class Stepper:
         self.param_steps = [0] * len(self.state.params)
         self._uniform_steps = True
         self.gnorm_sq = torch.zeros(1, device=self.state.flat_p.device, dtype=torch.float32)
+        if self.state.flat_p.is_cuda and os.environ.get("A8_BUCKET_NORM", "1") != "0":
+            self.reducer.norm_sq = self.gnorm_sq         # sum g^2 accumulated bucket by bucket under backward (no 380 MB pass at the end)
         self._grads_clean = False
         self._grad_ptrs = [self.state.flat_g.data_ptr() + 4 * o for o in self.state.offsets]
         ops.DIRECT_GRADS = True
@@ -370,6 +390,8 @@ class Stepper:
             self.refresh_weights()                        # someone wrote to a parameter through torch since the last step
         self.state.zero_grad(already_clean=self._grads_clean)     # step() cleared the buffer behind its read
         self._grads_clean = False
+        if self.reducer.norm_sq is not None:
+            self.gnorm_sq.zero_()
         self.reducer.begin_step()
 
     @contextlib.contextmanager
@@ -443,8 +465,9 @@ class Stepper:
         self.reducer.finish()
         self.global_step += 1
         scale = 1.0 if counts is not None else 1.0 / self.reducer.world
-        self.gnorm_sq.zero_()
-        K.sumsq_(st.flat_g, self.gnorm_sq)
+        if self.reducer.norm_sq is None:
+            self.gnorm_sq.zero_()
+            K.sumsq_(st.flat_g, self.gnorm_sq)
         lr = self.current_lr
         for lo, hi, nstep in self._active_runs():
             K.adamw_(st.flat_p[lo:hi], st.flat_g[lo:hi], st.flat_m[lo:hi], st.flat_v[lo:hi], lr, self.betas[0], self.betas[1],

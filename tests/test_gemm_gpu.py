@@ -225,21 +225,25 @@ def test_gemm_160_row_tiles_match_default(depth):
         torch.testing.assert_close(c0, c1, rtol=1e-4, atol=1e-2)       # (column sums combine in a different block order)
 
 
-def test_gemm_pipelined_256_kernel_matches_default():
-    """The pipelined 256 x 256 NT kernel (a8_set_tuning key 5; N % 256 == 0, K % 64 == 0, no bias / column sums) walks K in
-    the same order as the default kernel: outputs must be bit-identical across M tails, single and odd k-tile counts, the
-    conv row remaps on A, C and z, and each epilogue it carries; ineligible problems must fall through to the default."""
+@pytest.mark.parametrize("key", [5, 11, 8])
+def test_gemm_pipelined_256_kernel_matches_default(key):
+    """The alternative NT kernels -- pipelined 256 x 256 (a8_set_tuning key 5; N % 256 == 0, K % 64 == 0), full-width persistent
+    128 x 512 (key 11; N % 512 == 0, K % 64 == 0) and the tall 192-row tile (key 8 = 3); none carries a bias / column
+    sums except the tall one -- walk K in the same order as the default kernel: outputs must be bit-identical across M tails,
+    single and odd k-tile counts, the conv row remaps on A, C and z, and each epilogue; ineligible problems must fall through."""
     from audio8_amd import kernels as Kn, _lib as L
     dev, bf = "cuda", torch.bfloat16
+    saved = {5: 0, 11: 0, 8: 0}
 
     def both(fn):
-        L.check(L.lib().a8_set_tuning(5, 0), "tune")
+        for k_, v_ in saved.items():
+            L.check(L.lib().a8_set_tuning(k_, v_), "tune")
         ref = fn()
-        L.check(L.lib().a8_set_tuning(5, 1), "tune")
+        L.check(L.lib().a8_set_tuning(key, 3 if key == 8 else 1), "tune")
         try:
             got = fn()
         finally:
-            L.check(L.lib().a8_set_tuning(5, 0), "tune")
+            L.check(L.lib().a8_set_tuning(key, saved[key]), "tune")
         return ref, got
 
     def same(ref, got, what):
@@ -247,6 +251,7 @@ def test_gemm_pipelined_256_kernel_matches_default():
             assert torch.equal(r, g_), what
 
     for (M, N, K) in [(781, 768, 512), (256, 256, 64), (300, 512, 2048), (6248, 768, 768), (1000, 256, 192), (33, 512, 320),
+                      (40000, 512, 1536), (129, 1024, 96), (4133, 512, 1024),      # several tiles per persistent block, 2 column tiles
                       (1000, 264, 72), (300, 136, 2056)]:                  # the last two are not eligible
         A, B = _mk((M, K), bf, 1).to(dev), _mk((N, K), bf, 2).to(dev)
         same(*both(lambda: (Kn.gemm(L.NT, A, B, M, N, K),)), ("plain", M, N, K))
