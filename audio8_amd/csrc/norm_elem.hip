@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
     if (threadIdx.x == 0) atomicAdd(out, s);
 }
 
-__global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                              long long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s,
                              const float* __restrict__ gnorm_sq, float max_norm, float grad_scale, const long long* __restrict__ grad_denom,
                              int zero_grad) {
@@ -465,15 +465,32 @@ __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float
         const float nrm = sqrtf(gnorm_sq[0]) * grad_scale;
         clip *= fminf(1.0f, max_norm / (nrm + 1e-6f));     // torch.nn.utils.clip_grad_norm_
     }
-    const float step = lr / bc1;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const float gi = g[i] * clip;
-        if (zero_grad) g[i] = 0.f;                      // the next step accumulates into a clean buffer: no separate fill pass
-        const float mi = b1 * m[i] + (1.f - b1) * gi;
-        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-        m[i] = mi; v[i] = vi;
-        const float pi = p[i] * (1.f - lr * wd);
-        p[i] = pi - step * mi / (sqrtf(vi) / bc2s + eps);
+    const float step = lr / bc1, decay = 1.f - lr * wd;
+    auto upd = [&](float& pi, float& gi, float& mi, float& vi) {
+        const float gc = gi * clip;
+        mi = b1 * mi + (1.f - b1) * gc;
+        vi = b2 * vi + (1.f - b2) * gc * gc;
+        pi = pi * decay - step * mi / (sqrtf(vi) / bc2s + eps);
+        if (zero_grad) gi = 0.f;                           // the next step accumulates into a clean buffer: no separate fill pass
+    };
+    // 16 bytes per lane (the four flat buffers are 16-byte aligned and every range handed in starts on a multiple of 4 elements)
+    const long long n4 = n >> 2;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        f32x4 P = reinterpret_cast<f32x4*>(p)[i], G = reinterpret_cast<f32x4*>(g)[i], M = reinterpret_cast<f32x4*>(m)[i], V = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float pe = P[e], ge = G[e], me = M[e], ve = V[e];
+            upd(pe, ge, me, ve);
+            P[e] = pe; G[e] = ge; M[e] = me; V[e] = ve;
+        }
+        reinterpret_cast<f32x4*>(p)[i] = P;
+        reinterpret_cast<f32x4*>(m)[i] = M;
+        reinterpret_cast<f32x4*>(v)[i] = V;
+        if (zero_grad) reinterpret_cast<f32x4*>(g)[i] = G;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long long i = n4 * 4 + threadIdx.x;
+        upd(p[i], g[i], m[i], v[i]);
     }
 }
 
@@ -639,7 +656,9 @@ extern "C" int a8_adamw(float* p, float* g, float* m, float* v, int64_t n, float
     if (n == 0) return A8_OK;
     const float bc1 = 1.0f - powf(beta1, (float)step);
     const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n, lr, beta1, beta2, eps,
+    A8_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0,
+               "a8_adamw: buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4 + 1, 512)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n, lr, beta1, beta2, eps,
                        weight_decay, bc1, bc2s, gnorm_sq, max_norm, grad_scale, (const long long*)grad_denom, zero_grad);
     return a8_check_launch("a8_adamw");
 }

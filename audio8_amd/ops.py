@@ -219,26 +219,34 @@ def acc_wgrad(p, dy, x, n_out, n_in, m, **kw):
 # The four weight-gradient products of an encoder layer as ONE grouped launch at the end of the layer's backward:
 # 432 output tiles fill the chip without split-K (each alone needs a 3-12 way split + f32 atomics to do so).
 GROUP_WGRAD = True
+# q/k/v bias column sums and the positional conv's weight-gradient chain also go to the side stream (A/B knob)
+SIDE_EXTRAS = True
 
 
 class WgradGroup:
-    """Collects (params, target, dy, x, n_out, n_in, m) and issues them together on the side stream."""
+    """Collects (params, target, dy, x, n_out, n_in, m) and issues them together on the side stream, followed by any other
+    parameter-gradient work of the layer that feeds nothing downstream (`extra` callables, e.g. the q/k/v bias column sums)."""
 
     def __init__(self):
         self.items = []
+        self.extra = []
 
     def add(self, params, tgt, dy, x, n_out, n_in, m):
         self.items.append((params, tgt, dy, x, n_out, n_in, m))
 
     def flush(self):
-        if not self.items:
+        if not self.items and not self.extra:
             return
         items, self.items = self.items, []
+        extra, self.extra = self.extra, []
 
         def run():
-            K.gemm_grouped(L.TN, [(dy, x, n_out, n_in, m, dict(out=tgt, accumulate=True)) for _, tgt, dy, x, n_out, n_in, m in items])
-            for params, *_ in items:
-                _ready(*params)
+            if items:
+                K.gemm_grouped(L.TN, [(dy, x, n_out, n_in, m, dict(out=tgt, accumulate=True)) for _, tgt, dy, x, n_out, n_in, m in items])
+                for params, *_ in items:
+                    _ready(*params)
+            for fn in extra:
+                fn()
         _on_side(run, *[t for it in items for t in (it[2], it[3])])
 
 
@@ -660,16 +668,24 @@ class PosConvFn(torch.autograd.Function):
             dbias = None
         dxc, _ = K.posconv_fwd(dz, wt, None, G, k, k - 1 - ctx.pad_left, -1)
         dx = K.add(dy, dxc)
-        dwg = torch.zeros((G, dg, k, dg), device=x.device, dtype=torch.float32)
-        K.posconv_wgrad(x, dz, dwg, G, k, ctx.pad_left)
         tv, tg = _target(pv), _target(pg)
         direct = tv is not None and tg is not None
         dv = tv if direct else torch.zeros(pv.shape, device=x.device, dtype=torch.float32)
         dgain = tg if direct else torch.zeros(pg.shape, device=x.device, dtype=torch.float32)
-        K.weightnorm_bwd_(dwg, pv.detach(), pg.detach(), inv_norm, dv, dgain, G)
-        if direct:
-            _ready(pv, pg)
+
+        def wgrad_chain():
+            dwg = torch.zeros((G, dg, k, dg), device=x.device, dtype=torch.float32)
+            K.posconv_wgrad(x, dz, dwg, G, k, ctx.pad_left)
+            K.weightnorm_bwd_(dwg, pv.detach(), pg.detach(), inv_norm, dv, dgain, G)
+            if direct:
+                _ready(pv, pg)
+        if direct and SIDE_EXTRAS:               # feeds nothing downstream: beside the data-gradient chain, on the side stream
+            _on_side(wgrad_chain, x, dz, inv_norm)
             dv = dgain = None
+        else:
+            wgrad_chain()
+            if direct:
+                dv = dgain = None
         return dx, dv, dgain, dbias, None, None
 
 
@@ -797,9 +813,17 @@ class EncoderLayerFn(torch.autograd.Function):
         _, _, _, dqkv = K.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, do, lse, B, T, H, 3 * d, 1.0 / math.sqrt(d // H),
                                    keymask, p, seed_a, dbias=_span3(tb[0], (3 * d,)) if (direct_qkv and ATTN_BIAS_FUSED) else None)
         if direct_qkv:
-            if not ATTN_BIAS_FUSED:
-                colsum(dqkv, _span3(tb[0], (3 * d,)))
-            _ready(bq, bk, bv)
+            bspan = _span3(tb[0], (3 * d,))
+            if ATTN_BIAS_FUSED:
+                _ready(bq, bk, bv)
+            elif wg is not None and SIDE_EXTRAS:     # off the critical path: with the grouped weight gradients on the side stream
+                def bias_colsum(dqkv=dqkv, bspan=bspan, ps=(bq, bk, bv)):
+                    colsum(dqkv, bspan)
+                    _ready(*ps)
+                wg.extra.append(bias_colsum)
+            else:
+                colsum(dqkv, bspan)
+                _ready(bq, bk, bv)
             wspan = _span3(tw[0], (3 * d, d))
             if wg is not None:
                 wg.add((wq, wk, wv), wspan, dqkv, x, 3 * d, d, M)

@@ -356,7 +356,7 @@ class Stepper:
         self.param_steps = [0] * len(self.state.params)
         self._uniform_steps = True
         self.gnorm_sq = torch.zeros(1, device=self.state.flat_p.device, dtype=torch.float32)
-        if self.state.flat_p.is_cuda and os.environ.get("A8_BUCKET_NORM", "1") != "0":
+        if self.state.flat_p.is_cuda and os.environ.get("A8_BUCKET_NORM", "0") != "0":
             self.reducer.norm_sq = self.gnorm_sq         # sum g^2 accumulated bucket by bucket under backward (no 380 MB pass at the end)
         self._grads_clean = False
         self._grad_ptrs = [self.state.flat_g.data_ptr() + 4 * o for o in self.state.offsets]

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Same-process, interleaved A/B of the full bench step under developer knobs (box-to-box and run-to-run noise on this pool is
+several per cent; only interleaved rounds in one process separate 1 % effects).
+usage: step_ab.py "name:key=val,key=val;name2:..."   keys: integers = a8_set_tuning keys; bucketnorm, sidewgrad, groupwgrad = 0/1"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from audio8_amd import _lib as L, ops, wav2vec2 as W  # noqa: E402
+from audio8_amd.trainer import Stepper  # noqa: E402
+
+DEFAULTS = {0: 5, 1: 802, 2: 41, 3: 41, 4: 41, 5: 0, 6: 3, 7: 0, 8: 0, 9: 0, 10: 0, 11: 0}
+cfgs = []
+for part in (sys.argv[1] if len(sys.argv) > 1 else "base:").split(";"):
+    name, _, kv = part.partition(":")
+    d = {}
+    for item in filter(None, kv.split(",")):
+        k, v = item.split("=")
+        d[int(k) if k.isdigit() else k] = int(v)
+    cfgs.append((name, d))
+ops.set_compute_dtype(torch.bfloat16)
+torch.manual_seed(0)
+np.random.seed(0)
+model = W.create_model(16).cuda().train()
+loss_fn = W.create_loss(640, 100)
+st = Stepper(model)
+x = (0.1 * torch.randn(8, 250000, generator=torch.Generator().manual_seed(1234))).clamp_(-1, 1).cuda()
+side = st.wgrad_stream
+
+
+def apply(d):
+    for k, v in DEFAULTS.items():
+        L.check(L.lib().a8_set_tuning(k, d.get(k, v)), "tune")
+    st.reducer.norm_sq = st.gnorm_sq if d.get("bucketnorm", 0) else None
+    ops.WGRAD_SIDE_STREAM = side if d.get("sidewgrad", 1) else None
+    ops.GROUP_WGRAD = bool(d.get("groupwgrad", 1))
+    ops.CONV_CHUNK_UTTS = d.get("convchunk", 0)
+    ops.SIDE_EXTRAS = bool(d.get("sidex", 1))
+
+
+def step():
+    st.zero_grad()
+    loss = loss_fn(model, x)
+    loss.backward()
+    W.prefetch_host_draws(model, loss_fn, x.shape)
+    v = loss.item()
+    st.step()
+    return v
+
+
+res = {n: [] for n, _ in cfgs}
+nsteps = int(os.environ.get("AB_STEPS", "8"))
+for rnd in range(int(os.environ.get("AB_ROUNDS", "5"))):
+    for name, d in cfgs:
+        apply(d)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            step()
+        torch.cuda.synchronize()
+        res[name].append((time.perf_counter() - t0) / nsteps * 1e3)
+    print("round %d: " % rnd + "  ".join("%s %.3f" % (n, res[n][-1]) for n, _ in cfgs), flush=True)
+print("median ms/step: " + "  ".join("%s %.3f (min %.3f)" % (n, float(np.median(res[n])), min(res[n])) for n, _ in cfgs))
+apply({})
