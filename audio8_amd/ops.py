@@ -576,13 +576,18 @@ class ConvStackFn(torch.autograd.Function):
                     assert pad == 1
                     b_even, b_odd = CONV_DGRAD_CACHE[id(ws[i])]
                     # even positions p = 2t, t = 0..Lout: rows [dz[t-1] | dz[t]] of the zero-padded dz (K = 2 co)
-                    K.gemm(L.NT, dz, b_even, nb * (Lout + 1), cin, 2 * co, out=dx, lda=co, a_rpb=Lout + 1, a_bs=dzrows * co,
-                           ldc=2 * cin, c_off=npad * cin, c_rpb=Lout + 1, c_bs=prow * cin, act=act,
-                           **(dict(zk, z_rpb=Lout + 1) if zk else {}))
+                    even = (dz, b_even, nb * (Lout + 1), cin, 2 * co,
+                            dict(out=dx, lda=co, a_rpb=Lout + 1, a_bs=dzrows * co, ldc=2 * cin, c_off=npad * cin, c_rpb=Lout + 1, c_bs=prow * cin,
+                                 act=act, **(dict(zk, z_rpb=Lout + 1) if zk else {})))
                     # odd positions p = 2t + 1, t = 0..Lout-1
-                    K.gemm(L.NT, dz, b_odd, M, cin, co, out=dx, lda=co, a_off=co, a_rpb=Lout, a_bs=dzrows * co,
-                           ldc=2 * cin, c_off=(npad + 1) * cin, c_rpb=Lout, c_bs=prow * cin, act=act,
-                           **(dict(zk, z_rpb=Lout, z_off=cin) if zk else {}))
+                    odd = (dz, b_odd, M, cin, co,
+                           dict(out=dx, lda=co, a_off=co, a_rpb=Lout, a_bs=dzrows * co, ldc=2 * cin, c_off=(npad + 1) * cin, c_rpb=Lout, c_bs=prow * cin,
+                                act=act, **(dict(zk, z_rpb=Lout, z_off=cin) if zk else {})))
+                    if CONV_DGRAD_GROUPED:               # one grid for both halves: no tail / ramp between two half-size launches
+                        K.gemm_grouped(L.NT, [even, odd])
+                    else:
+                        for A_, B_, m_, n_, k_, kw_ in (even, odd):
+                            K.gemm(L.NT, A_, B_, m_, n_, k_, **kw_)
                 dz, pad = dx, npad
             return dz, pad
 
@@ -616,6 +621,8 @@ class ConvStackFn(torch.autograd.Function):
 # while it is still resident in the 256 MB Infinity Cache; the remaining (small) layers run on the whole batch.  0 = off.
 CONV_CHUNK_UTTS = 0
 CONV_CHUNK_LAYERS = 3
+# even / odd halves of a k = 3, stride 2 conv data gradient as ONE grouped launch (A/B knob)
+CONV_DGRAD_GROUPED = True
 
 
 def _conv_chunking(B, nl):

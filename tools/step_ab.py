@@ -40,6 +40,7 @@ def apply(d):
     ops.GROUP_WGRAD = bool(d.get("groupwgrad", 1))
     ops.CONV_CHUNK_UTTS = d.get("convchunk", 0)
     ops.SIDE_EXTRAS = bool(d.get("sidex", 1))
+    ops.CONV_DGRAD_GROUPED = bool(d.get("dgroup", 1))
 
 
 def step():
