@@ -29,7 +29,7 @@ struct GemmArgs {
     const float* bias;
     float* colsum;
     int M, N, K, kchunk, nsplit, tiles_m, tiles_n;
-    int act, out_f32, atomic, bias_rows;
+    int act, out_f32, atomic, bias_rows, group_m;
     float alpha;
 };
 
@@ -252,7 +252,7 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
     // grouped tile order: consecutive ids (= one XCD's co-resident blocks) cover GROUP_M m-tiles x several n-tiles, so
     // both the A row-panels and the B tiles they touch stay resident in that XCD's 4 MB L2 (sweeping all n-tiles per
     // m-panel streamed the whole weight matrix through L2 once per panel: 5-10x over-fetch measured with FETCH_SIZE).
-    constexpr int GROUP_M = 8;
+    const int GROUP_M = g.group_m;
     const int tpg = GROUP_M * g.tiles_n;
     const int grp = tile / tpg, first_m = grp * GROUP_M;
     const int gsz = min(GROUP_M, g.tiles_m - first_m);
@@ -793,6 +793,7 @@ static int build_args(const a8_gemm_desc* d, GemmArgs& g, long long* grid) {
     nsplit = d->K > 0 ? cdiv(d->K, kchunk) : 1;
     g.kchunk = kchunk; g.nsplit = nsplit;
     g.act = d->act; g.out_f32 = d->out_f32; g.alpha = d->alpha;
+    g.group_m = g_a8_tuning[12] > 0 ? g_a8_tuning[12] : 8;           // m-tiles per tile-order group (developer knob 12; 8 measured best)
     g.atomic = (nsplit > 1 || d->accumulate) ? 1 : 0;
     A8_REQUIRE(!(g.atomic && !d->out_f32), "a8_gemm: split-K / accumulate needs an f32 output");
     A8_REQUIRE(!(nsplit > 1 && (d->bias || d->act || d->zout || d->colsum)), "a8_gemm: split-K cannot carry a bias/activation/colsum epilogue");

@@ -137,7 +137,10 @@ def _splitk(out_tiles, kred):
     128x128-tile blocks (576 blocks would run as two rounds at 56 % utilisation), while every split keeps at
     least ~800 reduction rows (shorter splits are dominated by prologue + atomic epilogue; measured with
     tools/splitk_sweep.py)."""
-    return max(1, min(16, 512 // max(1, out_tiles), kred // 800))
+    return max(1, min(16, SPLITK_SLOTS // max(1, out_tiles), kred // SPLITK_MIN_ROWS))
+
+
+SPLITK_SLOTS, SPLITK_MIN_ROWS = 512, 800     # developer knobs for the split-K rule above
 
 
 def _tiles(m, n):
