@@ -206,7 +206,7 @@ def main():
         if args.gemm_table:
             tab = {}
             for e0, e1, fl, lay, _, shp in sprof:
-                t = tab.setdefault((lay,) + shp, [0, 0.0, fl])
+                t = tab.setdefault((lay,) + shp + (int(fl / 1e6),), [0, 0.0, fl])     # (grouped launches of different sizes share a shape tag)
                 t[0] += 1
                 t[1] += e0.elapsed_time(e1)
             for k, (n, ms, fl) in sorted(tab.items(), key=lambda kv: -kv[1][1]):
