@@ -141,7 +141,7 @@ A8_DEV void flush_colsum(float (&acc)[MC][8], float* lds, float* __restrict__ ou
 // MC = 16-byte chunks per lane (cols <= 512 * MC).  dbias (optional) += column sums of the dx output, i.e. the bias
 // gradient of the Linear whose output fed this LayerNorm through dropout (saves a separate column-sum pass).
 template <typename T, int NW, int MC>
-__global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ dy2,
+__global__ __launch_bounds__(NW * 64, MC <= 2 ? 4 : 2) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ dy2,
                                                          const T* __restrict__ x, const T* __restrict__ res,
                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, T* __restrict__ dx, T* __restrict__ dres,
