@@ -97,8 +97,8 @@ template <int KB> struct StageTile<float, KB> {
 
 // ---- epilogue (shared by the main-loop variants).  Needs NWM*2 waves x (16*MI/NP rows x 64 cols x 4 B) of free LDS;
 // NP = passes over the wave's rows (2 halves the staging so that small-LDS variants keep their occupancy).
-template <typename T, int MI, int NWM, int NP = 1>
-A8_DEV void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MI][4], char* lds, const int w, const int m0, const int n0, const int lane) {
+template <typename T, int MI, int NWM, int NP = 1, int NJ = 4>
+A8_DEV void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MI][NJ], char* lds, const int w, const int m0, const int n0, const int lane) {
     const int wm = w >> 1, wn = w & 1;
     // ---- epilogue through LDS: each wave parks its 64-column f32 sub-tile in its own slab of the (now free) ring, then
     // walks it row by row so that every global store / f32 atomic wave-instruction is ONE contiguous row segment
@@ -107,7 +107,8 @@ A8_DEV void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MI][4], char* lds, con
     constexpr int MP = MI / NP, PROWS = 16 * MP;                      // fragments / rows per pass
     static_assert(MI % NP == 0, "passes must divide the wave's row fragments");
     float* cw = reinterpret_cast<float*>(lds) + w * (PROWS * 64);
-    const int nw = n0 + wn * 64;
+    constexpr int WN = 16 * NJ;                                       // columns of the tile owned by a wave (its LDS slab stays 64 wide)
+    const int nw = n0 + wn * WN;
     auto zrow = [&](int m) -> long long { return g.z_rpb ? (m / g.z_rpb) * g.z_bs + (m % g.z_rpb) * g.ldz : (long long)m * g.ldz; };
     const bool f32_rows = g.out_f32 || sizeof(T) == 4;
     float csum1 = 0.f;
@@ -120,7 +121,7 @@ A8_DEV void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MI][4], char* lds, con
 #pragma unroll
             for (int i = 0; i < MP; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < NJ; ++j) {
                     f32x4 v = acc[ps * MP + i][j];
                     v *= g.alpha;
                     *reinterpret_cast<f32x4*>(cw + (16 * i + li) * 64 + (((4 * j + g4) ^ li) << 2)) = v;
@@ -130,7 +131,7 @@ A8_DEV void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MI][4], char* lds, con
         const int mw = m0 + wm * WROWS + ps * PROWS;
         if (f32_rows) {
             const int n = nw + lane;
-            const bool n_ok = n < g.N;
+            const bool n_ok = n < g.N && lane < WN;
             const float bn = (g.bias && !g.bias_rows && n_ok) ? g.bias[n] : 0.f;
             for (int rr = 0; rr < PROWS; ++rr) {
                 const int m = mw + rr;
@@ -152,7 +153,7 @@ A8_DEV void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MI][4], char* lds, con
             // 16-bit output: lane owns 8 consecutive columns (16 B), a wave-instruction covers 8 rows x 128 B
             const int c8 = (lane & 7) << 3;                 // first column within the wave's 64
             const int n = nw + c8;
-            const bool n_ok = n < g.N;
+            const bool n_ok = n < g.N && c8 < WN;
             float bn[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) bn[e] = (g.bias && !g.bias_rows && n_ok) ? g.bias[n + e] : 0.f;
@@ -217,14 +218,14 @@ A8_DEV void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MI][4], char* lds, con
             float t = 0.f;
 #pragma unroll
             for (int q = 0; q < NWM; ++q) t += reinterpret_cast<const float*>(lds)[(q * 2 + wn) * (PROWS * 64) + lane];
-            if (nw + lane < g.N) atomicAdd(g.colsum + nw + lane, t);
+            if (nw + lane < g.N && lane < WN) atomicAdd(g.colsum + nw + lane, t);
         }
     }
 }
 
 // Main loop: NST-deep ring of LDS stages filled by LDS-DMA (global_load_lds, 16 B per lane), NST-1 k-tiles in
 // flight per block; one raw s_barrier and one counted s_waitcnt vmcnt per k-tile; no register staging.
-template <typename T, bool AKS, bool BKS, int KB, int NST, int NWM, int MIP = 0>
+template <typename T, bool AKS, bool BKS, int KB, int NST, int NWM, int MIP = 0, int NJ = 4>
 A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
     typedef StageTile<T, KB> ST;
     typedef KcGeom<KB> G;
@@ -234,7 +235,9 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
     constexpr int MI = MIP ? MIP : (NWM == 2 ? 4 : 2);   // 16-row fragments per wave along M: a wave owns (16 MI) x 64 of the tile
     constexpr int BM = 16 * MI * NWM;             // tile rows: 128; 160 with 10 waves (NWM = 5); 192 / 256 with 8 waves of 48 / 64 rows (MIP = 3 / 4)
     static_assert(BM == 128 || !(AKS || BKS), "tiles taller than 128 rows are built for K-contiguous operands");
-    constexpr int TA = BM * G::KROW, TB = G::OPBYTES, STAGE = TA + TB;
+    constexpr int BN = 32 * NJ;                   // tile columns: 128; 96 with NJ = 3 (a wave owns 48)
+    static_assert(NJ == 4 || !(AKS || BKS), "narrow tiles are built for K-contiguous operands");
+    constexpr int TA = BM * G::KROW, TB = BN * G::KROW, STAGE = TA + TB;
     constexpr int NPA = TA / 1024, NPB = TB / 1024;                        // 1 KB LDS-DMA pieces per operand per stage
     constexpr int PPA = (NPA + NW - 1) / NW, PPB = (NPB + NW - 1) / NW;    // ... per wave (the last may be missing when NW does not divide)
     constexpr int PPW = PPA > PPB ? PPA : PPB;
@@ -257,7 +260,7 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
     const int grp = tile / tpg, first_m = grp * GROUP_M;
     const int gsz = min(GROUP_M, g.tiles_m - first_m);
     const int tin = tile - grp * tpg;
-    const int m0 = (first_m + tin % gsz) * BM, n0 = (tin / gsz) * 128;
+    const int m0 = (first_m + tin % gsz) * BM, n0 = (tin / gsz) * BN;
     const int kbeg = split * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
     const int nkb = (kend - kbeg + BK - 1) / BK;
@@ -352,11 +355,11 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
         }
     };
 
-    f32x4 acc[MI][4];
+    f32x4 acc[MI][NJ];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s) issue(s);
@@ -371,15 +374,15 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
         const char* tb = ta + TA;
         // all fragment reads of the k-tile are issued up front (one exposed LDS latency per tile, counted lgkmcnt waits
         // after that), pinned ahead of the MFMA block
-        typename MM::Frag fa[ST::KSTEPS][MI], fb[ST::KSTEPS][4];
+        typename MM::Frag fa[ST::KSTEPS][MI], fb[ST::KSTEPS][NJ];
 #pragma unroll
         for (int ks = 0; ks < ST::KSTEPS; ++ks) {
 #pragma unroll
             for (int i = 0; i < MI; ++i)
                 fa[ks][i] = AKS ? ST::ks_frag(ta, wm * (16 * MI) + 16 * i, ks, lane) : ST::kc_frag(ta, wm * (16 * MI) + 16 * i, ks, lane);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                fb[ks][i] = BKS ? ST::ks_frag(tb, wn * 64 + 16 * i, ks, lane) : ST::kc_frag(tb, wn * 64 + 16 * i, ks, lane);
+            for (int i = 0; i < NJ; ++i)
+                fb[ks][i] = BKS ? ST::ks_frag(tb, wn * (16 * NJ) + 16 * i, ks, lane) : ST::kc_frag(tb, wn * (16 * NJ) + 16 * i, ks, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (AKS || BKS) {
@@ -392,13 +395,13 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = MM::mma(fb[ks][j], fa[ks][i], acc[i][j]);
+                for (int j = 0; j < NJ; ++j) acc[i][j] = MM::mma(fb[ks][j], fa[ks][i], acc[i][j]);
     }
     // no DMA may still be in flight, and every wave must be done reading the ring, before LDS is reused
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    gemm_epilogue<T, MI, NWM, NP>(g, acc, lds, w, m0, n0, lane);
+    gemm_epilogue<T, MI, NWM, NP, NJ>(g, acc, lds, w, m0, n0, lane);
 }
 
 // ---- tall tiles for the products that would put between one and two 128 x 128 tiles on a CU (M = 6248, N = 768: 294 tiles on
@@ -408,6 +411,15 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
 template <typename T, int MIP>
 __global__ __launch_bounds__(512, 2) void gemm_tall_kernel(const GemmArgs g) {
     gemm_body<T, false, false, 2, 3, 4, MIP>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n * g.nsplit));
+}
+
+// ---- 96-column tiles (8 waves of 32 x 48) for the products whose 128 x 128 tiling leaves the chip between one and two tiles per CU:
+// M = 6248, N = 768 gives 294 tiles on 256 CUs, and the launch lasts as long as the 38 CUs that hold two; 49 x 8 = 392 tiles of
+// 128 x 96 put two co-resident blocks on more than half of the CUs and each finishes a quarter sooner.  Same ring, same k order
+// (bit-identical results); the B stage is 12 KB, so 4 of the 8 waves issue one DMA piece less per k-tile.
+template <typename T>
+__global__ __launch_bounds__(512, 2) void gemm_n96_kernel(const GemmArgs g) {
+    gemm_body<T, false, false, 2, 2, 4, 0, 3>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n * g.nsplit));
 }
 
 // ---- pipelined 256 x 256 main loop for large NT problems with N % 256 == 0 and K % 64 == 0 (the conv layers: N = 512):
@@ -836,6 +848,15 @@ extern "C" int a8_gemm(const a8_gemm_desc* d, void* stream) {
             g.tiles_m = cdiv(d->M, 128); g.tiles_n = d->N / 512;
             const int nt = g.tiles_m * g.tiles_n;
             hipLaunchKernelGGL(gemm_w512_kernel<bf16>, dim3(nt < 256 ? nt : 256), dim3(512), 0, s, g);
+            return a8_check_launch("a8_gemm");
+        }
+    }
+    // 96-column tiles (a8_set_tuning key 13: 0 = never, 1 = when 128-column tiles would leave 257..512 blocks and 96 divides N, 2 = whenever 96 divides N)
+    if (d->dtype == A8_BF16 && d->layout == A8_GEMM_NT && g_variant == 5 && g_a8_tuning[13] > 0 && d->N % 96 == 0) {
+        const long long t96 = (long long)g.tiles_m * (d->N / 96) * g.nsplit;
+        if (g_a8_tuning[13] == 2 || (grid > 256 && grid <= 512 && t96 <= 512)) {
+            g.tiles_n = d->N / 96;
+            hipLaunchKernelGGL(gemm_n96_kernel<bf16>, dim3((int)t96), dim3(512), 0, s, g);
             return a8_check_launch("a8_gemm");
         }
     }

@@ -225,21 +225,21 @@ def test_gemm_160_row_tiles_match_default(depth):
         torch.testing.assert_close(c0, c1, rtol=1e-4, atol=1e-2)       # (column sums combine in a different block order)
 
 
-@pytest.mark.parametrize("key", [5, 11, 8])
+@pytest.mark.parametrize("key", [5, 11, 8, 13])
 def test_gemm_pipelined_256_kernel_matches_default(key):
     """The alternative NT kernels -- pipelined 256 x 256 (a8_set_tuning key 5; N % 256 == 0, K % 64 == 0), full-width persistent
-    128 x 512 (key 11; N % 512 == 0, K % 64 == 0) and the tall 192-row tile (key 8 = 3); none carries a bias / column
-    sums except the tall one -- walk K in the same order as the default kernel: outputs must be bit-identical across M tails,
+    128 x 512 (key 11; N % 512 == 0, K % 64 == 0), the tall 192-row tile (key 8 = 3) and the 96-column tile (key 13 = 2: whenever
+    96 divides N); none carries a bias / column sums except the tall and the 96-column ones -- walk K in the same order as the default kernel: outputs must be bit-identical across M tails,
     single and odd k-tile counts, the conv row remaps on A, C and z, and each epilogue; ineligible problems must fall through."""
     from audio8_amd import kernels as Kn, _lib as L
     dev, bf = "cuda", torch.bfloat16
-    saved = {5: 0, 11: 0, 8: 0}
+    saved = {5: 0, 11: 0, 8: 0, 13: 0}
 
     def both(fn):
         for k_, v_ in saved.items():
             L.check(L.lib().a8_set_tuning(k_, v_), "tune")
         ref = fn()
-        L.check(L.lib().a8_set_tuning(key, 3 if key == 8 else 1), "tune")
+        L.check(L.lib().a8_set_tuning(key, {8: 3, 13: 2}.get(key, 1)), "tune")
         try:
             got = fn()
         finally:
@@ -268,6 +268,14 @@ def test_gemm_pipelined_256_kernel_matches_default(key):
     bias = torch.randn(N, device=dev)
     same(*both(lambda: (Kn.gemm(L.NT, A, B, M, N, K, bias=bias),)), "bias (falls through)")
     same(*both(lambda: (Kn.gemm(L.NT, A, B, M, N, K, out_dtype=torch.float32),)), "f32 out (falls through)")
+
+    def with_colsum():
+        cs = torch.zeros(N, device=dev)
+        out = Kn.gemm(L.NT, A, B, M, N, K, act=L.ACT_MUL_GELU_GRAD, zin=z, colsum=cs)
+        return out, cs
+    (r_out, r_cs), (g_out, g_cs) = both(with_colsum)
+    assert torch.equal(r_out, g_out)
+    torch.testing.assert_close(r_cs, g_cs, rtol=1e-4, atol=1e-2)      # (column sums combine in a different block order)
     # conv forward as a GEMM: overlapping rows of a channels-last activation (k = 3, stride 2), utterance boundaries inside tiles
     Bn, Lin, Cc = 3, 1001, 512
     Lout = (Lin - 3) // 2 + 1
