@@ -225,7 +225,7 @@ A8_DEV void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MI][NJ], char* lds, co
 
 // Main loop: NST-deep ring of LDS stages filled by LDS-DMA (global_load_lds, 16 B per lane), NST-1 k-tiles in
 // flight per block; one raw s_barrier and one counted s_waitcnt vmcnt per k-tile; no register staging.
-template <typename T, bool AKS, bool BKS, int KB, int NST, int NWM, int MIP = 0, int NJ = 4>
+template <typename T, bool AKS, bool BKS, int KB, int NST, int NWM, int MIP = 0, int NJ = 4, bool A3 = false>
 A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
     typedef StageTile<T, KB> ST;
     typedef KcGeom<KB> G;
@@ -242,7 +242,8 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
     constexpr int PPA = (NPA + NW - 1) / NW, PPB = (NPB + NW - 1) / NW;    // ... per wave (the last may be missing when NW does not divide)
     constexpr int PPW = PPA > PPB ? PPA : PPB;
     constexpr bool UNEVEN = NPA % NW != 0 || NPB % NW != 0;                // then a wave without a last piece DMAs 16 zero bytes per lane
-    constexpr int RING = NST * STAGE + (UNEVEN ? 1024 : 0);                // into a spare KB, so that vmcnt counts stay uniform
+    static_assert(!A3 || (!AKS && !BKS && NST == 2 && !UNEVEN), "the 3-deep A ring is built for NT, 2-deep B, even piece counts");
+    constexpr int RING = A3 ? 3 * TA + 2 * TB : NST * STAGE + (UNEVEN ? 1024 : 0);   // (spare KB: so that vmcnt counts stay uniform)
     constexpr int NP = (KB == 1 && NST == 2) ? 2 : 1;                      // small-LDS variant: epilogue in two passes
     constexpr int EPI = NW * 16 * MI * 64 * 4 / NP;                        // epilogue staging: a 64-column f32 slab per wave
     __shared__ __attribute__((aligned(1024))) char lds[RING > EPI ? RING : EPI];
@@ -361,6 +362,59 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    if constexpr (A3) {
+        // Asymmetric ring: the A operand (activations, streamed once from HBM / the Infinity Cache) is requested TWO k-tiles
+        // ahead into a 3-deep ring, the B operand (weights, L2-resident) one k-tile ahead into a 2-deep ring: 3 x 16 + 2 x 16 = 80 KB,
+        // still two blocks per CU.  Per iteration a wave issues its B pieces first and its A pieces last, so "all but the PPA
+        // youngest" (vmcnt counts in issue order) is exactly: A(kb) and B(kb) have landed, A(kb+1) may still be in flight.
+        auto issue_a = [&](int kb, char* ta) {
+            const int k0 = kbeg + kb * BK;
+#pragma unroll
+            for (int j = 0; j < PPA; ++j) {
+                const int k = k0 + a_k[j];
+                glds16((a_ok[j] && k + EPC <= kend) ? a_ptr[j] + (long long)k * SZ : zero, ta + (w + NW * j) * 1024);
+            }
+        };
+        auto issue_b = [&](int kb, char* tb) {
+            const int k0 = kbeg + kb * BK;
+#pragma unroll
+            for (int j = 0; j < PPB; ++j) {
+                const int k = k0 + b_k[j];
+                glds16((b_ok[j] && k + EPC <= kend) ? b_ptr[j] + (long long)k * SZ : zero, tb + (w + NW * j) * 1024);
+            }
+        };
+        char* const bbase = lds + 3 * TA;
+        issue_a(0, lds);
+        issue_b(0, bbase);
+        issue_a(1, lds + TA);
+        int sa = 0, sb = 0;                           // ring slots of the k-tile being consumed
+        for (int kb = 0; kb < nkb; ++kb) {
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPA) : "memory");
+            __builtin_amdgcn_s_barrier();
+            const int sa2 = sa == 0 ? 2 : sa - 1;     // (sa + 2) % 3: the slot read in the previous iteration
+            issue_b(kb + 1, bbase + (sb ^ 1) * TB);   // (beyond kend: 16 zero bytes per lane -- keeps the counts uniform)
+            issue_a(kb + 2, lds + sa2 * TA);
+            const char* ta = lds + sa * TA;
+            const char* tb = bbase + sb * TB;
+            typename MM::Frag fa[ST::KSTEPS][MI], fb[ST::KSTEPS][NJ];
+#pragma unroll
+            for (int ks = 0; ks < ST::KSTEPS; ++ks) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) fa[ks][i] = ST::kc_frag(ta, wm * (16 * MI) + 16 * i, ks, lane);
+#pragma unroll
+                for (int i = 0; i < NJ; ++i) fb[ks][i] = ST::kc_frag(tb, wn * (16 * NJ) + 16 * i, ks, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < ST::KSTEPS; ++ks)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = MM::mma(fb[ks][j], fa[ks][i], acc[i][j]);
+            sa = sa == 2 ? 0 : sa + 1;
+            sb ^= 1;
+        }
+    } else {
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s) issue(s);
     for (int kb = 0; kb < nkb; ++kb) {
@@ -397,6 +451,7 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) acc[i][j] = MM::mma(fb[ks][j], fa[ks][i], acc[i][j]);
     }
+    }
     // no DMA may still be in flight, and every wave must be done reading the ring, before LDS is reused
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -411,6 +466,12 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
 template <typename T, int MIP>
 __global__ __launch_bounds__(512, 2) void gemm_tall_kernel(const GemmArgs g) {
     gemm_body<T, false, false, 2, 3, 4, MIP>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n * g.nsplit));
+}
+
+// ---- the default 128 x 128 NT tile with the asymmetric ring (A three deep, B two deep: gemm_body, A3)
+template <typename T>
+__global__ __launch_bounds__(512, 4) void gemm_a3_kernel(const GemmArgs g) {
+    gemm_body<T, false, false, 2, 2, 4, 0, 4, true>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n * g.nsplit));
 }
 
 // ---- 96-column tiles (8 waves of 32 x 48) for the products whose 128 x 128 tiling leaves the chip between one and two tiles per CU:
@@ -850,6 +911,11 @@ extern "C" int a8_gemm(const a8_gemm_desc* d, void* stream) {
             hipLaunchKernelGGL(gemm_w512_kernel<bf16>, dim3(nt < 256 ? nt : 256), dim3(512), 0, s, g);
             return a8_check_launch("a8_gemm");
         }
+    }
+    // Asymmetric ring (a8_set_tuning key 14: 0 = never, otherwise the minimum M; 1 = every bf16 NT problem)
+    if (d->dtype == A8_BF16 && d->layout == A8_GEMM_NT && g_variant == 5 && g_a8_tuning[14] > 0 && d->M >= g_a8_tuning[14]) {
+        hipLaunchKernelGGL(gemm_a3_kernel<bf16>, dim3((int)grid), dim3(512), 0, s, g);
+        return a8_check_launch("a8_gemm");
     }
     // 96-column tiles (a8_set_tuning key 13: 0 = never, 1 = when 128-column tiles would leave 257..512 blocks and 96 divides N, 2 = whenever 96 divides N)
     if (d->dtype == A8_BF16 && d->layout == A8_GEMM_NT && g_variant == 5 && g_a8_tuning[13] > 0 && d->N % 96 == 0) {

@@ -225,25 +225,27 @@ def test_gemm_160_row_tiles_match_default(depth):
         torch.testing.assert_close(c0, c1, rtol=1e-4, atol=1e-2)       # (column sums combine in a different block order)
 
 
-@pytest.mark.parametrize("key", [5, 11, 8, 13])
+@pytest.mark.parametrize("key", [5, 11, 8, 13, 14])
 def test_gemm_pipelined_256_kernel_matches_default(key):
     """The alternative NT kernels -- pipelined 256 x 256 (a8_set_tuning key 5; N % 256 == 0, K % 64 == 0), full-width persistent
     128 x 512 (key 11; N % 512 == 0, K % 64 == 0), the tall 192-row tile (key 8 = 3) and the 96-column tile (key 13 = 2: whenever
-    96 divides N); none carries a bias / column sums except the tall and the 96-column ones -- walk K in the same order as the default kernel: outputs must be bit-identical across M tails,
+    96 divides N) and the asymmetric ring (key 14 = 1: A three k-tiles deep); none carries a bias / column sums except the tall,
+    the 96-column and the asymmetric-ring ones -- walk K in the same order as the default kernel: outputs must be bit-identical across M tails,
     single and odd k-tile counts, the conv row remaps on A, C and z, and each epilogue; ineligible problems must fall through."""
     from audio8_amd import kernels as Kn, _lib as L
     dev, bf = "cuda", torch.bfloat16
-    saved = {5: 0, 11: 0, 8: 0, 13: 0}
+    saved = {5: 0, 11: 0, 8: 0, 13: 0, 14: 0}
 
     def both(fn):
-        for k_, v_ in saved.items():
-            L.check(L.lib().a8_set_tuning(k_, v_), "tune")
-        ref = fn()
-        L.check(L.lib().a8_set_tuning(key, {8: 3, 13: 2}.get(key, 1)), "tune")
         try:
+            for k_, v_ in saved.items():
+                L.check(L.lib().a8_set_tuning(k_, v_), "tune")          # the reference: every alternative kernel off
+            ref = fn()
+            L.check(L.lib().a8_set_tuning(key, {8: 3, 13: 2}.get(key, 1)), "tune")
             got = fn()
         finally:
-            L.check(L.lib().a8_set_tuning(key, saved[key]), "tune")
+            for k_, v_ in {**saved, 14: 10000}.items():                 # back to the library defaults
+                L.check(L.lib().a8_set_tuning(k_, v_), "tune")
         return ref, got
 
     def same(ref, got, what):

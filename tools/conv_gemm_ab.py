@@ -11,13 +11,15 @@ from audio8_amd import _lib as L, kernels as K  # noqa: E402
 from tools.micro_bench import timeit  # noqa: E402
 
 bf = torch.bfloat16
-cfgs = [("default", {}), ("w512", {11: 1}), ("p256", {5: 1})]
+cfgs = [("default", {}), ("a3", {14: 1}), ("w512", {11: 1}), ("p256", {5: 1})]
+if os.environ.get("AB_ONLY"):
+    cfgs = [c for c in cfgs if c[0] in ("default",) + tuple(os.environ["AB_ONLY"].split(","))]
 B, C = 8, 512
 layers = [(49999, 24999, 3), (24999, 12499, 3), (12499, 6249, 3), (6249, 3124, 3), (3124, 1562, 2), (1562, 781, 2)]
 
 
 def tune(d):
-    for k in (5, 11):
+    for k in (5, 11, 14):
         L.check(L.lib().a8_set_tuning(k, d.get(k, 0)), "tune")
 
 
