@@ -797,6 +797,16 @@ __global__ __launch_bounds__(128 * NWM, (NST * 2 * 8192 * KB <= 65536) ? NWM : N
     gemm_body<T, AKS, BKS, KB, NST, NWM>(g, bid - grp.start[i]);
 }
 
+// the grouped launch with the asymmetric ring of gemm_a3_kernel (bf16 NT; the conv data-gradient halves)
+template <typename T>
+__global__ __launch_bounds__(512, 4) void gemm_grouped_a3_kernel(const GemmGroup grp) {
+    const int bid = xcd_remap(blockIdx.x, grp.start[grp.n]);
+    int i = 0;
+    while (i + 1 < grp.n && bid >= grp.start[i + 1]) ++i;
+    const GemmArgs g = grp.g[i];
+    gemm_body<T, false, false, 2, 2, 4, 0, 4, true>(g, bid - grp.start[i]);
+}
+
 #define g_variant g_a8_tuning[0]
                         // tuning knob (a8_set_tuning key 0): 5 = 128 B of K per row, 2-deep ring, 8 waves (default: measured best);
                         // 2 = same with 4 waves; 1 = 64 B rows, 4-deep ring, 4 waves
@@ -978,7 +988,15 @@ extern "C" int a8_gemm_grouped(const a8_gemm_desc* descs, int n, void* stream) {
     if (descs[0].dtype == A8_BF16) {
         switch (g_variant) {
             case 1: return launch2g<bf16, 1, 4, 2>(descs[0].layout, grp, (int)total, s);
-            case 5: return launch2g<bf16, 2, 2, 4>(descs[0].layout, grp, (int)total, s);
+            case 5: {
+                bool a3 = descs[0].layout == A8_GEMM_NT && g_a8_tuning[14] > 0;
+                for (int i = 0; i < n && a3; ++i) a3 = descs[i].M == 0 || descs[i].M >= g_a8_tuning[14];
+                if (a3) {
+                    hipLaunchKernelGGL(gemm_grouped_a3_kernel<bf16>, dim3((int)total), dim3(512), 0, s, grp);
+                    return a8_check_launch("a8_gemm_grouped");
+                }
+                return launch2g<bf16, 2, 2, 4>(descs[0].layout, grp, (int)total, s);
+            }
             case 6: return launch2g<bf16, 1, 4, 4>(descs[0].layout, grp, (int)total, s);
             default: return launch2g<bf16, 2, 2, 2>(descs[0].layout, grp, (int)total, s);
         }

@@ -170,6 +170,28 @@ def test_gemm_grouped(dtype, layout):
         np.testing.assert_array_equal(o.double().cpu().numpy(), r.numpy())
 
 
+def test_gemm_grouped_asymmetric_ring_matches_default():
+    """The grouped launch picks the asymmetric-ring main loop (a8_set_tuning key 14) when every problem is at least that tall:
+    bit-identical to the default grouped kernel, M tails and the gelu' epilogue included."""
+    from audio8_amd import kernels as Kn, _lib as L
+    dev, bf = "cuda", torch.bfloat16
+    shapes = [(1000, 512, 1024), (777, 512, 1536), (130, 256, 64)]
+    ops_ = [(_mk((M, K), bf, 50 + i).to(dev), _mk((N, K), bf, 60 + i).to(dev), _mk((M, N), bf, 70 + i).to(dev)) for i, (M, N, K) in enumerate(shapes)]
+
+    def run():
+        probs = [(A, B, M, N, K, dict(act=L.ACT_MUL_GELU_GRAD, zin=z) if i == 1 else {}) for i, ((M, N, K), (A, B, z)) in enumerate(zip(shapes, ops_))]
+        return [o.clone() for o in Kn.gemm_grouped(L.NT, probs)]
+    try:
+        L.check(L.lib().a8_set_tuning(14, 0), "tune")
+        ref = run()
+        L.check(L.lib().a8_set_tuning(14, 1), "tune")
+        got = run()
+    finally:
+        L.check(L.lib().a8_set_tuning(14, 10000), "tune")
+    for r, g_ in zip(ref, got):
+        assert torch.equal(r, g_)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_add_epilogue(dtype):
     from audio8_amd import kernels as Kn, _lib as L
