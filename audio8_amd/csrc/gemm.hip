@@ -29,7 +29,7 @@ struct GemmArgs {
     const float* bias;
     float* colsum;
     int M, N, K, kchunk, nsplit, tiles_m, tiles_n;
-    int act, out_f32, atomic, bias_rows, group_m;
+    int act, out_f32, atomic, bias_rows, group_m, zpre;
     float alpha;
 };
 
@@ -97,8 +97,12 @@ template <int KB> struct StageTile<float, KB> {
 
 // ---- epilogue (shared by the main-loop variants).  Needs NWM*2 waves x (16*MI/NP rows x 64 cols x 4 B) of free LDS;
 // NP = passes over the wave's rows (2 halves the staging so that small-LDS variants keep their occupancy).
+template <typename T> struct Vec8 { typedef T type __attribute__((ext_vector_type(8))); };
+
+// zpre (16-bit outputs, NP == 1, when use_zpre): the lane's zin values, loaded by the caller ahead of its main loop
 template <typename T, int MI, int NWM, int NP = 1, int NJ = 4>
-A8_DEV void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MI][NJ], char* lds, const int w, const int m0, const int n0, const int lane) {
+A8_DEV void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MI][NJ], char* lds, const int w, const int m0, const int n0, const int lane,
+                          const typename Vec8<T>::type (&zpre)[2 * MI], const bool use_zpre) {
     const int wm = w >> 1, wn = w & 1;
     // ---- epilogue through LDS: each wave parks its 64-column f32 sub-tile in its own slab of the (now free) ring, then
     // walks it row by row so that every global store / f32 atomic wave-instruction is ONE contiguous row segment
@@ -158,6 +162,7 @@ A8_DEV void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MI][NJ], char* lds, co
 #pragma unroll
             for (int e = 0; e < 8; ++e) bn[e] = (g.bias && !g.bias_rows && n_ok) ? g.bias[n + e] : 0.f;
             typedef T T8 __attribute__((ext_vector_type(8)));
+#pragma unroll
             for (int it = 0; it < PROWS / 8; ++it) {
                 if (mw + 8 * it >= g.M) break;
                 const int rr = 8 * it + (lane >> 3);
@@ -180,11 +185,11 @@ A8_DEV void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MI][NJ], char* lds, co
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
                 } else if (g.act == A8_ACT_MUL_GELU_GRAD) {
-                    const T8 zz = *reinterpret_cast<const T8*>(reinterpret_cast<const T*>(g.zin) + zrow(m) + n);
+                    const T8 zz = use_zpre ? zpre[NP == 1 ? it : 0] : *reinterpret_cast<const T8*>(reinterpret_cast<const T*>(g.zin) + zrow(m) + n);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(to_f(zz[e]));
                 } else if (g.act == A8_ACT_ADD) {
-                    const T8 zz = *reinterpret_cast<const T8*>(reinterpret_cast<const T*>(g.zin) + zrow(m) + n);
+                    const T8 zz = use_zpre ? zpre[NP == 1 ? it : 0] : *reinterpret_cast<const T8*>(reinterpret_cast<const T*>(g.zin) + zrow(m) + n);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += to_f(zz[e]);
                 }
@@ -362,6 +367,29 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // The epilogues that read a second input (x gelu'(z), + residual) get it NOW: the loads are older than every DMA of the main
+    // loop, so its first counted wait retires them together with the first k-tile (their latency would otherwise sit, exposed,
+    // between the last MFMA and the stores of every tile).  16-bit rows only; the lane -> (row, 8 columns) map of gemm_epilogue.
+    typedef typename Vec8<T>::type T8z;
+    constexpr bool ZPRE = sizeof(T) == 2 && NP == 1;
+    T8z zpre[2 * MI];
+    bool use_zpre = false;
+    if constexpr (ZPRE) {
+        use_zpre = g.zpre && g.zin != nullptr && !g.out_f32 && (g.act == A8_ACT_MUL_GELU_GRAD || g.act == A8_ACT_ADD);
+        if (use_zpre) {
+            const int c8 = (lane & 7) << 3, n = n0 + wn * (16 * NJ) + c8;
+#pragma unroll
+            for (int it = 0; it < 2 * MI; ++it) {
+                const int m = m0 + wm * (16 * MI) + 8 * it + (lane >> 3);
+                zpre[it] = T8z{};
+                if (m < g.M && n < g.N && c8 < 16 * NJ) {
+                    const long long zr = g.z_rpb ? (m / g.z_rpb) * g.z_bs + (m % g.z_rpb) * g.ldz : (long long)m * g.ldz;
+                    zpre[it] = *reinterpret_cast<const T8z*>(reinterpret_cast<const T*>(g.zin) + zr + n);
+                }
+            }
+        }
+    }
+
     if constexpr (A3) {
         // Asymmetric ring: the A operand (activations, streamed once from HBM / the Infinity Cache) is requested TWO k-tiles
         // ahead into a 3-deep ring, the B operand (weights, L2-resident) one k-tile ahead into a 2-deep ring: 3 x 16 + 2 x 16 = 80 KB,
@@ -456,7 +484,7 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    gemm_epilogue<T, MI, NWM, NP, NJ>(g, acc, lds, w, m0, n0, lane);
+    gemm_epilogue<T, MI, NWM, NP, NJ>(g, acc, lds, w, m0, n0, lane, zpre, use_zpre);
 }
 
 // ---- tall tiles for the products that would put between one and two 128 x 128 tiles on a CU (M = 6248, N = 768: 294 tiles on
@@ -877,6 +905,7 @@ static int build_args(const a8_gemm_desc* d, GemmArgs& g, long long* grid) {
     g.kchunk = kchunk; g.nsplit = nsplit;
     g.act = d->act; g.out_f32 = d->out_f32; g.alpha = d->alpha;
     g.group_m = g_a8_tuning[12] > 0 ? g_a8_tuning[12] : 8;           // m-tiles per tile-order group (developer knob 12; 8 measured best)
+    g.zpre = g_a8_tuning[15] == 0;                                   // developer knob 15: 1 = load zin in the epilogue (the round-1 form)
     g.atomic = (nsplit > 1 || d->accumulate) ? 1 : 0;
     A8_REQUIRE(!(g.atomic && !d->out_f32), "a8_gemm: split-K / accumulate needs an f32 output");
     A8_REQUIRE(!(nsplit > 1 && (d->bias || d->act || d->zout || d->colsum)), "a8_gemm: split-K cannot carry a bias/activation/colsum epilogue");

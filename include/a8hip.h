@@ -62,7 +62,7 @@ int a8_gemm_grouped(const a8_gemm_desc* descs, int n, void* stream);
  * 2..4 = LDS ring depth); 8 tall (192 / 256-row) NT GEMM tiles, one block per CU: 0 = off, 1 = when the 128-row tiling would
  * put between one and two tiles on a CU, 3 / 4 = always 192 / 256 rows; 13 NT GEMM tiles of 128 x 96 (bf16, 96 | N): 0 = off, 1 = when 128-column
  * tiles would leave 257..512 blocks, 2 = always; 14 asymmetric LDS ring for bf16 NT GEMMs (A requested two k-tiles ahead, B one): 0 = off,
- * otherwise the minimum M (default 10000: the conv layers) */
+ * otherwise the minimum M (default 10000: the conv layers); 15 = 1: the GEMM epilogues load their second input (zin) after the main loop instead of ahead of it */
 int a8_set_tuning(int key, int value);
 
 /* ---- per-step weight preparation (the f32 -> compute-dtype casts the reference's autocast-free f32 path never needs;
