@@ -102,7 +102,7 @@ template <typename T> struct Vec8 { typedef T type __attribute__((ext_vector_typ
 // zpre (16-bit outputs, NP == 1, when use_zpre): the lane's zin values, loaded by the caller ahead of its main loop
 template <typename T, int MI, int NWM, int NP = 1, int NJ = 4>
 A8_DEV void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MI][NJ], char* lds, const int w, const int m0, const int n0, const int lane,
-                          const typename Vec8<T>::type (&zpre)[2 * MI], const bool use_zpre) {
+                          const typename Vec8<T>::type (&zpre)[2 * MI], const bool use_zpre, const float (&bpre)[8], const bool use_bpre) {
     const int wm = w >> 1, wn = w & 1;
     // ---- epilogue through LDS: each wave parks its 64-column f32 sub-tile in its own slab of the (now free) ring, then
     // walks it row by row so that every global store / f32 atomic wave-instruction is ONE contiguous row segment
@@ -160,7 +160,7 @@ A8_DEV void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MI][NJ], char* lds, co
             const bool n_ok = n < g.N && c8 < WN;
             float bn[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) bn[e] = (g.bias && !g.bias_rows && n_ok) ? g.bias[n + e] : 0.f;
+            for (int e = 0; e < 8; ++e) bn[e] = use_bpre ? bpre[e] : ((g.bias && !g.bias_rows && n_ok) ? g.bias[n + e] : 0.f);
             typedef T T8 __attribute__((ext_vector_type(8)));
 #pragma unroll
             for (int it = 0; it < PROWS / 8; ++it) {
@@ -390,6 +390,20 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
         }
     }
 
+    float bpre[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // the lane's 8 bias columns, for the same reason
+    bool use_bpre = false;
+    if constexpr (ZPRE && !BKS) {                                     // (a bias rides on forward products: NT)
+        use_bpre = g.zpre && g.bias != nullptr && !g.bias_rows && !g.out_f32;
+        if (use_bpre) {
+            const int c8 = (lane & 7) << 3, n = n0 + wn * (16 * NJ) + c8;
+            if (n < g.N && c8 < 16 * NJ) {
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias + n), b1 = *reinterpret_cast<const f32x4*>(g.bias + n + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { bpre[e] = b0[e]; bpre[e + 4] = b1[e]; }
+            }
+        }
+    }
+
     if constexpr (A3) {
         // Asymmetric ring: the A operand (activations, streamed once from HBM / the Infinity Cache) is requested TWO k-tiles
         // ahead into a 3-deep ring, the B operand (weights, L2-resident) one k-tile ahead into a 2-deep ring: 3 x 16 + 2 x 16 = 80 KB,
@@ -484,7 +498,7 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    gemm_epilogue<T, MI, NWM, NP, NJ>(g, acc, lds, w, m0, n0, lane, zpre, use_zpre);
+    gemm_epilogue<T, MI, NWM, NP, NJ>(g, acc, lds, w, m0, n0, lane, zpre, use_zpre, bpre, use_bpre);
 }
 
 // ---- tall tiles for the products that would put between one and two 128 x 128 tiles on a CU (M = 6248, N = 768: 294 tiles on
