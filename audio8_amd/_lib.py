@@ -79,7 +79,11 @@ class GemmDesc(C.Structure):
         ("out_f32", C.c_int), ("accumulate", C.c_int), ("splitk", C.c_int),
         ("alpha", C.c_float),
         ("colsum", C.c_void_p),
+        ("sk_ws", C.c_void_p), ("sk_ws_bytes", C.c_int64), ("sk_epoch", C.c_uint32),
     ]
+
+
+GEMM_SK_WS_BYTES = 65536 + 512 * 65536          # A8_GEMM_SK_WS_BYTES of include/a8hip.h
 
 
 class WPrepDesc(C.Structure):

@@ -30,12 +30,18 @@ struct GemmArgs {
     float* colsum;
     int M, N, K, kchunk, nsplit, tiles_m, tiles_n;
     int act, out_f32, atomic, bias_rows, group_m, zpre;
+    char* sk_ws; unsigned sk_epoch;               // stream-K: flag words (64 B apart) then 64 KB f32 slabs, one of each per worker
     float alpha;
 };
 
-A8_DEV long long outer_off(const Op& o, long long idx) {
-    return o.rpb ? (idx / o.rpb) * o.bs + (idx % o.rpb) * o.ld : idx * o.ld;
+// (index / rows_per_batch, index % rows_per_batch) -> offset.  Indices and rows_per_batch fit 31 bits (checked on the host): one
+// 32-bit unsigned division instead of the ~200-instruction 64-bit one the compiler emits for long long operands.
+A8_DEV long long remap_off(long long idx, long long rpb, long long bs, long long ld) {
+    if (!rpb) return idx * ld;
+    const unsigned q = (unsigned)idx / (unsigned)rpb, r = (unsigned)idx - q * (unsigned)rpb;
+    return (long long)q * bs + (long long)r * ld;
 }
+A8_DEV long long outer_off(const Op& o, long long idx) { return remap_off(idx, o.rpb, o.bs, o.ld); }
 
 // 16 zero bytes: the LDS-DMA source of every out-of-range lane (M/N/K tails are zero-filled this way)
 __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
@@ -113,7 +119,7 @@ A8_DEV void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MI][NJ], char* lds, co
     float* cw = reinterpret_cast<float*>(lds) + w * (PROWS * 64);
     constexpr int WN = 16 * NJ;                                       // columns of the tile owned by a wave (its LDS slab stays 64 wide)
     const int nw = n0 + wn * WN;
-    auto zrow = [&](int m) -> long long { return g.z_rpb ? (m / g.z_rpb) * g.z_bs + (m % g.z_rpb) * g.ldz : (long long)m * g.ldz; };
+    auto zrow = [&](int m) -> long long { return remap_off(m, g.z_rpb, g.z_bs, g.ldz); };
     const bool f32_rows = g.out_f32 || sizeof(T) == 4;
     float csum1 = 0.f;
     float csum8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -147,7 +153,7 @@ A8_DEV void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MI][NJ], char* lds, co
                 if (g.act == A8_ACT_GELU) v = gelu_f(v);
                 else if (g.act == A8_ACT_MUL_GELU_GRAD) v *= gelu_grad_f(to_f(reinterpret_cast<const T*>(g.zin)[zrow(m) + n]));
                 else if (g.act == A8_ACT_ADD) v += to_f(reinterpret_cast<const T*>(g.zin)[zrow(m) + n]);
-                const long long crow = g.c_rpb ? (m / g.c_rpb) * g.c_bs + (m % g.c_rpb) * g.ldc : (long long)m * g.ldc;
+                const long long crow = remap_off(m, g.c_rpb, g.c_bs, g.ldc);
                 float* cp = reinterpret_cast<float*>(g.C) + crow + n;
                 if (g.atomic) atomicAdd(cp, v);
                 else *cp = v;
@@ -193,7 +199,7 @@ A8_DEV void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MI][NJ], char* lds, co
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += to_f(zz[e]);
                 }
-                const long long crow = g.c_rpb ? (m / g.c_rpb) * g.c_bs + (m % g.c_rpb) * g.ldc : (long long)m * g.ldc;
+                const long long crow = remap_off(m, g.c_rpb, g.c_bs, g.ldc);
                 T8 ov;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { ov[e] = from_f<T>(v[e]); csum8[e] += v[e]; }
@@ -230,8 +236,14 @@ A8_DEV void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MI][NJ], char* lds, co
 
 // Main loop: NST-deep ring of LDS stages filled by LDS-DMA (global_load_lds, 16 B per lane), NST-1 k-tiles in
 // flight per block; one raw s_barrier and one counted s_waitcnt vmcnt per k-tile; no register staging.
-template <typename T, bool AKS, bool BKS, int KB, int NST, int NWM, int MIP = 0, int NJ = 4, bool A3 = false>
-A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
+// Stream-K segment kinds (gemm_core's `mode`): a whole tile; the LAST k-range of a tile (adds the partial sums the other
+// contributors published, then runs the epilogue); any other k-range (publishes its partial sums, no epilogue)
+enum { SEG_FULL = 0, SEG_FINISH = 1, SEG_PARTIAL = 2 };
+constexpr int SK_XCDS = 8;          // blocks b, b + 8, b + 16 ... are observed to share an XCD (a speed assumption only)
+constexpr int SK_FLAG_STRIDE = 64, SK_FLAG_BYTES = 65536, SK_SLAB_BYTES = 65536;     // (A8_GEMM_SK_WS_BYTES: flags, then A8_GEMM_SK_WORKERS slabs)
+
+template <typename T, bool AKS, bool BKS, int KB, int NST, int NWM, int MIP = 0, int NJ = 4, bool A3 = false, bool SK = false>
+A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const int kend, const int mode, const int worker, const int c_first) {
     typedef StageTile<T, KB> ST;
     typedef KcGeom<KB> G;
     typedef Mma<T> MM;
@@ -256,8 +268,7 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = w >> 1, wn = w & 1;            // wm in [0, NWM)
-    const int split = bid / (g.tiles_m * g.tiles_n);
-    const int tile = bid - split * (g.tiles_m * g.tiles_n);
+    if constexpr (SK) __syncthreads();            // the previous segment's epilogue is done with the LDS this segment's DMAs refill
     // grouped tile order: consecutive ids (= one XCD's co-resident blocks) cover GROUP_M m-tiles x several n-tiles, so
     // both the A row-panels and the B tiles they touch stay resident in that XCD's 4 MB L2 (sweeping all n-tiles per
     // m-panel streamed the whole weight matrix through L2 once per panel: 5-10x over-fetch measured with FETCH_SIZE).
@@ -267,8 +278,6 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
     const int gsz = min(GROUP_M, g.tiles_m - first_m);
     const int tin = tile - grp * tpg;
     const int m0 = (first_m + tin % gsz) * BM, n0 = (tin / gsz) * BN;
-    const int kbeg = split * g.kchunk;
-    const int kend = min(g.K, kbeg + g.kchunk);
     const int nkb = (kend - kbeg + BK - 1) / BK;
     const char* zero = reinterpret_cast<const char*>(g_zero16);
 
@@ -316,13 +325,13 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
         if constexpr (AKS) {
             const long long k = kbeg + a_k[j];
             a_cur[j] = a_ptr[j] + outer_off(g.A, k) * SZ;
-            a_r[j] = g.A.rpb ? (int)(k % g.A.rpb) : 0;
+            a_r[j] = g.A.rpb ? (int)((unsigned)k % (unsigned)g.A.rpb) : 0;
             a_k[j] = (int)k;
         }
         if constexpr (BKS) {
             const long long k = kbeg + b_k[j];
             b_cur[j] = b_ptr[j] + outer_off(g.B, k) * SZ;
-            b_r[j] = g.B.rpb ? (int)(k % g.B.rpb) : 0;
+            b_r[j] = g.B.rpb ? (int)((unsigned)k % (unsigned)g.B.rpb) : 0;
             b_k[j] = (int)k;
         }
     }
@@ -375,7 +384,7 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
     T8z zpre[2 * MI];
     bool use_zpre = false;
     if constexpr (ZPRE) {
-        use_zpre = g.zpre && g.zin != nullptr && !g.out_f32 && (g.act == A8_ACT_MUL_GELU_GRAD || g.act == A8_ACT_ADD);
+        use_zpre = g.zpre && g.zin != nullptr && !g.out_f32 && (g.act == A8_ACT_MUL_GELU_GRAD || g.act == A8_ACT_ADD) && !(SK && mode == SEG_PARTIAL);
         if (use_zpre) {
             const int c8 = (lane & 7) << 3, n = n0 + wn * (16 * NJ) + c8;
 #pragma unroll
@@ -383,7 +392,7 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
                 const int m = m0 + wm * (16 * MI) + 8 * it + (lane >> 3);
                 zpre[it] = T8z{};
                 if (m < g.M && n < g.N && c8 < 16 * NJ) {
-                    const long long zr = g.z_rpb ? (m / g.z_rpb) * g.z_bs + (m % g.z_rpb) * g.ldz : (long long)m * g.ldz;
+                    const long long zr = remap_off(m, g.z_rpb, g.z_bs, g.ldz);
                     zpre[it] = *reinterpret_cast<const T8z*>(reinterpret_cast<const T*>(g.zin) + zr + n);
                 }
             }
@@ -393,7 +402,7 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
     float bpre[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // the lane's 8 bias columns, for the same reason
     bool use_bpre = false;
     if constexpr (ZPRE && !BKS) {                                     // (a bias rides on forward products: NT)
-        use_bpre = g.zpre && g.bias != nullptr && !g.bias_rows && !g.out_f32;
+        use_bpre = g.zpre && g.bias != nullptr && !g.bias_rows && !g.out_f32 && !(SK && mode == SEG_PARTIAL);
         if (use_bpre) {
             const int c8 = (lane & 7) << 3, n = n0 + wn * (16 * NJ) + c8;
             if (n < g.N && c8 < 16 * NJ) {
@@ -498,7 +507,100 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    if constexpr (SK) {
+        // In-launch hand-off of partial sums (cdna_hip_programming.md, Guideline 16 R1): the payload is stored write-through
+        // (sc1, 16 B per lane), every storing wave drains its stores, the workgroup meets, ONE lane stores the flag (agent scope);
+        // the finishing workgroup polls that one word relaxed, makes ONE agent-scope acquire, waits for it, meets, then reads the
+        // slab with plain loads.  Results do not depend on dispatch order or XCD placement; a finisher only ever waits for
+        // workers with a LOWER block index, which process their contributed segment first (see gemm_sk_kernel).
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(1))) unsigned gu32;
+        char* const slabs = g.sk_ws + SK_FLAG_BYTES;
+        const int lane_off = ((w * (MI * NJ)) * 64 + lane) * 16;
+        if (mode == SEG_PARTIAL) {
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slabs + (long long)worker * SK_SLAB_BYTES, 0, SK_SLAB_BYTES, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs, lane_off + (i * NJ + j) * 1024, 0, 16);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // EVERY storing wave drains ...
+            __syncthreads();                                            // ... before the one lane that signals for all of them
+            if (t == 0) __hip_atomic_store((gu32*)(g.sk_ws + (long long)worker * SK_FLAG_STRIDE), g.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        if (mode == SEG_FINISH) {
+            if (t == 0) {
+                for (int c = c_first; c < worker; c += SK_XCDS) {
+                    unsigned spins = 0;                                 // bounded (~2 s): a lost contributor must not hang the GPU; the
+                    while (__hip_atomic_load((gu32*)(g.sk_ws + (long long)c * SK_FLAG_STRIDE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != g.sk_epoch) {
+                        __builtin_amdgcn_s_sleep(4);                    // give-up word (last flag slot) tells the host the result is invalid
+                        if (++spins > (1u << 24)) {
+                            __hip_atomic_store((gu32*)(g.sk_ws + SK_FLAG_BYTES - SK_FLAG_STRIDE), g.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // ONE acquire after the last poll has matched
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (holds the barrier below until the invalidate has completed)
+            }
+            __syncthreads();
+            for (int c = c_first; c < worker; c += SK_XCDS) {
+                const f32x4* sl = reinterpret_cast<const f32x4*>(slabs + (long long)c * SK_SLAB_BYTES + lane_off);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] += sl[(i * NJ + j) * 64];
+            }
+        }
+    }
     gemm_epilogue<T, MI, NWM, NP, NJ>(g, acc, lds, w, m0, n0, lane, zpre, use_zpre, bpre, use_bpre);
+}
+
+template <typename T, bool AKS, bool BKS, int KB, int NST, int NWM, int MIP = 0, int NJ = 4, bool A3 = false>
+A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
+    const int split = bid / (g.tiles_m * g.tiles_n);
+    const int kbeg = split * g.kchunk;
+    gemm_core<T, AKS, BKS, KB, NST, NWM, MIP, NJ, A3, false>(g, bid - split * (g.tiles_m * g.tiles_n), kbeg, min(g.K, kbeg + g.kchunk), SEG_FULL, 0, 0);
+}
+
+// ---- stream-K (bf16 NT, 128 x 128 tiles): the launch's k-tile iterations (tiles x k-tiles, tile-major) are cut into gridDim.x equal
+// contiguous ranges, one per workgroup, so every co-resident slot of the chip gets the same amount of main-loop work whatever the
+// tile count (294 tiles of M = 6248, N = 768 otherwise leave 218 of 512 slots empty while 38 CUs run two tiles).  A range covers
+// the tail of one tile, whole tiles, and the head of another; it is processed BACKWARDS -- the head (whose partial sums another
+// workgroup is going to need) first, the tail (which needs other workgroups' partial sums) last -- so a finisher finds its
+// contributors' slabs already published.
+template <typename T>
+__global__ __launch_bounds__(512, 4) void gemm_sk_kernel(const GemmArgs g) {
+    constexpr int BK = 64;
+    // The tiles are first dealt to the 8 block classes b % 8 in contiguous, tile-aligned chunks (what xcd_remap does for the
+    // default kernel: the blocks of one XCD work on neighbouring tiles and share their operand panels in that XCD's L2); the
+    // k-tile iterations of a chunk are then cut into equal ranges for the class's workers j = b / 8.  A finisher waits for workers
+    // j' < j of its own class only: blocks b - 8, b - 16 ..., which were dispatched before it.
+    const unsigned x = blockIdx.x % SK_XCDS, j = blockIdx.x / SK_XCDS, WX = gridDim.x / SK_XCDS;
+    const unsigned ntile = g.tiles_m * g.tiles_n, q = ntile / SK_XCDS, r = ntile % SK_XCDS;
+    const unsigned t0 = x * q + (x < r ? x : r), nt = q + (x < r ? 1u : 0u);
+    const unsigned KT = (g.K + BK - 1) / BK;
+    const unsigned U = nt * KT;                                         // < 2^21 (host check): j * U fits 32 bits
+    const unsigned u0 = j * U / WX, u1 = (j + 1) * U / WX;
+    unsigned u = u1;
+    while (u > u0) {
+        const unsigned tl = (u - 1) / KT;                               // tile within the chunk
+        const unsigned tbase = tl * KT;
+        const unsigned lo = u0 > tbase ? u0 : tbase;
+        const int ka = (int)(lo - tbase), kb = (int)(u - tbase);
+        const int mode = (ka == 0 && kb == (int)KT) ? SEG_FULL : (kb == (int)KT ? SEG_FINISH : SEG_PARTIAL);
+        const unsigned tile = t0 + tl;
+        int c_first = (int)blockIdx.x;
+        if (mode == SEG_FINISH) {                      // the worker of this class whose range holds the tile's first iteration
+            unsigned e = tbase * WX / U;
+            while ((e + 1) * U / WX <= tbase) ++e;
+            while (e * U / WX > tbase) --e;
+            c_first = (int)(x + SK_XCDS * e);
+        }
+        gemm_core<T, false, false, 2, 2, 4, 0, 4, false, true>(g, (int)tile, ka * BK, min(g.K, kb * BK), mode, (int)blockIdx.x, c_first);
+        u = lo;
+    }
 }
 
 // ---- tall tiles for the products that would put between one and two 128 x 128 tiles on a CU (M = 6248, N = 768: 294 tiles on
@@ -649,13 +751,13 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs g) {
 
     // ---- epilogue: register r of acc[i][j] is column 16 j + 4 (lane >> 4) + r of row 16 i + (lane & 15)
     typedef T T4 __attribute__((ext_vector_type(4)));
-    auto zrow = [&](int m) -> long long { return g.z_rpb ? (m / g.z_rpb) * g.z_bs + (m % g.z_rpb) * g.ldz : (long long)m * g.ldz; };
+    auto zrow = [&](int m) -> long long { return remap_off(m, g.z_rpb, g.z_bs, g.ldz); };
     const int li = lane & 15, c4 = 4 * (lane >> 4);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int m = m0 + ra + 16 * i + li;
         if (m >= g.M) continue;
-        const long long crow = g.c_rpb ? (m / g.c_rpb) * g.c_bs + (m % g.c_rpb) * g.ldc : (long long)m * g.ldc;
+        const long long crow = remap_off(m, g.c_rpb, g.c_bs, g.ldc);
         const long long zr = (g.zout || g.zin) ? zrow(m) : 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -740,7 +842,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w512_kernel(const GemmArgs g) {
         return *reinterpret_cast<const typename MM::Frag*>(tl + row * KROW + (((ks * 4 + (lane >> 4)) ^ (row & 7)) << 4));
     };
     typedef T T4 __attribute__((ext_vector_type(4)));
-    auto zrow = [&](int m) -> long long { return g.z_rpb ? (m / g.z_rpb) * g.z_bs + (m % g.z_rpb) * g.ldz : (long long)m * g.ldz; };
+    auto zrow = [&](int m) -> long long { return remap_off(m, g.z_rpb, g.z_bs, g.ldz); };
 
     issue();
     int cslot = 0;
@@ -785,7 +887,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w512_kernel(const GemmArgs g) {
         for (int i = 0; i < 4; ++i) {
             const int m = m0 + 64 * wr + 16 * i + li;
             if (m >= g.M) continue;
-            const long long crow = g.c_rpb ? (m / g.c_rpb) * g.c_bs + (m % g.c_rpb) * g.ldc : (long long)m * g.ldc;
+            const long long crow = remap_off(m, g.c_rpb, g.c_bs, g.ldc);
             const long long zr = (g.zout || g.zin) ? zrow(m) : 0;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -905,6 +1007,8 @@ static int build_args(const a8_gemm_desc* d, GemmArgs& g, long long* grid) {
     A8_REQUIRE(((uintptr_t)d->A % 16) == 0 && ((uintptr_t)d->B % 16) == 0 && ((uintptr_t)d->C % 16) == 0, "a8_gemm: pointers must be 16-byte aligned");
     A8_REQUIRE(d->a_bs % epc == 0 && d->b_bs % epc == 0, "a8_gemm: batch strides must keep 16-byte alignment");
     const int bk = d->dtype == A8_BF16 ? ((g_variant == 1 || g_variant == 6 || g_variant == 7) ? 32 : 64) : 16;
+    A8_REQUIRE(d->a_rpb >= 0 && d->b_rpb >= 0 && d->c_rpb >= 0 && d->z_rpb >= 0 && d->a_rpb < (1ll << 31) && d->b_rpb < (1ll << 31) &&
+               d->c_rpb < (1ll << 31) && d->z_rpb < (1ll << 31), "a8_gemm: rows-per-batch remaps must fit 31 bits");
     g.A = Op{(const char*)d->A, d->lda, d->a_rpb, d->a_bs};
     g.B = Op{(const char*)d->B, d->ldb, d->b_rpb, d->b_bs};
     g.C = (char*)d->C; g.ldc = d->ldc; g.c_rpb = d->c_rpb; g.c_bs = d->c_bs;
@@ -919,6 +1023,7 @@ static int build_args(const a8_gemm_desc* d, GemmArgs& g, long long* grid) {
     g.kchunk = kchunk; g.nsplit = nsplit;
     g.act = d->act; g.out_f32 = d->out_f32; g.alpha = d->alpha;
     g.group_m = g_a8_tuning[12] > 0 ? g_a8_tuning[12] : 8;           // m-tiles per tile-order group (developer knob 12; 8 measured best)
+    g.sk_ws = (char*)d->sk_ws; g.sk_epoch = d->sk_epoch;
     g.zpre = g_a8_tuning[15] == 0;                                   // developer knob 15: 1 = load zin in the epilogue (the round-1 form)
     g.atomic = (nsplit > 1 || d->accumulate) ? 1 : 0;
     A8_REQUIRE(!(g.atomic && !d->out_f32), "a8_gemm: split-K / accumulate needs an f32 output");
@@ -962,6 +1067,18 @@ extern "C" int a8_gemm(const a8_gemm_desc* d, void* stream) {
             g.tiles_m = cdiv(d->M, 128); g.tiles_n = d->N / 512;
             const int nt = g.tiles_m * g.tiles_n;
             hipLaunchKernelGGL(gemm_w512_kernel<bf16>, dim3(nt < 256 ? nt : 256), dim3(512), 0, s, g);
+            return a8_check_launch("a8_gemm");
+        }
+    }
+    // Stream-K (a8_set_tuning key 16: 0 = never, 1 = below three rounds of the 512 slots unless the tiles fill them exactly, 2 = whenever eligible)
+    if (d->dtype == A8_BF16 && d->layout == A8_GEMM_NT && g_variant == 5 && g_a8_tuning[16] > 0 && d->sk_ws && g.nsplit == 1 && !g.atomic &&
+        d->K >= 64) {
+        A8_REQUIRE(d->sk_ws_bytes >= A8_GEMM_SK_WS_BYTES && ((uintptr_t)d->sk_ws % 256) == 0 && d->sk_epoch != 0,
+                   "a8_gemm: the stream-K workspace needs %d bytes, 256-byte alignment and a non-zero epoch", (int)A8_GEMM_SK_WS_BYTES);
+        const long long units = grid * (long long)cdiv(d->K, 64);
+        const bool awkward = grid < 3 * A8_GEMM_SK_WORKERS && grid % A8_GEMM_SK_WORKERS != 0;
+        if ((g_a8_tuning[16] == 2 || awkward) && units >= 2 * A8_GEMM_SK_WORKERS && units < (1ll << 21)) {
+            hipLaunchKernelGGL(gemm_sk_kernel<bf16>, dim3(A8_GEMM_SK_WORKERS), dim3(512), 0, s, g);
             return a8_check_launch("a8_gemm");
         }
     }

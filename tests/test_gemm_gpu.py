@@ -324,3 +324,58 @@ def test_gemm_pipelined_256_kernel_matches_default(key):
                 zin=zprev, ldz=2 * cin, z_rpb=Lout + 1, z_bs=(2 * Lout + 1) * cin)
         return (dx,)
     same(*both(conv_dgrad_even), "conv dgrad remap")
+
+
+def test_gemm_stream_k_matches_default():
+    """Stream-K (a8_set_tuning key 16; bf16 NT with a workspace): the k-tile iterations of all tiles are cut into 512 equal ranges,
+    tiles split between workgroups are combined through f32 slabs inside the launch.  Integer operands (every partial sum exact):
+    bit-identical to the default kernel; random operands: equal up to the f32 summation order, i.e. at most one bf16 ulp.  Covers many
+    contributors per tile (K = 2056: 33 k-tiles, a K tail), M tails, every epilogue, and repeated launches on one workspace."""
+    from audio8_amd import kernels as Kn, _lib as L
+    dev, bf = "cuda", torch.bfloat16
+
+    def both(fn, reps=1):
+        try:
+            Kn.STREAM_K = True                                   # (hands every eligible product a workspace)
+            L.check(L.lib().a8_set_tuning(16, 0), "tune")
+            ref = fn()
+            L.check(L.lib().a8_set_tuning(16, 2), "tune")
+            got = [fn() for _ in range(reps)]
+        finally:
+            L.check(L.lib().a8_set_tuning(16, 0), "tune")
+            Kn.STREAM_K = False
+        return ref, got
+
+    for (M, N, K) in [(1000, 768, 2056), (6248, 768, 3072), (6248, 768, 768), (6248, 3072, 768), (6248, 2304, 768), (4099, 1024, 1024)]:
+        A, B = _mk((M, K), bf, 1, integer=True).to(dev), _mk((N, K), bf, 2, integer=True).to(dev)
+        ref, got = both(lambda: Kn.gemm(L.NT, A, B, M, N, K, out_dtype=torch.float32), reps=4)
+        assert torch.equal(ref.cpu().double(), A.cpu().double() @ B.cpu().double().T)
+        for g_ in got:
+            assert torch.equal(ref, g_), (M, N, K)
+    M, N, K = 6248, 768, 3072
+    A, B = _mk((M, K), bf, 3).to(dev), _mk((N, K), bf, 4).to(dev)
+    z, bias = _mk((M, N), bf, 5).to(dev), torch.randn(N, device=dev)
+
+    def close(ref, got, what):
+        for g_ in got:
+            for r, o in zip(ref, g_):
+                torch.testing.assert_close(r.float(), o.float(), rtol=1.6e-2, atol=1e-3, msg=lambda m: "%s: %s" % (what, m))
+            for o, o0 in zip(g_, got[0]):
+                assert torch.equal(o, o0), what + ": repeated launches differ"            # slab combination order is fixed: deterministic
+
+    def gelu_zout():
+        zo = torch.empty(M, N, device=dev, dtype=bf)
+        return Kn.gemm(L.NT, A, B, M, N, K, bias=bias, act=L.ACT_GELU, zout=zo, alpha=0.02), zo
+    close(*both(gelu_zout, 3), "bias + gelu + zout")
+    close(*both(lambda: (Kn.gemm(L.NT, A, B, M, N, K, act=L.ACT_MUL_GELU_GRAD, zin=z, alpha=0.02),), 3), "x gelu'(z)")
+    close(*both(lambda: (Kn.gemm(L.NT, A, B, M, N, K, act=L.ACT_ADD, zin=z, alpha=0.02),), 3), "add")
+
+    def with_colsum():
+        cs = torch.zeros(N, device=dev)
+        return Kn.gemm(L.NT, A, B, M, N, K, alpha=0.02, colsum=cs), cs
+    ref, got = both(with_colsum, 2)
+    for g_ in got:
+        torch.testing.assert_close(ref[0].float(), g_[0].float(), rtol=1.6e-2, atol=1e-3)
+        torch.testing.assert_close(ref[1], g_[1], rtol=1e-3, atol=0.5)
+    for ws, _ in Kn._SK_WS.values():                      # the give-up word of a bounded spin (last flag slot) was never written
+        assert int(ws[65536 - 64:65536 - 60].view(torch.int32).item()) == 0
