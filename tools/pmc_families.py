@@ -8,7 +8,7 @@ import glob
 import json
 import sys
 
-FAMILIES = [("gemm", lambda k: ("gemm_kernel" in k or "gemm_grouped_kernel" in k or "gemm_tall" in k or "gemm_p256" in k) and "<float" not in k and "IfL" not in k),
+FAMILIES = [("gemm", lambda k: ("gemm_" in k and "kernel" in k) and "<float" not in k and "IfL" not in k),
             ("conv0_apply", lambda k: "conv0_apply" in k), ("conv0_bwd", lambda k: "conv0_bwd_m" in k), ("conv0_moments", lambda k: "conv0_moments" in k),
             ("ln_fwd", lambda k: "ln_fwd" in k), ("ln_bwd", lambda k: "ln_bwd" in k),
             ("attn_fwd", lambda k: "attn_fwd" in k), ("attn_bwd_q", lambda k: "attn_bwd_q" in k), ("attn_bwd_kv", lambda k: "attn_bwd_kv" in k),
@@ -35,7 +35,7 @@ def main():
         fam[name] = {"launches_per_step": round(len(f) / steps, 2), "fetch_bytes_per_launch": round(sum(f) / len(f)),
                      "write_bytes_per_launch": round(sum(w) / max(1, len(w))), "hbm_bytes_per_step": round((sum(f) + sum(w)) / steps)}
     g = fam["gemm"]
-    res = {"kernel": "gemm_kernel<bf16> + gemm_grouped_kernel<bf16>", "steps_profiled": steps,
+    res = {"kernel": "every bf16 a8_gemm / a8_gemm_grouped kernel (gemm_kernel, gemm_grouped_kernel and their asymmetric-ring forms)", "steps_profiled": steps,
            "fetch_bytes_per_launch": g["fetch_bytes_per_launch"], "write_bytes_per_launch": g["write_bytes_per_launch"],
            "hbm_bytes_per_launch": g["fetch_bytes_per_launch"] + g["write_bytes_per_launch"], "hbm_bytes_per_step": g["hbm_bytes_per_step"],
            "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes); KiB units; FETCH_SIZE x2 (gfx950)",
