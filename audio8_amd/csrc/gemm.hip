@@ -376,42 +376,44 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // The epilogues that read a second input (x gelu'(z), + residual) get it NOW: the loads are older than every DMA of the main
-    // loop, so its first counted wait retires them together with the first k-tile (their latency would otherwise sit, exposed,
+    // The epilogues that read a second input (x gelu'(z), + residual) get it EARLY: right behind the first k-tile's DMAs (whose
+    // issue they must not delay), so the loop's first counted wait retires them together with that k-tile (their latency would otherwise sit, exposed,
     // between the last MFMA and the stores of every tile).  16-bit rows only; the lane -> (row, 8 columns) map of gemm_epilogue.
     typedef typename Vec8<T>::type T8z;
     constexpr bool ZPRE = sizeof(T) == 2 && NP == 1;
     T8z zpre[2 * MI];
     bool use_zpre = false;
-    if constexpr (ZPRE) {
-        use_zpre = g.zpre && g.zin != nullptr && !g.out_f32 && (g.act == A8_ACT_MUL_GELU_GRAD || g.act == A8_ACT_ADD) && !(SK && mode == SEG_PARTIAL);
-        if (use_zpre) {
-            const int c8 = (lane & 7) << 3, n = n0 + wn * (16 * NJ) + c8;
+    float bpre[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // the lane's 8 bias columns, for the same reason
+    bool use_bpre = false;
+    auto prefetch_epilogue_inputs = [&]() {
+        if constexpr (ZPRE) {
+            use_zpre = g.zpre && g.zin != nullptr && !g.out_f32 && (g.act == A8_ACT_MUL_GELU_GRAD || g.act == A8_ACT_ADD) && !(SK && mode == SEG_PARTIAL);
+            if (use_zpre) {
+                const int c8 = (lane & 7) << 3, n = n0 + wn * (16 * NJ) + c8;
 #pragma unroll
-            for (int it = 0; it < 2 * MI; ++it) {
-                const int m = m0 + wm * (16 * MI) + 8 * it + (lane >> 3);
-                zpre[it] = T8z{};
-                if (m < g.M && n < g.N && c8 < 16 * NJ) {
-                    const long long zr = remap_off(m, g.z_rpb, g.z_bs, g.ldz);
-                    zpre[it] = *reinterpret_cast<const T8z*>(reinterpret_cast<const T*>(g.zin) + zr + n);
+                for (int it = 0; it < 2 * MI; ++it) {
+                    const int m = m0 + wm * (16 * MI) + 8 * it + (lane >> 3);
+                    zpre[it] = T8z{};
+                    if (m < g.M && n < g.N && c8 < 16 * NJ) {
+                        const long long zr = remap_off(m, g.z_rpb, g.z_bs, g.ldz);
+                        zpre[it] = *reinterpret_cast<const T8z*>(reinterpret_cast<const T*>(g.zin) + zr + n);
+                    }
                 }
             }
         }
-    }
 
-    float bpre[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // the lane's 8 bias columns, for the same reason
-    bool use_bpre = false;
-    if constexpr (ZPRE && !BKS) {                                     // (a bias rides on forward products: NT)
-        use_bpre = g.zpre && g.bias != nullptr && !g.bias_rows && !g.out_f32 && !(SK && mode == SEG_PARTIAL);
-        if (use_bpre) {
-            const int c8 = (lane & 7) << 3, n = n0 + wn * (16 * NJ) + c8;
-            if (n < g.N && c8 < 16 * NJ) {
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias + n), b1 = *reinterpret_cast<const f32x4*>(g.bias + n + 4);
+        if constexpr (ZPRE && !BKS) {                                     // (a bias rides on forward products: NT)
+            use_bpre = g.zpre && g.bias != nullptr && !g.bias_rows && !g.out_f32 && !(SK && mode == SEG_PARTIAL);
+            if (use_bpre) {
+                const int c8 = (lane & 7) << 3, n = n0 + wn * (16 * NJ) + c8;
+                if (n < g.N && c8 < 16 * NJ) {
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias + n), b1 = *reinterpret_cast<const f32x4*>(g.bias + n + 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { bpre[e] = b0[e]; bpre[e + 4] = b1[e]; }
+                    for (int e = 0; e < 4; ++e) { bpre[e] = b0[e]; bpre[e + 4] = b1[e]; }
+                }
             }
         }
-    }
+    };
 
     if constexpr (A3) {
         // Asymmetric ring: the A operand (activations, streamed once from HBM / the Infinity Cache) is requested TWO k-tiles
@@ -437,6 +439,7 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
         char* const bbase = lds + 3 * TA;
         issue_a(0, lds);
         issue_b(0, bbase);
+        prefetch_epilogue_inputs();
         issue_a(1, lds + TA);
         int sa = 0, sb = 0;                           // ring slots of the k-tile being consumed
         for (int kb = 0; kb < nkb; ++kb) {
@@ -468,6 +471,7 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
     } else {
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s) issue(s);
+    prefetch_epilogue_inputs();
     for (int kb = 0; kb < nkb; ++kb) {
         // stage kb has landed once all but the (NST-2) youngest stages' DMAs of this wave are done (2*PPW per stage per lane)
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NST - 2) * (PPA + PPB)) : "memory");
