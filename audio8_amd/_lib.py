@@ -25,6 +25,7 @@ ARGTYPES = {
     "a8_gemm": [C.c_void_p, C.c_void_p],
     "a8_gemm_grouped": [C.c_void_p, C.c_int, C.c_void_p],
     "a8_set_tuning": [C.c_int, C.c_int],
+    "a8_debug_set_stamps": [C.c_void_p],
     "a8_prepare_weights": [C.c_int, C.c_void_p, C.c_int, C.c_void_p],
     "a8_prepare_weights_device": [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p],
     "a8_conv0_gn_gelu_fwd": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p],
@@ -142,7 +143,7 @@ def require_cuda(*ts):
 
 
 EXPORTS = [
-    "a8_version", "a8_last_error", "a8_gemm", "a8_gemm_grouped", "a8_set_tuning", "a8_prepare_weights", "a8_prepare_weights_device",
+    "a8_version", "a8_last_error", "a8_gemm", "a8_gemm_grouped", "a8_set_tuning", "a8_debug_set_stamps", "a8_prepare_weights", "a8_prepare_weights_device",
     "a8_conv0_gn_gelu_fwd", "a8_conv0_gn_gelu_bwd", "a8_col2im_gelu_grad",
     "a8_layernorm_fwd", "a8_layernorm_bwd",
     "a8_cast", "a8_dropout", "a8_mask_fill_rows", "a8_mask_fill_rows_bwd", "a8_mask_zero_cols", "a8_zero_rows",

@@ -30,6 +30,7 @@ struct GemmArgs {
     float* colsum;
     int M, N, K, kchunk, nsplit, tiles_m, tiles_n;
     int act, out_f32, atomic, bias_rows, group_m, zpre;
+    unsigned long long* stamps;                   // developer aid (a8_debug_set_stamps): 8 timestamps per block, nullptr = off
     char* sk_ws; unsigned sk_epoch;               // stream-K: flag words (64 B apart) then 64 KB f32 slabs, one of each per worker
     float alpha;
 };
@@ -236,6 +237,10 @@ A8_DEV void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MI][NJ], char* lds, co
 
 // Main loop: NST-deep ring of LDS stages filled by LDS-DMA (global_load_lds, 16 B per lane), NST-1 k-tiles in
 // flight per block; one raw s_barrier and one counted s_waitcnt vmcnt per k-tile; no register staging.
+A8_DEV void stamp(const GemmArgs& g, int i) {
+    if (g.stamps && threadIdx.x == 0) g.stamps[(long long)blockIdx.x * 8 + i] = __builtin_amdgcn_s_memrealtime();
+}
+
 // Stream-K segment kinds (gemm_core's `mode`): a whole tile; the LAST k-range of a tile (adds the partial sums the other
 // contributors published, then runs the epilogue); any other k-range (publishes its partial sums, no epilogue)
 enum { SEG_FULL = 0, SEG_FINISH = 1, SEG_PARTIAL = 2 };
@@ -269,6 +274,7 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = w >> 1, wn = w & 1;            // wm in [0, NWM)
     if constexpr (SK) __syncthreads();            // the previous segment's epilogue is done with the LDS this segment's DMAs refill
+    if constexpr (!SK) stamp(g, 0);
     // grouped tile order: consecutive ids (= one XCD's co-resident blocks) cover GROUP_M m-tiles x several n-tiles, so
     // both the A row-panels and the B tiles they touch stay resident in that XCD's 4 MB L2 (sweeping all n-tiles per
     // m-panel streamed the whole weight matrix through L2 once per panel: 5-10x over-fetch measured with FETCH_SIZE).
@@ -471,11 +477,13 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
     } else {
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s) issue(s);
+    if constexpr (!SK) stamp(g, 1);
     prefetch_epilogue_inputs();
     for (int kb = 0; kb < nkb; ++kb) {
         // stage kb has landed once all but the (NST-2) youngest stages' DMAs of this wave are done (2*PPW per stage per lane)
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NST - 2) * (PPA + PPB)) : "memory");
         __builtin_amdgcn_s_barrier();
+        if constexpr (!SK) { if (kb == 0) stamp(g, 2); }
         // DMA issue order, measured: with plain b128 fragment reads (NT) issuing the refill first is best; with
         // transposed reads (twice the LDS instructions) issuing it after the reads hides its issue slots in their latency
         if constexpr (!(AKS || BKS)) issue(kb + NST - 1);
@@ -508,6 +516,7 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
     }
     }
     // no DMA may still be in flight, and every wave must be done reading the ring, before LDS is reused
+    if constexpr (!SK) stamp(g, 3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -559,6 +568,10 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
         }
     }
     gemm_epilogue<T, MI, NWM, NP, NJ>(g, acc, lds, w, m0, n0, lane, zpre, use_zpre, bpre, use_bpre);
+    if constexpr (!SK) {
+        __syncthreads();
+        stamp(g, 4);
+    }
 }
 
 template <typename T, bool AKS, bool BKS, int KB, int NST, int NWM, int MIP = 0, int NJ = 4, bool A3 = false>
@@ -995,6 +1008,9 @@ template <typename T> int launch(const a8_gemm_desc* d, const GemmArgs& g, int g
 
 }  // namespace
 
+static unsigned long long* g_stamps = nullptr;
+extern "C" int a8_debug_set_stamps(void* p) { g_stamps = (unsigned long long*)p; return A8_OK; }
+
 // validates one descriptor and fills the kernel arguments; *grid = blocks it needs
 static int build_args(const a8_gemm_desc* d, GemmArgs& g, long long* grid) {
     A8_REQUIRE(d != nullptr, "a8_gemm: null descriptor");
@@ -1028,6 +1044,7 @@ static int build_args(const a8_gemm_desc* d, GemmArgs& g, long long* grid) {
     g.act = d->act; g.out_f32 = d->out_f32; g.alpha = d->alpha;
     g.group_m = g_a8_tuning[12] > 0 ? g_a8_tuning[12] : 8;           // m-tiles per tile-order group (developer knob 12; 8 measured best)
     g.sk_ws = (char*)d->sk_ws; g.sk_epoch = d->sk_epoch;
+    g.stamps = g_stamps;
     g.zpre = g_a8_tuning[15] == 0;                                   // developer knob 15: 1 = load zin in the epilogue (the round-1 form)
     g.atomic = (nsplit > 1 || d->accumulate) ? 1 : 0;
     A8_REQUIRE(!(g.atomic && !d->out_f32), "a8_gemm: split-K / accumulate needs an f32 output");

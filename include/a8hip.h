@@ -71,6 +71,9 @@ int a8_gemm_grouped(const a8_gemm_desc* descs, int n, void* stream);
  * otherwise the minimum M (default 10000: the conv layers); 16 stream-K for bf16 NT products given a workspace: 0 = off, 1 = when the tile count
  * is below three rounds of the 512 slots and not a multiple of them, 2 = whenever eligible; 15 = 1: the GEMM epilogues load their second input (zin) after the main loop instead of ahead of it */
 int a8_set_tuning(int key, int value);
+/* developer aid: when p is not NULL every a8_gemm block of the default kernels writes 5 timestamps (100 MHz counter: entry, first DMAs issued,
+ * first k-tile landed, main loop done, epilogue done) to ((uint64_t*)p)[8 * blockIdx + i]; NULL switches it off.  tools/tile_stamps.py */
+int a8_debug_set_stamps(void* p);
 
 /* ---- per-step weight preparation (the f32 -> compute-dtype casts the reference's autocast-free f32 path never needs;
  * conv kernels [rows][cols/kw][kw] are re-laid-out to [rows][kk*(cols/kw) + ci]).  dst [rows][cols] and/or dstT [cols][rows]. */
