@@ -247,7 +247,7 @@ enum { SEG_FULL = 0, SEG_FINISH = 1, SEG_PARTIAL = 2 };
 constexpr int SK_XCDS = 8;          // blocks b, b + 8, b + 16 ... are observed to share an XCD (a speed assumption only)
 constexpr int SK_FLAG_STRIDE = 64, SK_FLAG_BYTES = 65536, SK_SLAB_BYTES = 65536;     // (A8_GEMM_SK_WS_BYTES: flags, then A8_GEMM_SK_WORKERS slabs)
 
-template <typename T, bool AKS, bool BKS, int KB, int NST, int NWM, int MIP = 0, int NJ = 4, bool A3 = false, bool SK = false>
+template <typename T, bool AKS, bool BKS, int KB, int NST, int NWM, int MIP = 0, int NJ = 4, bool A3 = false, bool SK = false, bool PIPE = false>
 A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const int kend, const int mode, const int worker, const int c_first) {
     typedef StageTile<T, KB> ST;
     typedef KcGeom<KB> G;
@@ -421,7 +421,57 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
         }
     };
 
-    if constexpr (A3) {
+    if constexpr (PIPE) {
+        // One block per CU (tools/tile_stamps.py: a lone block of the default loop spends 0.65 us per k-tile -- one LDS-DMA round trip,
+        // then its fragment reads, then its MFMAs, in series -- for 0.21 us of MFMA work).  Here the fragments of k-tile kb+1 are read
+        // into a second register set while k-tile kb multiplies, which also frees the LDS stage of kb one iteration early: with NST
+        // stages the DMA of k-tile kb+NST is issued at the top of iteration kb and has NST-1 iterations to land.  One barrier per k-tile.
+        static_assert(!AKS && !BKS && !UNEVEN && !A3 && !SK, "the pipelined loop is built for NT and even piece counts");
+        typename MM::Frag fa[2][ST::KSTEPS][MI], fb[2][ST::KSTEPS][NJ];
+        auto rd = [&](int set, int kb) {
+            const char* ta = lds + (kb % NST) * STAGE;
+            const char* tb = ta + TA;
+#pragma unroll
+            for (int ks = 0; ks < ST::KSTEPS; ++ks) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) fa[set][ks][i] = ST::kc_frag(ta, wm * (16 * MI) + 16 * i, ks, lane);
+#pragma unroll
+                for (int i = 0; i < NJ; ++i) fb[set][ks][i] = ST::kc_frag(tb, wn * (16 * NJ) + 16 * i, ks, lane);
+            }
+        };
+        auto mm = [&](int set) {
+#pragma unroll
+            for (int ks = 0; ks < ST::KSTEPS; ++ks)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = MM::mma(fb[set][ks][j], fa[set][ks][i], acc[i][j]);
+        };
+        issue(0);
+        prefetch_epilogue_inputs();                    // older than stages 1.. : retired by the wait for stage 0
+#pragma unroll
+        for (int s = 1; s < NST; ++s) issue(s);
+        stamp(g, 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 1) * (PPA + PPB)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        stamp(g, 2);
+        rd(0, 0);
+        auto iter = [&](int kb, int cur) {
+            // DMA(kb+1) has landed once all but the NST-2 youngest stages' pieces are done; this wave's reads of stage kb are complete
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NST - 2) * (PPA + PPB)) : "memory");
+            __builtin_amdgcn_s_barrier();
+            issue(kb + NST);                           // into the stage of k-tile kb: every wave holds its fragments in registers
+            __builtin_amdgcn_sched_barrier(0);
+            if (kb + 1 < nkb) rd(cur ^ 1, kb + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(cur);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        for (int kb = 0; kb < nkb; kb += 2) {
+            iter(kb, 0);
+            if (kb + 1 < nkb) iter(kb + 1, 1);
+        }
+    } else if constexpr (A3) {
         // Asymmetric ring: the A operand (activations, streamed once from HBM / the Infinity Cache) is requested TWO k-tiles
         // ahead into a 3-deep ring, the B operand (weights, L2-resident) one k-tile ahead into a 2-deep ring: 3 x 16 + 2 x 16 = 80 KB,
         // still two blocks per CU.  Per iteration a wave issues its B pieces first and its A pieces last, so "all but the PPA
@@ -447,10 +497,12 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
         issue_b(0, bbase);
         prefetch_epilogue_inputs();
         issue_a(1, lds + TA);
+        if constexpr (!SK) stamp(g, 1);
         int sa = 0, sb = 0;                           // ring slots of the k-tile being consumed
         for (int kb = 0; kb < nkb; ++kb) {
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPA) : "memory");
             __builtin_amdgcn_s_barrier();
+            if constexpr (!SK) { if (kb == 0) stamp(g, 2); }
             const int sa2 = sa == 0 ? 2 : sa - 1;     // (sa + 2) % 3: the slot read in the previous iteration
             issue_b(kb + 1, bbase + (sb ^ 1) * TB);   // (beyond kend: 16 zero bytes per lane -- keeps the counts uniform)
             issue_a(kb + 2, lds + sa2 * TA);
@@ -633,6 +685,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tall_kernel(const GemmArgs g) {
 template <typename T>
 __global__ __launch_bounds__(512, 4) void gemm_a3_kernel(const GemmArgs g) {
     gemm_body<T, false, false, 2, 2, 4, 0, 4, true>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n * g.nsplit));
+}
+
+// ---- tall tiles, ONE block per CU, register-pipelined main loop (gemm_core, PIPE): 192 x 128 with a 3-deep ring
+template <typename T, int MIP>
+__global__ __launch_bounds__(512, 2) void gemm_lone_kernel(const GemmArgs g) {
+    gemm_core<T, false, false, 2, 3, 4, MIP, 4, false, false, true>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n), 0, g.K, SEG_FULL, 0, 0);
 }
 
 // ---- 96-column tiles (8 waves of 32 x 48) for the products whose 128 x 128 tiling leaves the chip between one and two tiles per CU:
@@ -1123,7 +1181,13 @@ extern "C" int a8_gemm(const a8_gemm_desc* d, void* stream) {
         const long long t128 = grid, t192 = (long long)cdiv(d->M, 192) * g.tiles_n * g.nsplit, t256 = (long long)cdiv(d->M, 256) * g.tiles_n * g.nsplit;
         int mi = 0;
         if (mode == 3 || mode == 4) mi = mode;
-        else if (t128 > 256 && t128 <= 512) mi = t192 <= 256 ? 3 : (t256 <= 256 ? 4 : 0);
+        else if (mode == 1 && t128 > 256 && t128 <= 512) mi = t192 <= 256 ? 3 : (t256 <= 256 ? 4 : 0);
+        // modes 5 / 6: the register-pipelined 192-row kernel, by the same tile-count rule / always
+        if ((mode == 6 || (mode == 5 && t128 > 256 && t128 <= 512 && t192 <= 256)) && g.nsplit == 1) {
+            g.tiles_m = cdiv(d->M, 192);
+            hipLaunchKernelGGL((gemm_lone_kernel<bf16, 3>), dim3((int)t192), dim3(512), 0, s, g);
+            return a8_check_launch("a8_gemm");
+        }
         if (mi) {
             g.tiles_m = cdiv(d->M, 64 * mi);
             const int gr = (int)(mi == 3 ? t192 : t256);

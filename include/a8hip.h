@@ -66,7 +66,7 @@ int a8_gemm_grouped(const a8_gemm_desc* descs, int n, void* stream);
  * 16-row groups per wave); 5 minimum number of 256x256 tiles for the experimental pipelined NT GEMM (N % 256 == 0, K % 64 == 0, no bias; 0 = off);
  * 6 positional-conv weight-gradient loop splits; 7 experimental 160-row NT GEMM tiles for 257..512-tile problems (0 = off,
  * 2..4 = LDS ring depth); 8 tall (192 / 256-row) NT GEMM tiles, one block per CU: 0 = off, 1 = when the 128-row tiling would
- * put between one and two tiles on a CU, 3 / 4 = always 192 / 256 rows; 13 NT GEMM tiles of 128 x 96 (bf16, 96 | N): 0 = off, 1 = when 128-column
+ * put between one and two tiles on a CU, 3 / 4 = always 192 / 256 rows, 5 / 6 = the register-pipelined 192-row kernel by that rule / always; 13 NT GEMM tiles of 128 x 96 (bf16, 96 | N): 0 = off, 1 = when 128-column
  * tiles would leave 257..512 blocks, 2 = always; 14 asymmetric LDS ring for bf16 NT GEMMs (A requested two k-tiles ahead, B one): 0 = off,
  * otherwise the minimum M (default 10000: the conv layers); 16 stream-K for bf16 NT products given a workspace: 0 = off, 1 = when the tile count
  * is below three rounds of the 512 slots and not a multiple of them, 2 = whenever eligible; 15 = 1: the GEMM epilogues load their second input (zin) after the main loop instead of ahead of it */
