@@ -192,6 +192,7 @@ class TransformerEncoderStack(nn.Module):
         mask_u8 = None
         if mask is not None:
             mask_u8 = mask.reshape(B, T).to(torch.uint8).contiguous()
+        ops.wait_weight_prep()                 # the stack's bf16 weight copies may still be building on the side stream
         h = x.reshape(B * T, d)
         # one np.random.random() per layer per forward (eight_mile's layer-drop draw), taken up front -- or handed over by
         # wav2vec2.prefetch_host_draws, which took them in the same order while the GPU was busy with the previous step

@@ -116,6 +116,8 @@ CONV_DGRAD_CACHE = None      # id(conv weight, k = 3) -> (B_even [cin, 2co], B_o
 
 def cached_weights(p, dtype):
     if WEIGHT_CACHE is not None and dtype == WEIGHT_CACHE_DTYPE:
+        if WPREP_EVENT is not None and id(p) not in WPREP_EARLY:
+            wait_weight_prep()                 # a copy built on the side stream: whoever asks first makes the current stream wait
         return WEIGHT_CACHE.get(id(p))
     return None
 
@@ -161,6 +163,22 @@ def colsum(x2d, out=None):
     rows = x2d.numel() // x2d.shape[-1]
     L.check(L.lib().a8_gelu_bwd_bias(L.dt(x2d), L.ptr(x2d), None, None, L.ptr(out), rows, x2d.shape[-1], L.stream()), "a8_gelu_bwd_bias")
     return out
+
+
+# ------------------------------------------------------------------ split weight preparation
+# trainer.WeightCache.refresh() may build the encoder / head working copies on a side stream (beside the conv stack's forward);
+# the first consumer of those copies calls wait_weight_prep() once.  WPREP_SPLIT is the A/B knob.
+WPREP_SPLIT = True
+WPREP_EVENT = None
+WPREP_EARLY = frozenset()          # ids of the parameters whose copies are built on the caller's stream
+
+
+def wait_weight_prep():
+    global WPREP_EVENT
+    ev = WPREP_EVENT
+    if ev is not None:
+        torch.cuda.current_stream().wait_event(ev)
+        WPREP_EVENT = None
 
 
 # ------------------------------------------------------------------ direct gradient accumulation

@@ -85,6 +85,7 @@ class WeightCache:
         self.dtype = dtype
         dev = next(model.parameters()).device
         jobs = []               # (src_param, rows, cols, kw, tap, dst, dstT, ld_dst, ld_dstT)
+        early_ids = {id(p) for n, p in model.named_parameters() if n.startswith(("feature_extractor.", "proj_to_input.", "encoder.feature_extractor.", "encoder.proj_to_input."))}
         self.cache, self.conv_dgrad = {}, {}
         self._keep = []
 
@@ -130,26 +131,57 @@ class WeightCache:
                     # dx[2t+1] = dz[t] W[:, :, 1]
                     jobs.append((p, co, cin, kw, 1, None, b_odd, 0, 0))
                     self.conv_dgrad[id(p)] = (b_even, b_odd)
-        self.n = len(jobs)
-        self.descs = (L.WPrepDesc * self.n)()
-        starts = [0]
-        for i, (src, r, c, kw, tap, dst, dst_t, ld, ld_t) in enumerate(jobs):
-            self.descs[i] = L.WPrepDesc(src.data_ptr(), dst.data_ptr() if dst is not None else None,
-                                        dst_t.data_ptr() if dst_t is not None else None, r, c, kw, tap, ld, ld_t)
-            starts.append(starts[-1] + ((r + 63) // 64) * ((c + 63) // 64))
+        # Two descriptor tables: what the forward pass needs first (conv feature extractor, input projection) and the rest (encoder
+        # stack, heads).  refresh() builds the first on the caller's stream and -- given a side stream -- the second beside it, so the
+        # 0.16 ms of the second launch run under the conv stack; the encoder stack waits for ops.WPREP_EVENT once.
         self.params = [j[0] for j in jobs]
         self._src_ptrs = [p.data_ptr() for p in self.params]
-        raw = np.frombuffer(C.string_at(C.addressof(self.descs), C.sizeof(self.descs)), dtype=np.uint8).copy()
-        self.descs_dev = torch.from_numpy(raw).to(dev)
-        self.total_tiles = starts[-1]
-        self.tile_start_dev = torch.tensor(starts, dtype=torch.int32, device=dev)
+        self.tables = [self._table([j for j in jobs if id(j[0]) in early_ids], dev), self._table([j for j in jobs if id(j[0]) not in early_ids], dev)]
+        self.side = None
+        self.early_ids = frozenset(early_ids)
+
+    @staticmethod
+    def _table(jobs, dev):
+        import ctypes as C
+        import numpy as np
+        n = len(jobs)
+        if n == 0:
+            return None
+        descs = (L.WPrepDesc * n)()
+        starts = [0]
+        for i, (src, r, c, kw, tap, dst, dst_t, ld, ld_t) in enumerate(jobs):
+            descs[i] = L.WPrepDesc(src.data_ptr(), dst.data_ptr() if dst is not None else None,
+                                   dst_t.data_ptr() if dst_t is not None else None, r, c, kw, tap, ld, ld_t)
+            starts.append(starts[-1] + ((r + 63) // 64) * ((c + 63) // 64))
+        raw = np.frombuffer(C.string_at(C.addressof(descs), C.sizeof(descs)), dtype=np.uint8).copy()
+        return (torch.from_numpy(raw).to(dev), torch.tensor(starts, dtype=torch.int32, device=dev), n, starts[-1])
+
+    def _launch(self, table):
+        descs_dev, starts_dev, n, tiles = table
+        L.check(L.lib().a8_prepare_weights_device(L.dt(self._keep[0]), L.ptr(descs_dev), L.ptr(starts_dev), n, tiles, L.stream()),
+                "a8_prepare_weights_device")
 
     def refresh(self):
         for i, p in enumerate(self.params):               # parameters may have been re-pointed (e.g. .to(), load)
             if p.data_ptr() != self._src_ptrs[i]:
                 raise RuntimeError("WeightCache: a parameter's storage moved; rebuild the Stepper")
-        L.check(L.lib().a8_prepare_weights_device(L.dt(self._keep[0]), L.ptr(self.descs_dev), L.ptr(self.tile_start_dev), self.n,
-                                                  self.total_tiles, L.stream()), "a8_prepare_weights_device")
+        early, late = self.tables
+        if early is not None:
+            self._launch(early)
+        if late is None:
+            return
+        if self.side is None or not ops.WPREP_SPLIT:
+            self._launch(late)
+            return
+        cur = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(cur)                                    # the masters are final (AdamW is enqueued on `cur`)
+        self.side.wait_event(ev)
+        with torch.cuda.stream(self.side):
+            self._launch(late)
+            done = torch.cuda.Event()
+            done.record(self.side)
+        ops.WPREP_EVENT = done                            # taken (and cleared) by ops.wait_weight_prep() in front of the first consumer
 
 
 class GradReducer:
@@ -393,9 +425,12 @@ class Stepper:
         self.wcache = None
         if self.state.flat_p.is_cuda and ops.compute_dtype() == torch.bfloat16:
             self.wcache = WeightCache(model, torch.bfloat16)
+            self.wcache.side = self.wgrad_stream
             self.wcache.refresh()
+            ops.wait_weight_prep()                        # construction returns with the caller's stream ordered behind every copy
             ops.WEIGHT_CACHE, ops.WEIGHT_CACHE_DTYPE = self.wcache.cache, torch.bfloat16
             ops.CONV_DGRAD_CACHE = self.wcache.conv_dgrad
+            ops.WPREP_EARLY = self.wcache.early_ids
         self._versions = [p._version for p in self.state.params]
         global ACTIVE_STEPPER
         ACTIVE_STEPPER = self
@@ -408,6 +443,7 @@ class Stepper:
         """Rebuild the bf16 working copies (call after changing parameters outside step(), e.g. load_state_dict)."""
         if self.wcache is not None:
             self.wcache.refresh()
+            ops.wait_weight_prep()
         self._versions = [p._version for p in self.state.params]
 
     def zero_grad(self):
@@ -438,6 +474,8 @@ class Stepper:
         ops.WEIGHT_CACHE = None
         ops.WEIGHT_CACHE_DTYPE = None
         ops.CONV_DGRAD_CACHE = None
+        ops.wait_weight_prep()
+        ops.WPREP_EARLY = frozenset()
         global ACTIVE_STEPPER
         if ACTIVE_STEPPER is self:
             ACTIVE_STEPPER = None
