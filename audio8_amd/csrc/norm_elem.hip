@@ -43,18 +43,27 @@ static Drop make_drop(float p, uint32_t seed, uint32_t stream) {
 }
 
 // ------------------------------------------------------------------ LayerNorm forward
-template <typename T>
+// MC = 16-byte chunks per lane (cols <= 512 * MC).  gamma / beta are row-independent: loaded once per wave ahead of the row loop
+// (inside it they were one more dependent memory round trip between the variance reduction and the stores).
+template <typename T, int MC>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
                                                      int rows, int cols, float eps, Drop dr) {
     const int lane = threadIdx.x & 63, nch = cols >> 3;
     const float inv = 1.0f / (float)cols;
+    float gm[MC][8], bt[MC][8];
+#pragma unroll
+    for (int c = 0; c < MC; ++c)
+        if (lane + 64 * c < nch) {
+            load8(gamma + (lane + 64 * c) * 8, gm[c]);
+            load8(beta + (lane + 64 * c) * 8, bt[c]);
+        }
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
-        float v[MAXC][8];
+        float v[MC][8];
         float s = 0.f;
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
+        for (int c = 0; c < MC; ++c) {
             const int ch = lane + 64 * c;
             if (ch < nch) {
                 const long long off = (long long)row * cols + ch * 8;
@@ -76,21 +85,19 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
         const float mu = wave_sum(s) * inv;
         float q = 0.f;
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c)
+        for (int c = 0; c < MC; ++c)
             if (lane + 64 * c < nch) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { const float d = v[c][i] - mu; q += d * d; }
             }
         const float rs = rsqrtf(wave_sum(q) * inv + eps);
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
+        for (int c = 0; c < MC; ++c) {
             const int ch = lane + 64 * c;
             if (ch < nch) {
-                float gm[8], bt[8], o[8];
-                load8(gamma + ch * 8, gm);
-                load8(beta + ch * 8, bt);
+                float o[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) o[i] = (v[c][i] - mu) * rs * gm[i] + bt[i];
+                for (int i = 0; i < 8; ++i) o[i] = (v[c][i] - mu) * rs * gm[c][i] + bt[c][i];
                 store8(y + (long long)row * cols + ch * 8, o);
             }
         }
@@ -516,8 +523,10 @@ extern "C" int a8_layernorm_fwd(int dtype, const void* x, const void* res, const
     A8_REQUIRE(p >= 0.f && p < 1.f, "a8_layernorm_fwd: bad dropout p");
     if (rows == 0) return A8_OK;
     const Drop dr = make_drop(p, seed, rng_stream);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(ln_fwd_kernel<T>, dim3(grid_for(rows, 4)), dim3(256), 0, (hipStream_t)stream,
-                                         (const T*)x, (const T*)res, gamma, beta, (T*)y, mean, rstd, rows, cols, eps, dr));
+#define LN_FWD(MC) DISPATCH_T(dtype, hipLaunchKernelGGL((ln_fwd_kernel<T, MC>), dim3(grid_for(rows, 4)), dim3(256), 0, (hipStream_t)stream, \
+                                         (const T*)x, (const T*)res, gamma, beta, (T*)y, mean, rstd, rows, cols, eps, dr))
+    if (cols <= 512) LN_FWD(1); else if (cols <= 1024) LN_FWD(2); else LN_FWD(MAXC);
+#undef LN_FWD
     return a8_check_launch("a8_layernorm_fwd");
 }
 
