@@ -677,7 +677,7 @@ __global__ __launch_bounds__(512, 4) void gemm_sk_kernel(const GemmArgs g) {
 // (4 x 2, each 48 / 64 rows x 64 columns: 0.58 / 0.5 KB of fragment reads and 0.21 / 0.19 LDS-DMA instructions per MFMA instead of
 // 0.75 / 0.25), ONE block per CU, 3-deep ring (two k-tiles in flight: a lone block has no co-resident block to hide a DMA behind).
 template <typename T, int MIP>
-__global__ __launch_bounds__(512, 2) void gemm_tall_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tall_kernel(const GemmArgs g) {
     gemm_body<T, false, false, 2, 3, 4, MIP>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n * g.nsplit));
 }
 
