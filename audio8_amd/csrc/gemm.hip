@@ -71,18 +71,23 @@ template <int KB> struct StageTile<bf16, KB> {
         const int row = rb + (lane & 15);
         return *reinterpret_cast<const bf16x8*>(t + row * G::KROW + (((ks * 4 + (lane >> 4)) ^ G::swz(row)) << 4));
     }
+    // ROWS = operand rows of the tile (128, or 256: the image is then [BK k][512 B], a DMA piece 2 k-rows; the 3-bit key still
+    // spreads the eight k-rows a 32-lane group touches over all 64 banks)
+    template <int ROWS = 128>
     static A8_DEV bf16x8 ks_frag(const char* t, int rb, int ks, int lane) {
         const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3, nb = rb >> 4;
         const int k0 = ks * 32 + 8 * g + q, k1 = k0 + 4;
-        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, t + k0 * 256 + ((nb ^ ks_key(k0)) << 5) + 8 * p));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, t + k1 * 256 + ((nb ^ ks_key(k1)) << 5) + 8 * p));
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, t + k0 * (2 * ROWS) + ((nb ^ ks_key(k0)) << 5) + 8 * p));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, t + k1 * (2 * ROWS) + ((nb ^ ks_key(k1)) << 5) + 8 * p));
         typedef short s16x8 __attribute__((ext_vector_type(8)));
         s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(bf16x8, v);
     }
+    template <int ROWS = 128>
     static A8_DEV void ks_src(int p, int lane, int& k, int& col) {
-        k = 4 * p + (lane >> 4);
-        const int pc = lane & 15;
+        constexpr int LPR = ROWS / 8;                    // lanes (16-byte pieces) per k-row: 16 or 32
+        k = (64 / LPR) * p + lane / LPR;
+        const int pc = lane % LPR;
         col = (((pc >> 1) ^ ks_key(k)) << 4) + ((pc & 1) << 3);
     }
 };
@@ -93,9 +98,12 @@ template <int KB> struct StageTile<float, KB> {
         const int row = rb + (lane & 15);
         return *reinterpret_cast<const float*>(t + row * G::KROW + ((ks ^ G::swz(row)) << 4) + ((lane >> 4) << 2));
     }
+    template <int ROWS = 128>
     static A8_DEV float ks_frag(const char* t, int rb, int ks, int lane) {
+        static_assert(ROWS == 128, "f32 K-strided tiles are 128 rows");
         return *reinterpret_cast<const float*>(t + (ks * 4 + (lane >> 4)) * 512 + (rb + (lane & 15)) * 4);
     }
+    template <int ROWS = 128>
     static A8_DEV void ks_src(int p, int lane, int& k, int& col) {
         k = 2 * p + (lane >> 5);
         col = (lane & 31) << 2;
@@ -256,9 +264,9 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
     constexpr int NW = 2 * NWM;                   // waves per block: NWM along M x 2 along N
     constexpr int MI = MIP ? MIP : (NWM == 2 ? 4 : 2);   // 16-row fragments per wave along M: a wave owns (16 MI) x 64 of the tile
     constexpr int BM = 16 * MI * NWM;             // tile rows: 128; 160 with 10 waves (NWM = 5); 192 / 256 with 8 waves of 48 / 64 rows (MIP = 3 / 4)
-    static_assert(BM == 128 || !(AKS || BKS), "tiles taller than 128 rows are built for K-contiguous operands");
+    static_assert(BM == 128 || !(AKS || BKS) || (BM == 256 && sizeof(T) == 2), "K-strided tiles are 128 or (16-bit) 256 rows");
     constexpr int BN = 32 * NJ;                   // tile columns: 128; 96 with NJ = 3 (a wave owns 48)
-    static_assert(NJ == 4 || !(AKS || BKS), "narrow tiles are built for K-contiguous operands");
+    static_assert(NJ == 4 || !(AKS || BKS) || (NJ == 8 && sizeof(T) == 2), "K-strided tiles are 128 or (16-bit) 256 columns");
     constexpr int TA = BM * G::KROW, TB = BN * G::KROW, STAGE = TA + TB;
     constexpr int NPA = TA / 1024, NPB = TB / 1024;                        // 1 KB LDS-DMA pieces per operand per stage
     constexpr int PPA = (NPA + NW - 1) / NW, PPB = (NPB + NW - 1) / NW;    // ... per wave (the last may be missing when NW does not divide)
@@ -267,7 +275,7 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
     static_assert(!A3 || (!AKS && !BKS && NST == 2 && !UNEVEN), "the 3-deep A ring is built for NT, 2-deep B, even piece counts");
     constexpr int RING = A3 ? 3 * TA + 2 * TB : NST * STAGE + (UNEVEN ? 1024 : 0);   // (spare KB: so that vmcnt counts stay uniform)
     constexpr int NP = (KB == 1 && NST == 2) ? 2 : 1;                      // small-LDS variant: epilogue in two passes
-    constexpr int EPI = NW * 16 * MI * 64 * 4 / NP;                        // epilogue staging: a 64-column f32 slab per wave
+    constexpr int EPI = NJ == 8 ? NW * 16 * 128 * 4 : NW * 16 * MI * 64 * 4 / NP;   // epilogue staging: a 64-column f32 slab per wave (NJ = 8: 16 rows x 128 columns)
     __shared__ __attribute__((aligned(1024))) char lds[RING > EPI ? RING : EPI];
 
     const int t = threadIdx.x, lane = t & 63;
@@ -300,7 +308,7 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
             a_ptr[j] = g.A.p + (a_ok[j] ? outer_off(g.A, row) : 0) * SZ;
         } else {
             int kl, col;
-            ST::ks_src(p, lane, kl, col);
+            ST::template ks_src<BM>(p, lane, kl, col);
             a_k[j] = kl;
             a_ok[j] = m0 + col + EPC <= g.M;
             a_ptr[j] = g.A.p + (long long)(m0 + col) * SZ;
@@ -312,7 +320,7 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
             b_ptr[j] = g.B.p + (b_ok[j] ? outer_off(g.B, row) : 0) * SZ;
         } else {
             int kl, col;
-            ST::ks_src(p, lane, kl, col);
+            ST::template ks_src<BN>(p, lane, kl, col);
             b_k[j] = kl;
             b_ok[j] = n0 + col + EPC <= g.N;
             b_ptr[j] = g.B.p + (long long)(n0 + col) * SZ;
@@ -386,7 +394,7 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
     // issue they must not delay), so the loop's first counted wait retires them together with that k-tile (their latency would otherwise sit, exposed,
     // between the last MFMA and the stores of every tile).  16-bit rows only; the lane -> (row, 8 columns) map of gemm_epilogue.
     typedef typename Vec8<T>::type T8z;
-    constexpr bool ZPRE = sizeof(T) == 2 && NP == 1;
+    constexpr bool ZPRE = sizeof(T) == 2 && NP == 1 && NJ != 8;
     T8z zpre[2 * MI];
     bool use_zpre = false;
     float bpre[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // the lane's 8 bias columns, for the same reason
@@ -548,10 +556,10 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
         for (int ks = 0; ks < ST::KSTEPS; ++ks) {
 #pragma unroll
             for (int i = 0; i < MI; ++i)
-                fa[ks][i] = AKS ? ST::ks_frag(ta, wm * (16 * MI) + 16 * i, ks, lane) : ST::kc_frag(ta, wm * (16 * MI) + 16 * i, ks, lane);
+                fa[ks][i] = AKS ? ST::template ks_frag<BM>(ta, wm * (16 * MI) + 16 * i, ks, lane) : ST::kc_frag(ta, wm * (16 * MI) + 16 * i, ks, lane);
 #pragma unroll
             for (int i = 0; i < NJ; ++i)
-                fb[ks][i] = BKS ? ST::ks_frag(tb, wn * (16 * NJ) + 16 * i, ks, lane) : ST::kc_frag(tb, wn * (16 * NJ) + 16 * i, ks, lane);
+                fb[ks][i] = BKS ? ST::template ks_frag<BN>(tb, wn * (16 * NJ) + 16 * i, ks, lane) : ST::kc_frag(tb, wn * (16 * NJ) + 16 * i, ks, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (AKS || BKS) {
@@ -619,7 +627,40 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
             }
         }
     }
+    if constexpr (NJ == 8) {
+        // 256-column tiles (the weight-gradient kernel): f32 output only, stored or atomically added; a wave owns 16 MI rows x 128
+        // columns and sends them through a 16 x 128 f32 slab, one row fragment at a time, so that every atomic wave-instruction is
+        // 256 contiguous bytes of one row.
+        float* cw = reinterpret_cast<float*>(lds) + w * (16 * 128);
+        const int g4 = lane >> 4, li = lane & 15;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            if (i) __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                f32x4 v = acc[i][j];
+                v *= g.alpha;
+                *reinterpret_cast<f32x4*>(cw + li * 128 + (((4 * j + g4) ^ (li & 7)) << 2)) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int rr = 0; rr < 16; ++rr) {
+                const int m = m0 + wm * (16 * MI) + 16 * i + rr;
+                if (m >= g.M) break;
+                float* crow = reinterpret_cast<float*>(g.C) + remap_off(m, g.c_rpb, g.c_bs, g.ldc);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int cl = 64 * h + lane, n = n0 + wn * 128 + cl;
+                    const float v = cw[rr * 128 + (((cl >> 2) ^ (rr & 7)) << 2) + (cl & 3)];
+                    if (n < g.N) {
+                        if (g.atomic) atomicAdd(crow + n, v);
+                        else crow[n] = v;
+                    }
+                }
+            }
+        }
+    } else {
     gemm_epilogue<T, MI, NWM, NP, NJ>(g, acc, lds, w, m0, n0, lane, zpre, use_zpre, bpre, use_bpre);
+    }
     if constexpr (!SK) {
         __syncthreads();
         stamp(g, 4);
@@ -693,6 +734,17 @@ __global__ __launch_bounds__(512, 2) void gemm_lone_kernel(const GemmArgs g) {
     gemm_core<T, false, false, 2, 3, 4, MIP, 4, false, false, true>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n), 0, g.K, SEG_FULL, 0, 0);
 }
 
+// ---- 256 x 256 tiles for the weight gradients (TN, bf16 operands, f32 output): dW = dY^T X has a small output and a huge reduction,
+// so its time is the operand bytes staged into LDS -- (rows + columns) / (rows x columns) per FLOP: half of the 128 x 128 tile's.
+// 8 waves of 64 x 128, K-strided [k][512 B] stage images read through ds_read_b64_tr_b16, 2 x 64 KB ring, one block per CU;
+// split-K sized by the host to about one block per CU.
+template <typename T>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tn256_kernel(const GemmArgs g) {
+    const int bid = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n * g.nsplit);
+    const int split = bid / (g.tiles_m * g.tiles_n);
+    const int kbeg = split * g.kchunk;
+    gemm_core<T, true, true, 2, 2, 4, 4, 8>(g, bid - split * (g.tiles_m * g.tiles_n), kbeg, min(g.K, kbeg + g.kchunk), SEG_FULL, 0, 0);
+}
 // ---- 96-column tiles (8 waves of 32 x 48) for the products whose 128 x 128 tiling leaves the chip between one and two tiles per CU:
 // M = 6248, N = 768 gives 294 tiles on 256 CUs, and the launch lasts as long as the 38 CUs that hold two; 49 x 8 = 392 tiles of
 // 128 x 96 put two co-resident blocks on more than half of the CUs and each finishes a quarter sooner.  Same ring, same k order
@@ -1016,6 +1068,19 @@ __global__ __launch_bounds__(128 * NWM, (NST * 2 * 8192 * KB <= 65536) ? NWM : N
     gemm_body<T, AKS, BKS, KB, NST, NWM>(g, bid - grp.start[i]);
 }
 
+// the grouped launch with the 256 x 256 weight-gradient tiles of gemm_tn256_kernel
+template <typename T>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_grouped_tn256_kernel(const GemmGroup grp) {
+    const int bid = xcd_remap(blockIdx.x, grp.start[grp.n]);
+    int i = 0;
+    while (i + 1 < grp.n && bid >= grp.start[i + 1]) ++i;
+    const GemmArgs g = grp.g[i];
+    const int lb = bid - grp.start[i];
+    const int split = lb / (g.tiles_m * g.tiles_n);
+    const int kbeg = split * g.kchunk;
+    gemm_core<T, true, true, 2, 2, 4, 4, 8>(g, lb - split * (g.tiles_m * g.tiles_n), kbeg, min(g.K, kbeg + g.kchunk), SEG_FULL, 0, 0);
+}
+
 // the grouped launch with the asymmetric ring of gemm_a3_kernel (bf16 NT; the conv data-gradient halves)
 template <typename T>
 __global__ __launch_bounds__(512, 4) void gemm_grouped_a3_kernel(const GemmGroup grp) {
@@ -1113,12 +1178,32 @@ static int build_args(const a8_gemm_desc* d, GemmArgs& g, long long* grid) {
     return A8_OK;
 }
 
+// 256 x 256 weight-gradient tiles (a8_set_tuning key 18): eligibility, and the re-tiling of an argument block built for 128 x 128
+static bool tn256_eligible(const a8_gemm_desc* d, const GemmArgs& g) {
+    return d->dtype == A8_BF16 && d->layout == A8_GEMM_TN && g_variant == 5 && g_a8_tuning[18] > 0 && g.out_f32 && !d->bias && !d->act && !d->zout &&
+           !d->colsum && d->M >= 256 && d->N >= 256 && d->K >= 512;
+}
+static long long tn256_retile(const a8_gemm_desc* d, GemmArgs& g, int want_split) {
+    g.tiles_m = cdiv(d->M, 256); g.tiles_n = cdiv(d->N, 256);
+    int nsplit = g.atomic ? (want_split > 0 ? want_split : 1) : 1;
+    int kchunk = cdiv(cdiv(d->K, nsplit), 64) * 64;
+    nsplit = cdiv(d->K, kchunk);
+    g.kchunk = kchunk; g.nsplit = nsplit;
+    return (long long)g.tiles_m * g.tiles_n * nsplit;
+}
+
 extern "C" int a8_gemm(const a8_gemm_desc* d, void* stream) {
     GemmArgs g;
     long long grid = 0;
     if (int e = build_args(d, g, &grid)) return e;
     if (d->M == 0) return A8_OK;
     hipStream_t s = (hipStream_t)stream;
+    if (tn256_eligible(d, g)) {
+        const int t256 = cdiv(d->M, 256) * cdiv(d->N, 256);
+        const long long g256 = tn256_retile(d, g, 256 / t256 > 0 ? 256 / t256 : 1);      // about one block per CU
+        hipLaunchKernelGGL(gemm_tn256_kernel<bf16>, dim3((int)g256), dim3(512), 0, s, g);
+        return a8_check_launch("a8_gemm");
+    }
     // large NT problems whose N is a multiple of 256 (the conv layers): the pipelined 256 x 256 kernel
     // (a8_set_tuning key 5 = minimum number of 256 x 256 tiles; 0 = off)
     if (d->dtype == A8_BF16 && d->layout == A8_GEMM_NT && g_a8_tuning[5] > 0 && g_variant == 5 && d->N % 256 == 0 && d->K % 64 == 0 &&
@@ -1230,6 +1315,25 @@ extern "C" int a8_gemm_grouped(const a8_gemm_desc* descs, int n, void* stream) {
     }
     if (grp.n == 0) return A8_OK;
     hipStream_t s = (hipStream_t)stream;
+    {
+        bool all256 = true;
+        int t256 = 0;
+        for (int i = 0, k = 0; i < n; ++i) {
+            if (descs[i].M == 0) continue;
+            all256 = all256 && tn256_eligible(&descs[i], grp.g[k++]);
+            t256 += cdiv(descs[i].M, 256) * cdiv(descs[i].N, 256);
+        }
+        if (all256) {
+            long long tot = 0;
+            for (int i = 0, k = 0; i < n; ++i) {
+                if (descs[i].M == 0) continue;
+                tot += tn256_retile(&descs[i], grp.g[k], 256 / t256 > 0 ? 256 / t256 : 1);
+                grp.start[++k] = (int)tot;
+            }
+            hipLaunchKernelGGL(gemm_grouped_tn256_kernel<bf16>, dim3((int)tot), dim3(512), 0, s, grp);
+            return a8_check_launch("a8_gemm_grouped");
+        }
+    }
     if (descs[0].dtype == A8_BF16) {
         switch (g_variant) {
             case 1: return launch2g<bf16, 1, 4, 2>(descs[0].layout, grp, (int)total, s);

@@ -69,7 +69,7 @@ int a8_gemm_grouped(const a8_gemm_desc* descs, int n, void* stream);
  * put between one and two tiles on a CU, 3 / 4 = always 192 / 256 rows, 5 / 6 = the register-pipelined 192-row kernel by that rule / always; 13 NT GEMM tiles of 128 x 96 (bf16, 96 | N): 0 = off, 1 = when 128-column
  * tiles would leave 257..512 blocks, 2 = always; 14 asymmetric LDS ring for bf16 NT GEMMs (A requested two k-tiles ahead, B one): 0 = off,
  * otherwise the minimum M (default 10000: the conv layers); 16 stream-K for bf16 NT products given a workspace: 0 = off, 1 = when the tile count
- * is below three rounds of the 512 slots and not a multiple of them, 2 = whenever eligible; 15 = 1: the GEMM epilogues load their second input (zin) after the main loop instead of ahead of it */
+ * is below three rounds of the 512 slots and not a multiple of them, 2 = whenever eligible; 18 = 1: 256 x 256 tiles (one block per CU, library-chosen split-K) for bf16 TN products with f32 output, the weight gradients; 15 = 1: the GEMM epilogues load their second input (zin) after the main loop instead of ahead of it */
 int a8_set_tuning(int key, int value);
 /* developer aid: when p is not NULL every a8_gemm block of the default kernels writes 5 timestamps (100 MHz counter: entry, first DMAs issued,
  * first k-tile landed, main loop done, epilogue done) to ((uint64_t*)p)[8 * blockIdx + i]; NULL switches it off.  tools/tile_stamps.py */

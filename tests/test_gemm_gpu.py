@@ -379,3 +379,64 @@ def test_gemm_stream_k_matches_default():
         torch.testing.assert_close(ref[1], g_[1], rtol=1e-3, atol=0.5)
     for ws, _ in Kn._SK_WS.values():                      # the give-up word of a bounded spin (last flag slot) was never written
         assert int(ws[65536 - 64:65536 - 60].view(torch.int32).item()) == 0
+
+
+def test_gemm_tn_256_tiles_match_default():
+    """The 256 x 256 weight-gradient tiles (a8_set_tuning key 18; TN, bf16 operands, f32 output, split-K chosen by the library): exact on
+    integer operands (every partial sum exact), M / N / K tails, accumulate and plain store, the conv layers' row remap on the
+    reduction index (overlapping windows of a channels-last activation, padded dz rows), single and grouped launches."""
+    from audio8_amd import kernels as Kn, _lib as L
+    dev, bf = "cuda", torch.bfloat16
+
+    def both(fn):
+        try:
+            L.check(L.lib().a8_set_tuning(18, 0), "tune")
+            ref = fn()
+            L.check(L.lib().a8_set_tuning(18, 1), "tune")
+            got = fn()
+        finally:
+            L.check(L.lib().a8_set_tuning(18, 0), "tune")
+        return ref, got
+
+    for (M, N, Kr, acc) in [(768, 3072, 6248, True), (512, 512, 1000, True), (264, 392, 2056, True), (768, 768, 6248, False), (2304, 768, 520, True)]:
+        A, B = _mk((Kr, M), bf, 1, integer=True).to(dev), _mk((Kr, N), bf, 2, integer=True).to(dev)
+
+        def run():
+            out = torch.ones(M, N, device=dev) if acc else torch.empty(M, N, device=dev)
+            Kn.gemm(L.TN, A, B, M, N, Kr, out=out, accumulate=acc, splitk=3 if acc else 1)
+            return out
+        ref, got = both(run)
+        want = A.cpu().double().T @ B.cpu().double() + (1.0 if acc else 0.0)
+        assert torch.equal(ref.cpu().double(), want), (M, N, Kr)
+        assert torch.equal(got.cpu().double(), want), (M, N, Kr)
+    # conv weight gradient: dW2[co, kk*cin + ci] = sum over (b, t) dz[b, t, co] * x[b, 2t + kk, ci]  (k = 3, stride 2), dz rows padded by one
+    Bn, Lin, cin, co, k, st = 3, 401, 512, 512, 3, 2
+    Lout = (Lin - k) // st + 1
+    x = _mk((Bn, Lin, cin), bf, 3, integer=True).to(dev)
+    dzp = torch.zeros(Bn, Lout + 2, co, dtype=bf)
+    dzp[:, 1:-1] = _mk((Bn, Lout, co), bf, 4, integer=True)
+    dzp = dzp.to(dev)
+
+    def conv_wgrad():
+        out = torch.zeros(co, k * cin, device=dev)
+        Kn.gemm(L.TN, dzp, x, co, k * cin, Bn * Lout, out=out, accumulate=True, splitk=2, lda=co, a_off=co, a_rpb=Lout, a_bs=(Lout + 2) * co,
+                ldb=st * cin, b_rpb=Lout, b_bs=Lin * cin)
+        return out
+    ref, got = both(conv_wgrad)
+    xw = x.cpu().double().unfold(1, k, st)                               # [B, Lout, cin, k]
+    want = torch.einsum("btc,btik->cki", dzp[:, 1:-1].cpu().double(), xw).reshape(co, k * cin)
+    assert torch.equal(ref.cpu().double(), want)
+    assert torch.equal(got.cpu().double(), want)
+    # grouped: the four weight gradients of an encoder layer
+    Mr = 1000
+    shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768)]
+    ops_ = [(_mk((Mr, m), bf, 10 + i, integer=True).to(dev), _mk((Mr, n), bf, 20 + i, integer=True).to(dev)) for i, (m, n) in enumerate(shapes)]
+
+    def grouped():
+        outs = [torch.ones(m, n, device=dev) for m, n in shapes]
+        Kn.gemm_grouped(L.TN, [(a, b, m, n, Mr, dict(out=o, accumulate=True)) for (a, b), (m, n), o in zip(ops_, shapes, outs)])
+        return outs
+    ref, got = both(grouped)
+    for (a, b), r, g_ in zip(ops_, ref, got):
+        want = a.cpu().double().T @ b.cpu().double() + 1.0
+        assert torch.equal(r.cpu().double(), want) and torch.equal(g_.cpu().double(), want)
