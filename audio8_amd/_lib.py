@@ -24,6 +24,7 @@ ARGTYPES = {
     "a8_version": [],
     "a8_gemm": [C.c_void_p, C.c_void_p],
     "a8_gemm_grouped": [C.c_void_p, C.c_int, C.c_void_p],
+    "a8_encoder_layer_fwd": [C.c_void_p, C.c_void_p],
     "a8_set_tuning": [C.c_int, C.c_int],
     "a8_debug_set_stamps": [C.c_void_p],
     "a8_prepare_weights": [C.c_int, C.c_void_p, C.c_int, C.c_void_p],
@@ -82,6 +83,13 @@ class GemmDesc(C.Structure):
         ("colsum", C.c_void_p),
         ("sk_ws", C.c_void_p), ("sk_ws_bytes", C.c_int64), ("sk_epoch", C.c_uint32),
     ]
+
+
+class EncoderLayerDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("dtype", "B", "T", "H", "d", "dff")] + [("p", C.c_float), ("eps", C.c_float)] + \
+               [(n, C.c_uint32) for n in ("seed_attn", "seed1", "seed2")] + \
+               [(n, C.c_void_p) for n in ("x", "keymask", "wqkv", "wo", "w1", "w2", "bqkv", "bo", "b1", "b2", "g1", "be1", "g2", "be2",
+                                          "qkv", "o", "ao", "x1", "z1", "h", "f", "x2", "lse", "mean2", "rstd2", "mean1", "rstd1")]
 
 
 GEMM_SK_WS_BYTES = 65536 + 512 * 65536          # A8_GEMM_SK_WS_BYTES of include/a8hip.h
@@ -143,7 +151,7 @@ def require_cuda(*ts):
 
 
 EXPORTS = [
-    "a8_version", "a8_last_error", "a8_gemm", "a8_gemm_grouped", "a8_set_tuning", "a8_debug_set_stamps", "a8_prepare_weights", "a8_prepare_weights_device",
+    "a8_version", "a8_last_error", "a8_gemm", "a8_gemm_grouped", "a8_set_tuning", "a8_debug_set_stamps", "a8_encoder_layer_fwd", "a8_prepare_weights", "a8_prepare_weights_device",
     "a8_conv0_gn_gelu_fwd", "a8_conv0_gn_gelu_bwd", "a8_col2im_gelu_grad",
     "a8_layernorm_fwd", "a8_layernorm_bwd",
     "a8_cast", "a8_dropout", "a8_mask_fill_rows", "a8_mask_fill_rows_bwd", "a8_mask_zero_cols", "a8_zero_rows",

@@ -93,6 +93,30 @@ def gemm(layout, A, B, M, N, K, **kw):
     return out
 
 
+def encoder_layer_fwd(x, keymask, B, T, H, p, eps, seeds, wqkv, bqkv, wo, bo, w1, b1, w2, b2, g1, be1, g2, be2):
+    """a8_encoder_layer_fwd: the whole post-LN encoder layer forward in one C call.  Returns the tensors backward needs:
+    (x2, qkv, o, lse, ao, x1, mean2, rstd2, z1, h, f, mean1, rstd1)."""
+    M, d = x.shape
+    dff = w1.shape[0]
+    dev, dt = x.device, x.dtype
+    L.require_cuda(x, keymask, wqkv, wo, w1, w2, bqkv, bo, b1, b2, g1, be1, g2, be2)
+    qkv = torch.empty((M, 3 * d), device=dev, dtype=dt)
+    o, ao, x1, f, x2 = torch.empty((5, M, d), device=dev, dtype=dt).unbind(0)          # five contiguous [M, d] slabs, one allocation
+    z1, h = torch.empty((2, M, dff), device=dev, dtype=dt).unbind(0)
+    lse = torch.empty((B, H, T), device=dev, dtype=torch.float32)
+    stats = torch.empty((4, M), device=dev, dtype=torch.float32)
+    mean2, rstd2, mean1, rstd1 = stats.unbind(0)
+    sp, fsz = stats.data_ptr(), 4 * M
+    e = L.EncoderLayerDesc(L.dt(x), B, T, H, d, dff, p, eps, _u32(seeds[0]), _u32(seeds[1]), _u32(seeds[2]),
+                           x.data_ptr(), keymask.data_ptr() if keymask is not None else None,
+                           wqkv.data_ptr(), wo.data_ptr(), w1.data_ptr(), w2.data_ptr(),
+                           bqkv.data_ptr(), bo.data_ptr(), b1.data_ptr(), b2.data_ptr(), g1.data_ptr(), be1.data_ptr(), g2.data_ptr(), be2.data_ptr(),
+                           qkv.data_ptr(), o.data_ptr(), ao.data_ptr(), x1.data_ptr(), z1.data_ptr(), h.data_ptr(), f.data_ptr(), x2.data_ptr(),
+                           lse.data_ptr(), sp, sp + fsz, sp + 2 * fsz, sp + 3 * fsz)
+    L.check(L.lib().a8_encoder_layer_fwd(C.byref(e), L.stream()), "a8_encoder_layer_fwd")
+    return x2, qkv, o, lse, ao, x1, mean2, rstd2, z1, h, f, mean1, rstd1
+
+
 def gemm_grouped(layout, problems):
     """Several independent GEMMs of one layout and dtype in one launch.  problems: list of (A, B, M, N, K, kwargs)."""
     arr = (L.GemmDesc * len(problems))()

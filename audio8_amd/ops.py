@@ -725,6 +725,7 @@ class PosConvFn(torch.autograd.Function):
 # (a8_attn_bwd's dbias: block-level column sums, one atomic per column per block).  Same-box A/B: 13.67-13.75 ms fused vs
 # 13.64-13.69: the extra barriers and 2.4e5 atomics cost a little more than the 12 small passes they replace.
 ATTN_BIAS_FUSED = False
+COMPOSITE_ENCODER_FWD = True          # one C call per encoder layer forward (host time; the kernels are the same)
 
 
 class EncoderLayerFn(torch.autograd.Function):
@@ -759,6 +760,18 @@ class EncoderLayerFn(torch.autograd.Function):
         wo_c, wo_t = eo if eo is not None else (_wcast(wo, dt), None)
         w1_c, w1_t = e1 if e1 is not None else (_wcast(w1, dt), None)
         w2_c, w2_t = e2 if e2 is not None else (_wcast(w2, dt), None)
+        if COMPOSITE_ENCODER_FWD and K.GEMM_PROFILE is None and x.is_contiguous():
+            # the whole launch sequence below behind one C call (a8_encoder_layer_fwd); the per-launch path stays for the instrumented
+            # roofline steps of bench.py (per-GEMM events) and as the readable statement of the sequence
+            seed_a, seed1, seed2 = (next_seed(), next_seed(), next_seed()) if p > 0 else (0, 0, 0)
+            x2, qkv, o, lse, ao, x1, mean2, rstd2, z1, h, f, mean1, rstd1 = K.encoder_layer_fwd(
+                x, keymask, B, T, H, p, eps, (seed_a, seed1, seed2), wqkv_c, bqkv, wo_c, bo, w1_c, b1, w2_c, b2, g1, be1, g2, be2)
+            ctx.save_for_backward(x, keymask, qkv, o, lse, ao, x1, mean2, rstd2, z1, h, f, mean1, rstd1,
+                                  wqkv_c, wo_c, w1_c, w2_c, g1, g2)
+            ctx.cfg = (B, T, H, p, seed_a, seed1, seed2)
+            ctx.wts = (wqkv_t, wo_t, w1_t, w2_t)
+            ctx.params = (wq, bq, wk, bk, wv, bv, wo, bo, w1, b1, w2, b2, g1, be1, g2, be2)
+            return x2
         qkv = K.gemm(L.NT, x, wqkv_c, M, 3 * d, d, bias=bqkv)
         seed_a = next_seed() if p > 0 else 0
         o, lse = K.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, T, H, 3 * d, 1.0 / math.sqrt(d // H), keymask, p, seed_a)

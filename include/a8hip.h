@@ -176,6 +176,23 @@ int a8_attn_bwd(int dtype, const void* q, const void* k, const void* v, const vo
                 const uint8_t* keymask, void* dq, void* dk, void* dv, float* delta, float* dbias, int B, int T, int H, int64_t ld_qkv,
                 int64_t ld_o, int64_t ld_dqkv, float scale, float p, uint32_t seed, void* stream);
 
+/* ---- one encoder layer forward as ONE call (the launch sequence of eight_mile's post-LN TransformerEncoder, SURVEY 8a row a5:
+ * QKV GEMM, attention, output projection, LN2(x + drop), FFN1 + GELU, FFN2, LN1(x1 + drop)); replaces nothing new -- it issues the
+ * entry points above in order -- but costs the host one C transition instead of seven.  All buffers are the caller's:
+ * x, qkv [M,3d], o, ao, x1, f, x2 [M,d], z1, h [M,dff] in dtype; lse f32 [B,H,T]; mean / rstd f32 [M]; weights in dtype, row-major
+ * [out,in] (wqkv = [3d,d]); biases and LayerNorm parameters f32.  Seeds as a8_attn_fwd / a8_layernorm_fwd take them (p = 0: unused). */
+typedef struct a8_encoder_layer_desc {
+    int dtype, B, T, H, d, dff;
+    float p, eps;
+    uint32_t seed_attn, seed1, seed2;
+    const void* x; const uint8_t* keymask;
+    const void *wqkv, *wo, *w1, *w2;
+    const float *bqkv, *bo, *b1, *b2, *g1, *be1, *g2, *be2;
+    void *qkv, *o, *ao, *x1, *z1, *h, *f, *x2;
+    float *lse, *mean2, *rstd2, *mean1, *rstd1;
+} a8_encoder_layer_desc;
+int a8_encoder_layer_fwd(const a8_encoder_layer_desc* e, void* stream);
+
 /* ---- Gumbel-softmax product quantiser (GumbelVectorQuantizer.forward audio8/wav2vec2.py:547-576) ----
  * logits f32 [R, V] (R = B*Tm*G rows), gumbel f32 [R,V] or NULL (eval: plain argmax);
  * codes i32 [R]; avg_probs f32 [V] = mean over rows of softmax(logits) (written, not accumulated);

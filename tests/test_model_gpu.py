@@ -161,6 +161,36 @@ def test_training_step_with_dropout_runs_and_is_deterministic(restore_dtype):
     np.testing.assert_allclose(vals[0][0], vals[1][0], rtol=1e-4)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_composite_encoder_forward_call_is_bit_identical(restore_dtype, dtype):
+    """a8_encoder_layer_fwd (one C call per encoder layer forward) issues exactly the launches of the per-call path, with the same dropout
+    seeds in the same order: loss and every gradient of a training step with dropout are bit-identical with the switch on and off."""
+    from audio8_amd import ops, wav2vec2 as W
+    ops.set_compute_dtype(dtype)
+    x = synth(2, 16000).cuda()
+    outs = []
+    try:
+        for flag in (False, True):
+            ops.COMPOSITE_ENCODER_FWD = flag
+            torch.manual_seed(5)
+            np.random.seed(5)
+            ops.reset_seed_stream()
+            m = W.create_model(num_layers=2, dropout=0.1).cuda().train()
+            loss_fn = W.create_loss(640, 100)
+            loss = loss_fn(m, x)
+            loss.backward()
+            outs.append((float(loss.detach()), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}))
+    finally:
+        ops.COMPOSITE_ENCODER_FWD = True
+    assert outs[0][0] == outs[1][0]
+    assert outs[0][1].keys() == outs[1][1].keys()
+    for n, g in outs[0][1].items():
+        if "ln" in n or "layer_norm" in n or n.endswith("bias") or "mask_emb" in n:
+            torch.testing.assert_close(g, outs[1][1][n], rtol=1e-5, atol=1e-7)     # accumulated with float atomics: order-dependent last bits
+        else:
+            torch.testing.assert_close(g, outs[1][1][n], rtol=1e-5, atol=1e-7)
+
+
 def test_prefetched_host_draws_are_bit_identical(restore_dtype):
     """Two training steps with the next step's numpy draws taken ahead of time (prefetch_host_draws, right after
     backward) sample exactly the masks / negatives of two steps that draw inline -- same global-RNG call order --
