@@ -25,6 +25,7 @@ ARGTYPES = {
     "a8_gemm": [C.c_void_p, C.c_void_p],
     "a8_gemm_grouped": [C.c_void_p, C.c_int, C.c_void_p],
     "a8_encoder_layer_fwd": [C.c_void_p, C.c_void_p],
+    "a8_encoder_layer_bwd": [C.c_void_p, C.c_void_p],
     "a8_set_tuning": [C.c_int, C.c_int],
     "a8_debug_set_stamps": [C.c_void_p],
     "a8_prepare_weights": [C.c_int, C.c_void_p, C.c_int, C.c_void_p],
@@ -92,6 +93,14 @@ class EncoderLayerDesc(C.Structure):
                                           "qkv", "o", "ao", "x1", "z1", "h", "f", "x2", "lse", "mean2", "rstd2", "mean1", "rstd1")]
 
 
+class EncoderLayerBwdDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("dtype", "B", "T", "H", "d", "dff")] + [("p", C.c_float)] + \
+               [(n, C.c_uint32) for n in ("seed_attn", "seed1", "seed2")] + \
+               [(n, C.c_void_p) for n in ("dx2", "x", "qkv", "o", "ao", "x1", "z1", "f", "keymask", "lse", "mean2", "rstd2", "mean1", "rstd1", "g1", "g2",
+                                          "w2_t", "w1_t", "wo_t", "dg1", "dbe1", "dg2", "dbe2", "db2", "db1", "dbo",
+                                          "df", "dx1_res", "dz1", "dx1_ffn", "dao", "dx_res", "dout_o", "dqkv", "delta")]
+
+
 GEMM_SK_WS_BYTES = 65536 + 512 * 65536          # A8_GEMM_SK_WS_BYTES of include/a8hip.h
 
 
@@ -151,7 +160,7 @@ def require_cuda(*ts):
 
 
 EXPORTS = [
-    "a8_version", "a8_last_error", "a8_gemm", "a8_gemm_grouped", "a8_set_tuning", "a8_debug_set_stamps", "a8_encoder_layer_fwd", "a8_prepare_weights", "a8_prepare_weights_device",
+    "a8_version", "a8_last_error", "a8_gemm", "a8_gemm_grouped", "a8_set_tuning", "a8_debug_set_stamps", "a8_encoder_layer_fwd", "a8_encoder_layer_bwd", "a8_prepare_weights", "a8_prepare_weights_device",
     "a8_conv0_gn_gelu_fwd", "a8_conv0_gn_gelu_bwd", "a8_col2im_gelu_grad",
     "a8_layernorm_fwd", "a8_layernorm_bwd",
     "a8_cast", "a8_dropout", "a8_mask_fill_rows", "a8_mask_fill_rows_bwd", "a8_mask_zero_cols", "a8_zero_rows",

@@ -726,6 +726,7 @@ class PosConvFn(torch.autograd.Function):
 # 13.64-13.69: the extra barriers and 2.4e5 atomics cost a little more than the 12 small passes they replace.
 ATTN_BIAS_FUSED = False
 COMPOSITE_ENCODER_FWD = True          # one C call per encoder layer forward (host time; the kernels are the same)
+COMPOSITE_ENCODER_BWD = True          # ... and per data-gradient chain of its backward
 
 
 class EncoderLayerFn(torch.autograd.Function):
@@ -811,6 +812,34 @@ class EncoderLayerFn(torch.autograd.Function):
         dg2, dbe2, dir2 = ln_targets(pg2, pbe2)
         # ln1: x2 = LN(x1 + drop(f))
         tb2, tbo = _target(b2), _target(bo)      # bias gradients of w_2 / w_O ride on the LayerNorm backward passes
+        wqkv_t, wo_t, w1_t, w2_t = ctx.wts
+        tb1 = _target(b1)
+        tw, tb = [_target(w) for w in (wq, wk, wv)], [_target(b) for b in (bq, bk, bv)]
+        direct_qkv = all(t is not None for t in tw + tb) and _adjacent(*tw) and _adjacent(*tb)
+        if (COMPOSITE_ENCODER_BWD and K.GEMM_PROFILE is None and GROUP_WGRAD and dir1 and dir2 and direct_qkv and not ATTN_BIAS_FUSED
+                and all(t is not None for t in (tb2, tbo, tb1, wqkv_t, wo_t, w1_t, w2_t, _target(w1), _target(w2), _target(wo)))):
+            # the data-gradient chain up to the attention core behind one C call (a8_encoder_layer_bwd); the statement of the sequence,
+            # and every other case (no direct gradient targets, no prepared transposes, instrumented steps), is the code below
+            df, dz1, dao, dqkv, dx_res = K.encoder_layer_bwd(dx2, x, keymask, qkv, o, lse, ao, x1, mean2, rstd2, z1, f, mean1, rstd1, g1, g2,
+                                                             w2_t, w1_t, wo_t, dg1, dbe1, dg2, dbe2, tb2, tb1, tbo, B, T, H, p, (seed_a, seed1, seed2))
+            _ready(pg1, pbe1, b2, b1, pg2, pbe2, bo)
+            wg = WgradGroup()
+            wg.add((w2,), _target(w2), df, h, d, dff, M)
+            wg.add((w1,), _target(w1), dz1, x1, dff, d, M)
+            wg.add((wo,), _target(wo), dao, o, d, d, M)
+            bspan = _span3(tb[0], (3 * d,))
+            if SIDE_EXTRAS:
+                def bias_colsum(dqkv=dqkv, bspan=bspan, ps=(bq, bk, bv)):
+                    colsum(dqkv, bspan)
+                    _ready(*ps)
+                wg.extra.append(bias_colsum)
+            else:
+                colsum(dqkv, bspan)
+                _ready(bq, bk, bv)
+            wg.add((wq, wk, wv), _span3(tw[0], (3 * d, d)), dqkv, x, 3 * d, d, M)
+            wg.flush()
+            dx = _dgrad(dqkv, wqkv_c, wqkv_t, M, d, 3 * d, act=L.ACT_ADD, zin=dx_res, ldz=d)
+            return (dx,) + (None,) * 22
         df, dx1_res = K.layernorm_bwd(dx2, None, f, x1, g1.detach(), mean1, rstd1, dg1, dbe1, p, seed2, 4, want_dx=True, want_dres=p > 0, dbias=tb2)
         if p == 0:
             dx1_res = df

@@ -193,6 +193,25 @@ typedef struct a8_encoder_layer_desc {
 } a8_encoder_layer_desc;
 int a8_encoder_layer_fwd(const a8_encoder_layer_desc* e, void* stream);
 
+/* The data-gradient chain of that layer's backward up to and including the attention core, as one call (LN1 backward carrying the b2
+ * gradient, the FFN2 data gradient x gelu'(z1) carrying the b1 gradient, the FFN1 data gradient, LN2 backward carrying the bo gradient,
+ * the output projection's data gradient, attention backward).  dx2 = gradient of the layer output; x .. rstd1 as saved by the forward
+ * call; w2_t [dff,d], w1_t [d,dff], wo_t [d,d] = the TRANSPOSED working copies (a8_prepare_weights); dg1 .. dbo f32, accumulated (+=).
+ * Written: df, dz1, dx1_ffn, dao, dout_o, dqkv [M,3d], delta f32 [B,H,T], and with p > 0 dx1_res, dx_res (p = 0: pass df / dao again).
+ * The weight gradients and the QKV data gradient (dx = dqkv Wqkv + dx_res) are the caller's. */
+typedef struct a8_encoder_layer_bwd_desc {
+    int dtype, B, T, H, d, dff;
+    float p;
+    uint32_t seed_attn, seed1, seed2;
+    const void *dx2, *x, *qkv, *o, *ao, *x1, *z1, *f; const uint8_t* keymask;
+    const float *lse, *mean2, *rstd2, *mean1, *rstd1, *g1, *g2;
+    const void *w2_t, *w1_t, *wo_t;
+    float *dg1, *dbe1, *dg2, *dbe2, *db2, *db1, *dbo;
+    void *df, *dx1_res, *dz1, *dx1_ffn, *dao, *dx_res, *dout_o, *dqkv;
+    float* delta;
+} a8_encoder_layer_bwd_desc;
+int a8_encoder_layer_bwd(const a8_encoder_layer_bwd_desc* e, void* stream);
+
 /* ---- Gumbel-softmax product quantiser (GumbelVectorQuantizer.forward audio8/wav2vec2.py:547-576) ----
  * logits f32 [R, V] (R = B*Tm*G rows), gumbel f32 [R,V] or NULL (eval: plain argmax);
  * codes i32 [R]; avg_probs f32 [V] = mean over rows of softmax(logits) (written, not accumulated);

@@ -162,26 +162,36 @@ def test_training_step_with_dropout_runs_and_is_deterministic(restore_dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_composite_encoder_forward_call_is_bit_identical(restore_dtype, dtype):
-    """a8_encoder_layer_fwd (one C call per encoder layer forward) issues exactly the launches of the per-call path, with the same dropout
-    seeds in the same order: loss and every gradient of a training step with dropout are bit-identical with the switch on and off."""
+def test_composite_encoder_calls_match_the_per_launch_path(restore_dtype, dtype):
+    """a8_encoder_layer_fwd / a8_encoder_layer_bwd (one C call per encoder layer forward / per data-gradient chain of its backward) issue
+    exactly the launches of the per-call path, with the same dropout seeds in the same order: the loss of a training step with dropout is
+    bit-identical and every gradient agrees to the order of the float atomics, with the switches on and off; the backward call needs the
+    Stepper's direct gradient targets and prepared transposes (bf16) and silently stays on the per-launch path otherwise (f32)."""
     from audio8_amd import ops, wav2vec2 as W
     ops.set_compute_dtype(dtype)
     x = synth(2, 16000).cuda()
     outs = []
     try:
+        from audio8_amd.trainer import Stepper
         for flag in (False, True):
-            ops.COMPOSITE_ENCODER_FWD = flag
+            ops.COMPOSITE_ENCODER_FWD = ops.COMPOSITE_ENCODER_BWD = flag
             torch.manual_seed(5)
             np.random.seed(5)
             ops.reset_seed_stream()
             m = W.create_model(num_layers=2, dropout=0.1).cuda().train()
             loss_fn = W.create_loss(640, 100)
-            loss = loss_fn(m, x)
-            loss.backward()
-            outs.append((float(loss.detach()), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}))
+            st = Stepper(m)
+            try:
+                st.zero_grad()
+                loss = loss_fn(m, x)
+                loss.backward()
+                st.reducer.finish()
+                torch.cuda.synchronize()
+                outs.append((float(loss.detach()), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}))
+            finally:
+                st.close()
     finally:
-        ops.COMPOSITE_ENCODER_FWD = True
+        ops.COMPOSITE_ENCODER_FWD = ops.COMPOSITE_ENCODER_BWD = True
     assert outs[0][0] == outs[1][0]
     assert outs[0][1].keys() == outs[1][1].keys()
     for n, g in outs[0][1].items():
