@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Timeline analysis of a rocprofv3 kernel trace: for the last step, per-stream busy time, idle gaps on the busiest
-stream and the kernels that follow the largest gaps."""
+"""Timeline analysis of a rocprofv3 kernel trace: per-stream busy time, idle gaps on the busiest stream and the kernels that follow the
+largest gaps -- for the last TIMED step (as the bench runs it: composite calls, side stream) and for the last step of the process
+(bench.py's instrumented roofline step: every GEMM launched on its own between two HIP events, side stream off)."""
 import csv
 import glob
 import sys
@@ -12,10 +13,14 @@ def main():
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     # split steps by adamw launches
     ends = [i for i, r in enumerate(rows) if "adamw" in r["Kernel_Name"]]
-    lo, hi = ends[-2] + 1, ends[-1] + 1
-    step = rows[lo:hi]
+    if len(ends) >= 4:
+        analyse(rows[ends[-4] + 1:ends[-3] + 1], "last timed step")
+    analyse(rows[ends[-2] + 1:ends[-1] + 1], "last step (instrumented)")
+
+
+def analyse(step, label):
     t0, t1 = int(step[0]["Start_Timestamp"]), max(int(r["End_Timestamp"]) for r in step)
-    print(f"last step: {len(step)} kernels, span {(t1 - t0) / 1e6:.3f} ms")
+    print(f"{label}: {len(step)} kernels, span {(t1 - t0) / 1e6:.3f} ms")
     streams = {}
     for r in step:
         streams.setdefault((r["Queue_Id"], r.get("Stream_Id", "")), []).append(r)
@@ -45,7 +50,7 @@ def main():
             ce = max(ce, e)
     u += ce - cs
     print(f"  GPU busy (union of all queues): {u / 1e6:.3f} ms of {(t1 - t0) / 1e6:.3f} ms")
-    if len(sys.argv) > 3:      # every dispatch of one kernel in the last step: duration, grid, what ran before it
+    if len(sys.argv) > 3:      # every dispatch of one kernel in the step: duration, grid, what ran before it
         key = sys.argv[3]
         for i, r in enumerate(step):
             if key in r["Kernel_Name"]:
