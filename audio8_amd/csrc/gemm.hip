@@ -60,7 +60,7 @@ A8_DEV void glds16(const char* src, char* lds_dst_wave_uniform) {
 //   KS f32 : [BK k][512 B]; piece = 2 k-rows; lane -> k 2p + l/32, 16-B piece l%32 (no swizzle)
 template <int KB> struct KcGeom {
     static constexpr int KROW = 64 * KB, SPR = KROW / 16, RPP = 1024 / KROW, OPBYTES = 128 * KROW, NPIECE = OPBYTES / 1024;
-    static A8_DEV int swz(int row) { return KB == 1 ? ((row >> 1) & 3) : (row & 7); }
+    static A8_DEV int swz(int row) { return KB == 1 ? ((row >> 1) & 3) : KB == 4 ? (row & 15) : (row & 7); }     // (one 16-byte slot per row of a 16-row fragment)
 };
 template <typename T, int KB> struct StageTile;
 template <int KB> struct StageTile<bf16, KB> {
@@ -246,7 +246,11 @@ A8_DEV void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MI][NJ], char* lds, co
 // Main loop: NST-deep ring of LDS stages filled by LDS-DMA (global_load_lds, 16 B per lane), NST-1 k-tiles in
 // flight per block; one raw s_barrier and one counted s_waitcnt vmcnt per k-tile; no register staging.
 A8_DEV void stamp(const GemmArgs& g, int i) {
-    if (g.stamps && threadIdx.x == 0) g.stamps[(long long)blockIdx.x * 8 + i] = __builtin_amdgcn_s_memrealtime();
+    if (g.stamps && threadIdx.x == 0) {
+        g.stamps[(long long)blockIdx.x * 8 + i] = __builtin_amdgcn_s_memrealtime();
+        if (i == 2) g.stamps[(long long)blockIdx.x * 8 + 5] = __builtin_readcyclecounter();      // shader-clock cycles over the main loop:
+        if (i == 3) g.stamps[(long long)blockIdx.x * 8 + 6] = __builtin_readcyclecounter();      // with the 100 MHz stamps, the clock it ran at
+    }
 }
 
 // Stream-K segment kinds (gemm_core's `mode`): a whole tile; the LAST k-range of a tile (adds the partial sums the other
@@ -726,6 +730,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 template <typename T>
 __global__ __launch_bounds__(512, 4) void gemm_a3_kernel(const GemmArgs g) {
     gemm_body<T, false, false, 2, 2, 4, 0, 4, true>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n * g.nsplit));
+}
+
+// ---- 192 x 128 tiles, ONE block per CU, k-tiles of 128 (256-byte rows): a lone block pays one LDS-DMA round trip per k-tile whatever
+// the k-tile holds, so a twice deeper k-tile halves the round trips per FLOP; 2 x 80 KB ring = all of the LDS.
+template <typename T>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tall_k128_kernel(const GemmArgs g) {
+    gemm_body<T, false, false, 4, 2, 4, 3>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n * g.nsplit));
 }
 
 // ---- tall tiles, ONE block per CU, register-pipelined main loop (gemm_core, PIPE): 192 x 128 with a 3-deep ring
@@ -1267,6 +1278,12 @@ extern "C" int a8_gemm(const a8_gemm_desc* d, void* stream) {
         int mi = 0;
         if (mode == 3 || mode == 4) mi = mode;
         else if (mode == 1 && t128 > 256 && t128 <= 512) mi = t192 <= 256 ? 3 : (t256 <= 256 ? 4 : 0);
+        // modes 7 / 8: 192-row tiles with 128-element k-tiles, by the same tile-count rule / always
+        if ((mode == 8 || (mode == 7 && t128 > 256 && t128 <= 512 && t192 <= 256)) && g.nsplit == 1) {
+            g.tiles_m = cdiv(d->M, 192);
+            hipLaunchKernelGGL(gemm_tall_k128_kernel<bf16>, dim3((int)t192), dim3(512), 0, s, g);
+            return a8_check_launch("a8_gemm");
+        }
         // modes 5 / 6: the register-pipelined 192-row kernel, by the same tile-count rule / always
         if ((mode == 6 || (mode == 5 && t128 > 256 && t128 <= 512 && t192 <= 256)) && g.nsplit == 1) {
             g.tiles_m = cdiv(d->M, 192);

@@ -200,8 +200,23 @@ def main():
         return prof, sum(p[0].elapsed_time(p[1]) for p in prof), sum(p[2] for p in prof), phase_ms
     prof, tot_ms, tot_fl, ph_run = instrumented()              # as the step runs (weight-gradient GEMMs overlap on a side stream)
     side, ops.WGRAD_SIDE_STREAM = ops.WGRAD_SIDE_STREAM, None
-    sprof, ser_ms, ser_fl, ph_ser = instrumented()             # the same launches one after another (each kernel's own rate)
+    # the shader clock the GEMM main loops actually ran at: every block of the serialised step stamps the 100 MHz counter and the
+    # shader-clock counter at both ends of its main loop (a8_debug_set_stamps); under MFMA load the part runs well below 2.4 GHz
+    stamps = torch.zeros(16384 * 8, device=dev, dtype=torch.int64) if rank == 0 else None
+    if stamps is not None:
+        L.check(L.lib().a8_debug_set_stamps(stamps.data_ptr()), "a8_debug_set_stamps")
+    try:
+        sprof, ser_ms, ser_fl, ph_ser = instrumented()         # the same launches one after another (each kernel's own rate)
+    finally:
+        if stamps is not None:
+            L.check(L.lib().a8_debug_set_stamps(None), "a8_debug_set_stamps")
     ops.WGRAD_SIDE_STREAM = side
+    clock_mhz = None
+    if stamps is not None:
+        st = stamps.view(-1, 8).cpu()
+        ok = (st[:, 3] > st[:, 2]) & (st[:, 6] > st[:, 5])
+        if int(ok.sum()) > 100:
+            clock_mhz = float(((st[ok, 6] - st[ok, 5]).double() / ((st[ok, 3] - st[ok, 2]).double() / 100.0)).median())
     if rank == 0:
         if args.gemm_table:
             tab = {}
@@ -253,7 +268,11 @@ def main():
                     "algorithmic_bytes_per_launch": round(sum(p[4] for p in prof) / max(1, len(prof))),
                     "launches_per_step": len(prof), "avg_launch_us": round(tot_ms * 1e3 / max(1, len(prof)), 2),
                     "gemm_ms_per_step": round(tot_ms, 3), "algorithmic_gflop_per_step": round(tot_fl / 1e9, 1),
-                    "encoder": encoder, "conv_extractor": conv, "peak_hbm_TBs": PEAK_HBM_TBS}
+                    "encoder": encoder, "conv_extractor": conv, "peak_hbm_TBs": PEAK_HBM_TBS,
+                    "shader_clock_mhz_in_gemm": round(clock_mhz) if clock_mhz else None,
+                    "frac_serial_at_measured_clock": round(ser_fl / (ser_ms * 1e-3) / 1e12 / (peak * clock_mhz / 2400.0), 4) if clock_mhz else None,
+                    "clock_note": "peak is the guide's dense figure at the 2.4 GHz boost clock; the median shader clock over the GEMM main loops of the "
+                                  "serialised step is what the power management sustains under this load"}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)

@@ -247,7 +247,7 @@ def test_gemm_160_row_tiles_match_default(depth):
         torch.testing.assert_close(c0, c1, rtol=1e-4, atol=1e-2)       # (column sums combine in a different block order)
 
 
-@pytest.mark.parametrize("key", [5, 11, 8, 13, 14, 86])
+@pytest.mark.parametrize("key", [5, 11, 8, 13, 14, 86, 88])
 def test_gemm_pipelined_256_kernel_matches_default(key):
     """The alternative NT kernels -- pipelined 256 x 256 (a8_set_tuning key 5; N % 256 == 0, K % 64 == 0), full-width persistent
     128 x 512 (key 11; N % 512 == 0, K % 64 == 0), the tall 192-row tile (key 8 = 3) and the 96-column tile (key 13 = 2: whenever
@@ -263,7 +263,7 @@ def test_gemm_pipelined_256_kernel_matches_default(key):
             for k_, v_ in saved.items():
                 L.check(L.lib().a8_set_tuning(k_, v_), "tune")          # the reference: every alternative kernel off
             ref = fn()
-            L.check(L.lib().a8_set_tuning(8 if key == 86 else key, {8: 3, 13: 2, 86: 6}.get(key, 1)), "tune")    # 86: key 8 = 6, the register-pipelined 192-row kernel
+            L.check(L.lib().a8_set_tuning(8 if key in (86, 88) else key, {8: 3, 13: 2, 86: 6, 88: 8}.get(key, 1)), "tune")    # 86 / 88: key 8 = 6 / 8, the register-pipelined / 128-element-k-tile 192-row kernels
             got = fn()
         finally:
             for k_, v_ in {**saved, 14: 10000}.items():                 # back to the library defaults

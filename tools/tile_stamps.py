@@ -36,11 +36,13 @@ for name, m, n, k, opt in [(nm + vn, m, n, k, dict(o, tune=vt)) for (nm, m, n, k
         L.check(L.lib().a8_set_tuning(kk, {14: 10000}.get(kk, 0)), "tune")
     st = stamps.view(-1, 8)
     nb = int((st[:, 4] != 0).sum())                                          # blocks that ran (tile shapes differ by variant)
+    cyc = (st[:nb, 6] - st[:nb, 5]).double().cpu()                           # shader-clock cycles of the main loop
     st = st[:nb, :5].double().cpu() / 100.0                                  # us
+    mhz = float((cyc / (st[:, 3] - st[:, 2]).clamp_min(1e-3)).median())
     t0 = st[:, 0].min()
     ph = [(st[:, i + 1] - st[:, i]) for i in range(4)]
     print("%-28s %5d blocks: kernel span %.1f us | block start spread %.1f us (first round) | per block, mean (p90) us: prologue->DMA issued %.2f (%.2f), "
-          "first k-tile lands %.2f (%.2f), main loop %.2f (%.2f), epilogue %.2f (%.2f), total %.2f" % (
+          "first k-tile lands %.2f (%.2f), main loop %.2f (%.2f), epilogue %.2f (%.2f), total %.2f | shader clock over the main loop %.0f MHz" % (
               name, nb, float(st[:, 4].max() - t0), float(st[: min(nb, 512), 0].max() - t0),
               float(ph[0].mean()), float(ph[0].quantile(0.9)), float(ph[1].mean()), float(ph[1].quantile(0.9)),
-              float(ph[2].mean()), float(ph[2].quantile(0.9)), float(ph[3].mean()), float(ph[3].quantile(0.9)), float((st[:, 4] - st[:, 0]).mean())), flush=True)
+              float(ph[2].mean()), float(ph[2].quantile(0.9)), float(ph[3].mean()), float(ph[3].quantile(0.9)), float((st[:, 4] - st[:, 0]).mean()), mhz), flush=True)
