@@ -208,7 +208,8 @@ class OptimizerManager:
     exchange); gradient clipping stays where the driver put it (torch.nn.utils.clip_grad_norm_ over the flat views) unless
     `clip` is given, which fuses it into the update.
 
-    The learning rate of a step is lr_function(global_step) with global_step counted before the increment."""
+    The learning rate of a step is lr_function(global_step) with global_step as it stands before the step increments it
+    (the first step of a fresh run uses lr_function(0), a run resumed at step N continues with lr_function(N))."""
 
     def __init__(self, model, global_step=0, optim="adamw", lr=2.0e-4, lr_function=None, weight_decay=0.0, clip=0.0, **kwargs):
         from .trainer import Stepper
@@ -232,8 +233,11 @@ class OptimizerManager:
         self.stepper.zero_grad()
 
     def scale_grads(self, s):
-        """train.py:323 `optimizer.scale_grads(num_gpus / batch_size)`; `s` may be a device tensor.  (The native form is
+        """train.py:323 `optimizer.scale_grads(num_gpus / batch_size)`; `s` may be a device tensor.  The driver calls it between
+        backward() and step(), where DDP has already averaged the gradients: Stepper.sync_grads() first completes the exchange
+        (weight-gradient stream joined, every bucket reduced) and turns the flat buffer into that mean.  (The native form is
         `Stepper.step(batch_size=...)`, which needs no pass over the gradients.)"""
+        self.stepper.sync_grads()
         self.stepper.state.flat_g.mul_(s if torch.is_tensor(s) else float(s))
 
     def step(self):
@@ -260,6 +264,20 @@ class PassThroughDDP(torch.nn.Module):
         return trainer.ACTIVE_STEPPER.no_sync()
 
 
+_TORCH_CLIP_GRAD_NORM = torch.nn.utils.clip_grad_norm_
+
+
+def clip_grad_norm_(parameters, max_norm, *args, **kwargs):
+    """`torch.nn.utils.clip_grad_norm_` for the drivers (audio8/pretrain.py:182, train.py:324).  Under DDP every `.grad` is final
+    and averaged when backward() returns; here gradients may still be in flight on the weight-gradient stream and in the bucket
+    all-reduces, and hold the SUM over ranks: the active Stepper completes the exchange and forms the mean first
+    (Stepper.sync_grads()), then torch's own function runs on the flat views."""
+    from . import trainer
+    if trainer.ACTIVE_STEPPER is not None:
+        trainer.ACTIVE_STEPPER.sync_grads()
+    return _TORCH_CLIP_GRAD_NORM(parameters, max_norm, *args, **kwargs)
+
+
 # ------------------------------------------------------------------ module aliases for the unchanged drivers
 def install_aliases(audio8_too=True, patch_ddp=True):
     """Register this package under the module names audio8's drivers import, ahead of (absent) eight_mile:
@@ -267,7 +285,8 @@ def install_aliases(audio8_too=True, patch_ddp=True):
         audio8.utils (create_lrs) and -- with audio8_too -- audio8.wav2vec2 / audio8.ctc.
     Existing real modules are never replaced.  patch_ddp: `torch.nn.parallel.DistributedDataParallel` becomes PassThroughDDP,
     because the Stepper inside OptimizerManager already exchanges the gradients (an all-reduce by DDP on top would average
-    twice, and DDP's reducer cannot see gradients the kernels accumulate in place)."""
+    twice, and DDP's reducer cannot see gradients the kernels accumulate in place) and `torch.nn.utils.clip_grad_norm_` first
+    completes that exchange (clip_grad_norm_ above)."""
     from . import ctc as _ctc, layers as _layers, wav2vec2 as _w2v
     me = sys.modules[__name__]
 
@@ -295,6 +314,7 @@ def install_aliases(audio8_too=True, patch_ddp=True):
         load_tlm_npz=lambda *a, **k: (_ for _ in ()).throw(NotImplementedError("out of scope")))
     if patch_ddp:
         torch.nn.parallel.DistributedDataParallel = PassThroughDDP
+        torch.nn.utils.clip_grad_norm_ = clip_grad_norm_        # the drivers look it up at call time
     if audio8_too:
         mod("audio8")
         mod("audio8.utils", create_lrs=create_lrs, get_lr_decay=get_lr_decay)

@@ -355,10 +355,14 @@ class GradReducer:
         self.begin_pass()
 
     def all_reduce_counts(self, counts):
-        """SUM over ranks of a small device tensor (the batch-size / token counters of audio8/train.py:320-321, as ONE
-        collective) on the exchange stream, behind the gradient buckets; finish() makes the compute stream wait for it."""
+        """SUM over ranks of a small device tensor (the batch-size / token counters of audio8/train.py:320-321 and, when the
+        touched sets may differ between ranks, the per-parameter "has a gradient" flags, as ONE collective) on the exchange
+        stream.  Always issued AFTER every gradient bucket of the step (launch_pending()), so all ranks issue the same sequence of
+        collectives whatever each of them still had pending; wait() makes the compute stream wait for it."""
         if not self.enabled:
             return counts
+        if self.next_bucket < len(self.buckets):
+            raise RuntimeError("a8hip GradReducer: the counts collective must follow launch_pending() (same collective order on every rank)")
         if self.on_gpu:
             self.side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.side):
@@ -368,22 +372,33 @@ class GradReducer:
             self.handles.append(dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         return counts
 
-    def finish(self):
-        """Issue any bucket whose parameters produced no gradient this step (frozen encoder, audio8/train.py:266-268),
-        then make the compute stream wait for the exchange.  Gradients hold the SUM over ranks afterwards (and norm_sq
-        the sum of their squares)."""
+    def launch_pending(self):
+        """Issue, in index order, every bucket that is not out yet: the ones whose parameters produced no gradient on this rank
+        (frozen encoder, audio8/train.py:266-268; a layer this rank dropped) and everything they held back."""
         if not (self.enabled or self.norm_sq is not None):
             return
         for bk in self.buckets[self.next_bucket:]:       # in index order, like the ones already out
             if not bk.get("launched"):
                 self._launch(bk)
         self.next_bucket = len(self.buckets)
+
+    def wait(self):
+        """Make the compute stream (and, for gloo, the host) wait for every collective issued so far.  Gradients hold the SUM
+        over ranks afterwards (and norm_sq the sum of their squares)."""
+        if not (self.enabled or self.norm_sq is not None):
+            return
         for h in self.handles:
             h.wait()
+        self.handles = []
         if self.on_gpu:
             torch.cuda.current_stream().wait_stream(self.side)
             if self.norm_sq is not None and not self.stream_ordered:
                 K.sumsq_(self.state.flat_g, self.norm_sq)         # (gloo rehearsals: the reduced values exist only after wait())
+
+    def finish(self):
+        """launch_pending() + wait()."""
+        self.launch_pending()
+        self.wait()
 
 
 ACTIVE_STEPPER = None        # the Stepper that currently owns audio8_amd.ops' global hooks (driver.PassThroughDDP.no_sync finds it here)
@@ -402,7 +417,7 @@ class Stepper:
     left untouched and keep their own step count, as torch's AdamW does for `p.grad is None`."""
 
     def __init__(self, model, lr=2.0e-4, weight_decay=1.0e-2, betas=(0.9, 0.999), eps=1e-8, clip=1.0, bucket_mb=32.0, lr_function=None,
-                 wgrad_side_stream=True, process_group=None, global_step=0):
+                 wgrad_side_stream=True, process_group=None, global_step=0, sync_touched=None):
         self.state = FlatState(model)
         self.reducer = GradReducer(self.state, bucket_mb, process_group)
         if self.reducer.enabled:                         # C1 of SURVEY 2.2: rank 0's parameters everywhere -- BEFORE anything
@@ -432,6 +447,15 @@ class Stepper:
             ops.CONV_DGRAD_CACHE = self.wcache.conv_dgrad
             ops.WPREP_EARLY = self.wcache.early_ids
         self._versions = [p._version for p in self.state.params]
+        # Which parameters got a gradient can differ BETWEEN RANKS only through layer drop (each process draws from its own
+        # numpy RNG, audio8/wav2vec2.py:613-622); frozen sets follow the global step and are the same everywhere.  With it the
+        # per-parameter flags are OR-ed over the ranks in the step's counts collective, so that every rank updates the same set (as
+        # under DDP, where a parameter any rank used receives the averaged gradient everywhere).  None = detect from the model.
+        if sync_touched is None:
+            sync_touched = any(float(getattr(m, "layer_drop", 0.0) or 0.0) > 0.0 for m in model.modules())
+        self.sync_touched = bool(sync_touched)
+        self._exchanged = False          # this step's gradient exchange has been completed (sync_grads() / step())
+        self._mean_applied = False       # ... and flat_g was turned from the SUM into the MEAN over ranks (sync_grads())
         global ACTIVE_STEPPER
         ACTIVE_STEPPER = self
 
@@ -451,6 +475,8 @@ class Stepper:
             self.refresh_weights()                        # someone wrote to a parameter through torch since the last step
         self.state.zero_grad(already_clean=self._grads_clean)     # step() cleared the buffer behind its read
         self._grads_clean = False
+        self._exchanged = False
+        self._mean_applied = False
         if self.reducer.norm_sq is not None:
             self.gnorm_sq.zero_()
         self.reducer.begin_step()
@@ -503,35 +529,75 @@ class Stepper:
         self._uniform_steps = len(set(self.param_steps)) == 1
         return runs
 
+    def _exchange(self, batch_size=None, num_tokens=None):
+        """Complete the step's gradient exchange; idempotent until zero_grad().  Order, identical on every rank: join the
+        weight-gradient stream; issue every bucket still pending, in index order; then ONE small SUM collective that carries the
+        batch-size / token counters (audio8/train.py:320-321) and -- sync_touched -- the per-parameter "got a gradient" flags; wait.
+        Returns the all-reduced int64 device tensor [batch_size, num_tokens] when a batch size was given, else None."""
+        st, red = self.state, self.reducer
+        need_flags = self.sync_touched and red.enabled and not self._exchanged
+        if self._exchanged and batch_size is None:
+            return None
+        if not self._exchanged:
+            if self.wgrad_stream is not None:            # join the weight-gradient stream before gradients are read
+                torch.cuda.current_stream().wait_stream(self.wgrad_stream)
+            red.launch_pending()
+        payload = None
+        if batch_size is not None or need_flags:
+            vals = [0 if batch_size is None else batch_size, 0 if num_tokens is None else num_tokens]
+            host = [0 if torch.is_tensor(v) else int(v) for v in vals]
+            if need_flags:
+                host += [1 if t else 0 for t in red.touched]
+            if st.flat_p.is_cuda:
+                payload = ops.host_to_device(host, "int64")
+            else:
+                payload = torch.tensor(host, dtype=torch.int64)
+            for k, v in enumerate(vals):
+                if torch.is_tensor(v):
+                    payload[k] = v.to(device=payload.device, dtype=torch.int64).reshape(())
+            payload = red.all_reduce_counts(payload)
+        red.wait()
+        if need_flags:
+            flags = payload[2:].cpu()                    # (a host sync: only on models with layer drop under data parallelism)
+            red.touched = [bool(f) for f in flags.tolist()]
+            red.n_touched = sum(red.touched)
+        self._exchanged = True
+        return payload[:2] if batch_size is not None else None
+
+    def sync_grads(self):
+        """What DistributedDataParallel guarantees when backward() returns, on demand: every gradient final (weight-gradient stream
+        joined, all buckets exchanged) and `.grad` = the MEAN over ranks.  For code that reads or rescales gradients between
+        backward() and step() -- the drivers' clip_grad_norm_ and OptimizerManager.scale_grads (audio8/pretrain.py:182,
+        train.py:323-324).  The native path (Stepper(clip=...).step()) never needs it: the 1 / world factor rides in AdamW."""
+        if self._mean_applied:
+            return
+        self._exchange()
+        if self.reducer.enabled and self.reducer.world > 1:
+            self.state.flat_g.mul_(1.0 / self.reducer.world)
+        self._mean_applied = True
+
     def step(self, batch_size=None, num_tokens=None):
         """Exchange what is still pending, clip, AdamW.  With `batch_size` (int or 0-dim integer tensor; `num_tokens` likewise)
         the gradients are divided by the batch size summed over ranks instead of by the world size; returns the all-reduced
-        int64 device tensor [batch_size, num_tokens] (train.py logs both), else None."""
+        int64 device tensor [batch_size, num_tokens] (train.py logs both), else None.  The step's learning rate is
+        lr_function(global_step) with global_step as it stands BEFORE this step increments it."""
         st = self.state
         for p, want in zip(st.params, self._grad_ptrs):
             g = p.grad
             if g is None or g.data_ptr() != want:
                 raise RuntimeError("a8hip Stepper: a parameter's .grad no longer aliases the flat gradient buffer -- use "
                                    "stepper.zero_grad(), not model.zero_grad(set_to_none=True), between steps")
-        if self.wgrad_stream is not None:                # join the weight-gradient stream before gradients are read
-            torch.cuda.current_stream().wait_stream(self.wgrad_stream)
-        counts = None
-        if batch_size is not None:
-            vals = [batch_size, 0 if num_tokens is None else num_tokens]
-            if any(torch.is_tensor(v) for v in vals):
-                counts = torch.stack([torch.as_tensor(v, device=st.flat_p.device).to(torch.int64).reshape(()) for v in vals])
-            elif st.flat_p.is_cuda:
-                counts = ops.host_to_device([int(v) for v in vals], "int64")
-            else:
-                counts = torch.tensor([int(v) for v in vals], dtype=torch.int64)
-            counts = self.reducer.all_reduce_counts(counts)
-        self.reducer.finish()
+        counts = self._exchange(batch_size, num_tokens)
+        lr = self.current_lr
         self.global_step += 1
-        scale = 1.0 if counts is not None else 1.0 / self.reducer.world
-        if self.reducer.norm_sq is None:
+        world = self.reducer.world if self.reducer.enabled else 1
+        if counts is not None:                           # SUM over ranks / summed batch size
+            scale = float(world) if self._mean_applied else 1.0
+        else:                                            # MEAN over ranks
+            scale = 1.0 if self._mean_applied else 1.0 / world
+        if self.reducer.norm_sq is None or self._mean_applied:
             self.gnorm_sq.zero_()
             K.sumsq_(st.flat_g, self.gnorm_sq)
-        lr = self.current_lr
         for lo, hi, nstep in self._active_runs():
             K.adamw_(st.flat_p[lo:hi], st.flat_g[lo:hi], st.flat_m[lo:hi], st.flat_v[lo:hi], lr, self.betas[0], self.betas[1],
                      self.eps, self.wd, nstep, self.gnorm_sq, self.clip, scale, zero_grad=True, grad_denom=counts)

@@ -162,6 +162,62 @@ def _w2v_worker(rank, world, port, q):
             ok = ok and bool(covered[o:o + p.numel()].all()) == (not is_frozen)
             ok = ok and st.param_steps[i] == (1 if is_frozen else 2)
         ok = ok and len(runs) >= 2
+        def chk(ok_, tag, cond):
+            if not cond:
+                print("rank %d: DP contract check %s failed" % (rank, tag), flush=True)
+            return ok_ and bool(cond)
+
+        # ---- window 3: layer drop drawn per rank (each process has its own numpy RNG, audio8/wav2vec2.py:613-622): rank 0 drops
+        # encoder layer 0, rank 1 drops layer 1.  The bucket holding a dropped layer never completes on that rank and holds the
+        # later ones back until the step: both ranks must still issue the same collective sequence (buckets in index order, then
+        # the counts + flags collective), end with the SUM, and agree on which parameters to update (the union).
+        fs.flat_g.zero_()
+        st._grads_clean = True
+        st.zero_grad()
+        st.sync_touched = True
+        mine = "encoder.transformer.encoders.%d." % rank
+        run_backward(g2, skip=(mine,))
+        ok = chk(ok, 1, red.next_bucket < len(red.buckets))  # something was held back on this rank
+        local_touched = list(red.touched)
+        ok = chk(ok, 2, not all(local_touched))
+        try:                                                   # the counts collective may not overtake pending buckets
+            red.all_reduce_counts(torch.zeros(2, dtype=torch.int64))
+            ok = chk(ok, 99, False)
+        except RuntimeError:
+            pass
+        counts = st._exchange(batch_size=3 + rank, num_tokens=torch.tensor(7 * (rank + 1)))
+        ok = chk(ok, 3, counts.tolist() == [sum(3 + r for r in range(world)), sum(7 * (r + 1) for r in range(world))])
+        ok = chk(ok, 4, all(red.touched) and red.n_touched == len(fs.params))  # union over ranks: every layer was used somewhere
+        want = torch.zeros_like(fs.flat_g)
+        for r in range(world):
+            gr = oracle_grads(20 + r)
+            for p, o in zip(fs.params, fs.offsets):
+                if not names[id(p)].startswith("encoder.transformer.encoders.%d." % r):
+                    want[o:o + p.numel()] += gr[names[id(p)]].reshape(-1)
+        ok = chk(ok, 5, torch.allclose(fs.flat_g, want, rtol=1e-5, atol=1e-7))
+        both = [torch.empty_like(fs.flat_g) for _ in range(world)]
+        dist.all_gather(both, fs.flat_g)
+        ok = chk(ok, 6, torch.equal(both[0], both[1]))  # bitwise the same reduced gradients on both ranks
+        ok = chk(ok, 7, st._exchange() is None)  # idempotent: nothing is issued twice
+        # ---- window 4: the unchanged drivers' order -- backward; clip_grad_norm_; step (audio8/pretrain.py:179-183): the patched
+        # clip first completes the exchange and forms the MEAN, so every rank clips the same, averaged, gradient
+        from audio8_amd import driver
+        fs.flat_g.zero_()
+        st._grads_clean = True
+        st.zero_grad()
+        st.sync_touched = False
+        run_backward(g2)
+        total = driver.clip_grad_norm_(model.parameters(), 0.5)
+        mean = torch.zeros_like(fs.flat_g)
+        for r in range(world):
+            gr = oracle_grads(20 + r)
+            for p, o in zip(fs.params, fs.offsets):
+                mean[o:o + p.numel()] += gr[names[id(p)]].reshape(-1) / world
+        mnorm = float(mean.double().norm())                    # (float32 norm() of 24 M elements on the CPU is only good to ~2e-4)
+        ok = chk(ok, 8, st._mean_applied and abs(float(total) - mnorm) <= 1e-4 * mnorm)
+        ok = chk(ok, 9, torch.allclose(fs.flat_g, mean * min(1.0, 0.5 / (mnorm + 1e-6)), rtol=1e-4, atol=1e-8))
+        st.sync_grads()                                        # a second call must not divide again
+        ok = chk(ok, 10, torch.allclose(fs.flat_g, mean * min(1.0, 0.5 / (mnorm + 1e-6)), rtol=1e-4, atol=1e-8))
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
