@@ -27,7 +27,6 @@ ARGTYPES = {
     "a8_encoder_layer_fwd": [C.c_void_p, C.c_void_p],
     "a8_encoder_layer_bwd": [C.c_void_p, C.c_void_p],
     "a8_set_tuning": [C.c_int, C.c_int],
-    "a8_debug_set_stamps": [C.c_void_p],
     "a8_prepare_weights": [C.c_int, C.c_void_p, C.c_int, C.c_void_p],
     "a8_prepare_weights_device": [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p],
     "a8_conv0_gn_gelu_fwd": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p],
@@ -82,7 +81,6 @@ class GemmDesc(C.Structure):
         ("out_f32", C.c_int), ("accumulate", C.c_int), ("splitk", C.c_int),
         ("alpha", C.c_float),
         ("colsum", C.c_void_p),
-        ("sk_ws", C.c_void_p), ("sk_ws_bytes", C.c_int64), ("sk_epoch", C.c_uint32),
     ]
 
 
@@ -99,9 +97,6 @@ class EncoderLayerBwdDesc(C.Structure):
                [(n, C.c_void_p) for n in ("dx2", "x", "qkv", "o", "ao", "x1", "z1", "f", "keymask", "lse", "mean2", "rstd2", "mean1", "rstd1", "g1", "g2",
                                           "w2_t", "w1_t", "wo_t", "dg1", "dbe1", "dg2", "dbe2", "db2", "db1", "dbo",
                                           "df", "dx1_res", "dz1", "dx1_ffn", "dao", "dx_res", "dout_o", "dqkv", "delta")]
-
-
-GEMM_SK_WS_BYTES = 65536 + 512 * 65536          # A8_GEMM_SK_WS_BYTES of include/a8hip.h
 
 
 class WPrepDesc(C.Structure):
@@ -124,6 +119,9 @@ def lib():
             fn = getattr(_lib, name)
             fn.argtypes = argtypes
             fn.restype = C.c_int
+        if hasattr(_lib, "a8_debug_set_stamps"):          # developer build only (make STAMPS=1): in-kernel timestamps of the GEMM tiles
+            _lib.a8_debug_set_stamps.argtypes = [C.c_void_p]
+            _lib.a8_debug_set_stamps.restype = C.c_int
     return _lib
 
 
@@ -160,7 +158,7 @@ def require_cuda(*ts):
 
 
 EXPORTS = [
-    "a8_version", "a8_last_error", "a8_gemm", "a8_gemm_grouped", "a8_set_tuning", "a8_debug_set_stamps", "a8_encoder_layer_fwd", "a8_encoder_layer_bwd", "a8_prepare_weights", "a8_prepare_weights_device",
+    "a8_version", "a8_last_error", "a8_gemm", "a8_gemm_grouped", "a8_set_tuning", "a8_encoder_layer_fwd", "a8_encoder_layer_bwd", "a8_prepare_weights", "a8_prepare_weights_device",
     "a8_conv0_gn_gelu_fwd", "a8_conv0_gn_gelu_bwd", "a8_col2im_gelu_grad",
     "a8_layernorm_fwd", "a8_layernorm_bwd",
     "a8_cast", "a8_dropout", "a8_mask_fill_rows", "a8_mask_fill_rows_bwd", "a8_mask_zero_cols", "a8_zero_rows",

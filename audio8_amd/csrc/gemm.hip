@@ -29,11 +29,13 @@ struct GemmArgs {
     const float* bias;
     float* colsum;
     int M, N, K, kchunk, nsplit, tiles_m, tiles_n;
-    int act, out_f32, atomic, bias_rows, group_m, zpre;
-    unsigned long long* stamps;                   // developer aid (a8_debug_set_stamps): 8 timestamps per block, nullptr = off
-    char* sk_ws; unsigned sk_epoch;               // stream-K: flag words (64 B apart) then 64 KB f32 slabs, one of each per worker
+    int act, out_f32, atomic, bias_rows, group_m;
+#ifdef A8_STAMPS
+    unsigned long long* stamps;                   // developer build only (make STAMPS=1, a8_debug_set_stamps): 8 timestamps per block, nullptr = off
+#endif
     float alpha;
 };
+
 
 // (index / rows_per_batch, index % rows_per_batch) -> offset.  Indices and rows_per_batch fit 31 bits (checked on the host): one
 // 32-bit unsigned division instead of the ~200-instruction 64-bit one the compiler emits for long long operands.
@@ -60,7 +62,7 @@ A8_DEV void glds16(const char* src, char* lds_dst_wave_uniform) {
 //   KS f32 : [BK k][512 B]; piece = 2 k-rows; lane -> k 2p + l/32, 16-B piece l%32 (no swizzle)
 template <int KB> struct KcGeom {
     static constexpr int KROW = 64 * KB, SPR = KROW / 16, RPP = 1024 / KROW, OPBYTES = 128 * KROW, NPIECE = OPBYTES / 1024;
-    static A8_DEV int swz(int row) { return KB == 1 ? ((row >> 1) & 3) : KB == 4 ? (row & 15) : (row & 7); }     // (one 16-byte slot per row of a 16-row fragment)
+    static A8_DEV int swz(int row) { return KB == 1 ? ((row >> 1) & 3) : (row & 7); }     // (one 16-byte slot per row of a 16-row fragment)
 };
 template <typename T, int KB> struct StageTile;
 template <int KB> struct StageTile<bf16, KB> {
@@ -71,23 +73,18 @@ template <int KB> struct StageTile<bf16, KB> {
         const int row = rb + (lane & 15);
         return *reinterpret_cast<const bf16x8*>(t + row * G::KROW + (((ks * 4 + (lane >> 4)) ^ G::swz(row)) << 4));
     }
-    // ROWS = operand rows of the tile (128, or 256: the image is then [BK k][512 B], a DMA piece 2 k-rows; the 3-bit key still
-    // spreads the eight k-rows a 32-lane group touches over all 64 banks)
-    template <int ROWS = 128>
     static A8_DEV bf16x8 ks_frag(const char* t, int rb, int ks, int lane) {
         const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3, nb = rb >> 4;
         const int k0 = ks * 32 + 8 * g + q, k1 = k0 + 4;
-        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, t + k0 * (2 * ROWS) + ((nb ^ ks_key(k0)) << 5) + 8 * p));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, t + k1 * (2 * ROWS) + ((nb ^ ks_key(k1)) << 5) + 8 * p));
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, t + k0 * 256 + ((nb ^ ks_key(k0)) << 5) + 8 * p));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, t + k1 * 256 + ((nb ^ ks_key(k1)) << 5) + 8 * p));
         typedef short s16x8 __attribute__((ext_vector_type(8)));
         s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(bf16x8, v);
     }
-    template <int ROWS = 128>
     static A8_DEV void ks_src(int p, int lane, int& k, int& col) {
-        constexpr int LPR = ROWS / 8;                    // lanes (16-byte pieces) per k-row: 16 or 32
-        k = (64 / LPR) * p + lane / LPR;
-        const int pc = lane % LPR;
+        k = 4 * p + (lane >> 4);                         // 16 lanes (16-byte pieces) per k-row
+        const int pc = lane & 15;
         col = (((pc >> 1) ^ ks_key(k)) << 4) + ((pc & 1) << 3);
     }
 };
@@ -98,24 +95,22 @@ template <int KB> struct StageTile<float, KB> {
         const int row = rb + (lane & 15);
         return *reinterpret_cast<const float*>(t + row * G::KROW + ((ks ^ G::swz(row)) << 4) + ((lane >> 4) << 2));
     }
-    template <int ROWS = 128>
     static A8_DEV float ks_frag(const char* t, int rb, int ks, int lane) {
-        static_assert(ROWS == 128, "f32 K-strided tiles are 128 rows");
         return *reinterpret_cast<const float*>(t + (ks * 4 + (lane >> 4)) * 512 + (rb + (lane & 15)) * 4);
     }
-    template <int ROWS = 128>
     static A8_DEV void ks_src(int p, int lane, int& k, int& col) {
         k = 2 * p + (lane >> 5);
         col = (lane & 31) << 2;
     }
 };
-
 // ---- epilogue (shared by the main-loop variants).  Needs NWM*2 waves x (16*MI/NP rows x 64 cols x 4 B) of free LDS;
 // NP = passes over the wave's rows (2 halves the staging so that small-LDS variants keep their occupancy).
 template <typename T> struct Vec8 { typedef T type __attribute__((ext_vector_type(8))); };
 
 // zpre (16-bit outputs, NP == 1, when use_zpre): the lane's zin values, loaded by the caller ahead of its main loop
-template <typename T, int MI, int NWM, int NP = 1, int NJ = 4>
+constexpr int NJ = 4;              // 16-column fragments per wave along N: a wave owns (16 MI) x 64 of the 128 x 128 tile
+
+template <typename T, int MI, int NWM, int NP = 1>
 A8_DEV void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MI][NJ], char* lds, const int w, const int m0, const int n0, const int lane,
                           const typename Vec8<T>::type (&zpre)[2 * MI], const bool use_zpre, const float (&bpre)[8], const bool use_bpre) {
     const int wm = w >> 1, wn = w & 1;
@@ -242,9 +237,9 @@ A8_DEV void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MI][NJ], char* lds, co
         }
     }
 }
-
 // Main loop: NST-deep ring of LDS stages filled by LDS-DMA (global_load_lds, 16 B per lane), NST-1 k-tiles in
 // flight per block; one raw s_barrier and one counted s_waitcnt vmcnt per k-tile; no register staging.
+#ifdef A8_STAMPS
 A8_DEV void stamp(const GemmArgs& g, int i) {
     if (g.stamps && threadIdx.x == 0) {
         g.stamps[(long long)blockIdx.x * 8 + i] = __builtin_amdgcn_s_memrealtime();
@@ -252,41 +247,35 @@ A8_DEV void stamp(const GemmArgs& g, int i) {
         if (i == 3) g.stamps[(long long)blockIdx.x * 8 + 6] = __builtin_readcyclecounter();      // with the 100 MHz stamps, the clock it ran at
     }
 }
+#else
+A8_DEV void stamp(const GemmArgs&, int) {}
+#endif
 
-// Stream-K segment kinds (gemm_core's `mode`): a whole tile; the LAST k-range of a tile (adds the partial sums the other
-// contributors published, then runs the epilogue); any other k-range (publishes its partial sums, no epilogue)
-enum { SEG_FULL = 0, SEG_FINISH = 1, SEG_PARTIAL = 2 };
-constexpr int SK_XCDS = 8;          // blocks b, b + 8, b + 16 ... are observed to share an XCD (a speed assumption only)
-constexpr int SK_FLAG_STRIDE = 64, SK_FLAG_BYTES = 65536, SK_SLAB_BYTES = 65536;     // (A8_GEMM_SK_WS_BYTES: flags, then A8_GEMM_SK_WORKERS slabs)
-
-template <typename T, bool AKS, bool BKS, int KB, int NST, int NWM, int MIP = 0, int NJ = 4, bool A3 = false, bool SK = false, bool PIPE = false>
-A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const int kend, const int mode, const int worker, const int c_first) {
+// A3: the asymmetric ring (A three k-tiles deep, B two) of gemm_a3_kernel below
+template <typename T, bool AKS, bool BKS, int KB, int NST, int NWM, bool A3 = false>
+A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const int kend) {
     typedef StageTile<T, KB> ST;
     typedef KcGeom<KB> G;
     typedef Mma<T> MM;
     constexpr int BK = ST::BK, EPC = 16 / (int)sizeof(T), SZ = (int)sizeof(T);
     constexpr int NW = 2 * NWM;                   // waves per block: NWM along M x 2 along N
-    constexpr int MI = MIP ? MIP : (NWM == 2 ? 4 : 2);   // 16-row fragments per wave along M: a wave owns (16 MI) x 64 of the tile
-    constexpr int BM = 16 * MI * NWM;             // tile rows: 128; 160 with 10 waves (NWM = 5); 192 / 256 with 8 waves of 48 / 64 rows (MIP = 3 / 4)
-    static_assert(BM == 128 || !(AKS || BKS) || (BM == 256 && sizeof(T) == 2), "K-strided tiles are 128 or (16-bit) 256 rows");
-    constexpr int BN = 32 * NJ;                   // tile columns: 128; 96 with NJ = 3 (a wave owns 48)
-    static_assert(NJ == 4 || !(AKS || BKS) || (NJ == 8 && sizeof(T) == 2), "K-strided tiles are 128 or (16-bit) 256 columns");
+    constexpr int MI = NWM == 2 ? 4 : 2;          // 16-row fragments per wave along M: a wave owns (16 MI) x 64 of the tile
+    constexpr int BM = 16 * MI * NWM, BN = 32 * NJ;
+    static_assert(BM == 128 && BN == 128, "128 x 128 tiles");
     constexpr int TA = BM * G::KROW, TB = BN * G::KROW, STAGE = TA + TB;
-    constexpr int NPA = TA / 1024, NPB = TB / 1024;                        // 1 KB LDS-DMA pieces per operand per stage
-    constexpr int PPA = (NPA + NW - 1) / NW, PPB = (NPB + NW - 1) / NW;    // ... per wave (the last may be missing when NW does not divide)
-    constexpr int PPW = PPA > PPB ? PPA : PPB;
-    constexpr bool UNEVEN = NPA % NW != 0 || NPB % NW != 0;                // then a wave without a last piece DMAs 16 zero bytes per lane
-    static_assert(!A3 || (!AKS && !BKS && NST == 2 && !UNEVEN), "the 3-deep A ring is built for NT, 2-deep B, even piece counts");
-    constexpr int RING = A3 ? 3 * TA + 2 * TB : NST * STAGE + (UNEVEN ? 1024 : 0);   // (spare KB: so that vmcnt counts stay uniform)
+    constexpr int PPA = TA / 1024 / NW, PPB = TB / 1024 / NW;              // 1 KB LDS-DMA pieces per operand per stage per wave
+    static_assert(PPA * NW * 1024 == TA && PPB * NW * 1024 == TB && PPA == PPB, "the waves share the DMA pieces evenly");
+    constexpr int PPW = PPA;
+    static_assert(!A3 || (!AKS && !BKS && NST == 2), "the 3-deep A ring is built for NT with a 2-deep B ring");
+    constexpr int RING = A3 ? 3 * TA + 2 * TB : NST * STAGE;
     constexpr int NP = (KB == 1 && NST == 2) ? 2 : 1;                      // small-LDS variant: epilogue in two passes
-    constexpr int EPI = NJ == 8 ? NW * 16 * 128 * 4 : NW * 16 * MI * 64 * 4 / NP;   // epilogue staging: a 64-column f32 slab per wave (NJ = 8: 16 rows x 128 columns)
+    constexpr int EPI = NW * 16 * MI * 64 * 4 / NP;                        // epilogue staging: a 64-column f32 slab per wave
     __shared__ __attribute__((aligned(1024))) char lds[RING > EPI ? RING : EPI];
 
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = w >> 1, wn = w & 1;            // wm in [0, NWM)
-    if constexpr (SK) __syncthreads();            // the previous segment's epilogue is done with the LDS this segment's DMAs refill
-    if constexpr (!SK) stamp(g, 0);
+    stamp(g, 0);
     // grouped tile order: consecutive ids (= one XCD's co-resident blocks) cover GROUP_M m-tiles x several n-tiles, so
     // both the A row-panels and the B tiles they touch stay resident in that XCD's 4 MB L2 (sweeping all n-tiles per
     // m-panel streamed the whole weight matrix through L2 once per panel: 5-10x over-fetch measured with FETCH_SIZE).
@@ -312,7 +301,7 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
             a_ptr[j] = g.A.p + (a_ok[j] ? outer_off(g.A, row) : 0) * SZ;
         } else {
             int kl, col;
-            ST::template ks_src<BM>(p, lane, kl, col);
+            ST::ks_src(p, lane, kl, col);
             a_k[j] = kl;
             a_ok[j] = m0 + col + EPC <= g.M;
             a_ptr[j] = g.A.p + (long long)(m0 + col) * SZ;
@@ -324,7 +313,7 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
             b_ptr[j] = g.B.p + (b_ok[j] ? outer_off(g.B, row) : 0) * SZ;
         } else {
             int kl, col;
-            ST::template ks_src<BN>(p, lane, kl, col);
+            ST::ks_src(p, lane, kl, col);
             b_k[j] = kl;
             b_ok[j] = n0 + col + EPC <= g.N;
             b_ptr[j] = g.B.p + (long long)(n0 + col) * SZ;
@@ -359,8 +348,7 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
         const int k0 = kbeg + kb * BK;
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
-            const int p = w + NW * j;                 // wave-uniform: a missing last piece is a scalar branch
-            const bool has_a = j < PPA && (NPA % NW == 0 || p < NPA), has_b = j < PPB && (NPB % NW == 0 || p < NPB);
+            const int p = w + NW * j;
             const char* sa;
             if constexpr (!AKS) {
                 const int k = k0 + a_k[j];
@@ -371,8 +359,7 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
                 a_cur[j] += a_step;
                 if (g.A.rpb) { a_r[j] += BK; while (a_r[j] >= (int)g.A.rpb) { a_r[j] -= (int)g.A.rpb; a_cur[j] += a_wrap; } }
             }
-            if (has_a) glds16(sa, ta + p * 1024);
-            else if (UNEVEN && j < PPA) glds16(zero, lds + NST * STAGE);
+            glds16(sa, ta + p * 1024);
             const char* sb;
             if constexpr (!BKS) {
                 const int k = k0 + b_k[j];
@@ -383,8 +370,7 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
                 b_cur[j] += b_step;
                 if (g.B.rpb) { b_r[j] += BK; while (b_r[j] >= (int)g.B.rpb) { b_r[j] -= (int)g.B.rpb; b_cur[j] += b_wrap; } }
             }
-            if (has_b) glds16(sb, tb + p * 1024);
-            else if (UNEVEN && j < PPB) glds16(zero, lds + NST * STAGE);
+            glds16(sb, tb + p * 1024);
         }
     };
 
@@ -398,14 +384,14 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
     // issue they must not delay), so the loop's first counted wait retires them together with that k-tile (their latency would otherwise sit, exposed,
     // between the last MFMA and the stores of every tile).  16-bit rows only; the lane -> (row, 8 columns) map of gemm_epilogue.
     typedef typename Vec8<T>::type T8z;
-    constexpr bool ZPRE = sizeof(T) == 2 && NP == 1 && NJ != 8;
+    constexpr bool ZPRE = sizeof(T) == 2 && NP == 1;
     T8z zpre[2 * MI];
     bool use_zpre = false;
     float bpre[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // the lane's 8 bias columns, for the same reason
     bool use_bpre = false;
     auto prefetch_epilogue_inputs = [&]() {
         if constexpr (ZPRE) {
-            use_zpre = g.zpre && g.zin != nullptr && !g.out_f32 && (g.act == A8_ACT_MUL_GELU_GRAD || g.act == A8_ACT_ADD) && !(SK && mode == SEG_PARTIAL);
+            use_zpre = g.zin != nullptr && !g.out_f32 && (g.act == A8_ACT_MUL_GELU_GRAD || g.act == A8_ACT_ADD);
             if (use_zpre) {
                 const int c8 = (lane & 7) << 3, n = n0 + wn * (16 * NJ) + c8;
 #pragma unroll
@@ -419,9 +405,8 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
                 }
             }
         }
-
         if constexpr (ZPRE && !BKS) {                                     // (a bias rides on forward products: NT)
-            use_bpre = g.zpre && g.bias != nullptr && !g.bias_rows && !g.out_f32 && !(SK && mode == SEG_PARTIAL);
+            use_bpre = g.bias != nullptr && !g.bias_rows && !g.out_f32;
             if (use_bpre) {
                 const int c8 = (lane & 7) << 3, n = n0 + wn * (16 * NJ) + c8;
                 if (n < g.N && c8 < 16 * NJ) {
@@ -433,57 +418,7 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
         }
     };
 
-    if constexpr (PIPE) {
-        // One block per CU (tools/tile_stamps.py: a lone block of the default loop spends 0.65 us per k-tile -- one LDS-DMA round trip,
-        // then its fragment reads, then its MFMAs, in series -- for 0.21 us of MFMA work).  Here the fragments of k-tile kb+1 are read
-        // into a second register set while k-tile kb multiplies, which also frees the LDS stage of kb one iteration early: with NST
-        // stages the DMA of k-tile kb+NST is issued at the top of iteration kb and has NST-1 iterations to land.  One barrier per k-tile.
-        static_assert(!AKS && !BKS && !UNEVEN && !A3 && !SK, "the pipelined loop is built for NT and even piece counts");
-        typename MM::Frag fa[2][ST::KSTEPS][MI], fb[2][ST::KSTEPS][NJ];
-        auto rd = [&](int set, int kb) {
-            const char* ta = lds + (kb % NST) * STAGE;
-            const char* tb = ta + TA;
-#pragma unroll
-            for (int ks = 0; ks < ST::KSTEPS; ++ks) {
-#pragma unroll
-                for (int i = 0; i < MI; ++i) fa[set][ks][i] = ST::kc_frag(ta, wm * (16 * MI) + 16 * i, ks, lane);
-#pragma unroll
-                for (int i = 0; i < NJ; ++i) fb[set][ks][i] = ST::kc_frag(tb, wn * (16 * NJ) + 16 * i, ks, lane);
-            }
-        };
-        auto mm = [&](int set) {
-#pragma unroll
-            for (int ks = 0; ks < ST::KSTEPS; ++ks)
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) acc[i][j] = MM::mma(fb[set][ks][j], fa[set][ks][i], acc[i][j]);
-        };
-        issue(0);
-        prefetch_epilogue_inputs();                    // older than stages 1.. : retired by the wait for stage 0
-#pragma unroll
-        for (int s = 1; s < NST; ++s) issue(s);
-        stamp(g, 1);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 1) * (PPA + PPB)) : "memory");
-        __builtin_amdgcn_s_barrier();
-        stamp(g, 2);
-        rd(0, 0);
-        auto iter = [&](int kb, int cur) {
-            // DMA(kb+1) has landed once all but the NST-2 youngest stages' pieces are done; this wave's reads of stage kb are complete
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NST - 2) * (PPA + PPB)) : "memory");
-            __builtin_amdgcn_s_barrier();
-            issue(kb + NST);                           // into the stage of k-tile kb: every wave holds its fragments in registers
-            __builtin_amdgcn_sched_barrier(0);
-            if (kb + 1 < nkb) rd(cur ^ 1, kb + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(cur);
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        for (int kb = 0; kb < nkb; kb += 2) {
-            iter(kb, 0);
-            if (kb + 1 < nkb) iter(kb + 1, 1);
-        }
-    } else if constexpr (A3) {
+    if constexpr (A3) {
         // Asymmetric ring: the A operand (activations, streamed once from HBM / the Infinity Cache) is requested TWO k-tiles
         // ahead into a 3-deep ring, the B operand (weights, L2-resident) one k-tile ahead into a 2-deep ring: 3 x 16 + 2 x 16 = 80 KB,
         // still two blocks per CU.  Per iteration a wave issues its B pieces first and its A pieces last, so "all but the PPA
@@ -509,12 +444,12 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
         issue_b(0, bbase);
         prefetch_epilogue_inputs();
         issue_a(1, lds + TA);
-        if constexpr (!SK) stamp(g, 1);
+        stamp(g, 1);
         int sa = 0, sb = 0;                           // ring slots of the k-tile being consumed
         for (int kb = 0; kb < nkb; ++kb) {
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPA) : "memory");
             __builtin_amdgcn_s_barrier();
-            if constexpr (!SK) { if (kb == 0) stamp(g, 2); }
+            if (kb == 0) stamp(g, 2);
             const int sa2 = sa == 0 ? 2 : sa - 1;     // (sa + 2) % 3: the slot read in the previous iteration
             issue_b(kb + 1, bbase + (sb ^ 1) * TB);   // (beyond kend: 16 zero bytes per lane -- keeps the counts uniform)
             issue_a(kb + 2, lds + sa2 * TA);
@@ -540,229 +475,67 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
         }
     } else {
 #pragma unroll
-    for (int s = 0; s < NST - 1; ++s) issue(s);
-    if constexpr (!SK) stamp(g, 1);
-    prefetch_epilogue_inputs();
-    for (int kb = 0; kb < nkb; ++kb) {
-        // stage kb has landed once all but the (NST-2) youngest stages' DMAs of this wave are done (2*PPW per stage per lane)
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NST - 2) * (PPA + PPB)) : "memory");
-        __builtin_amdgcn_s_barrier();
-        if constexpr (!SK) { if (kb == 0) stamp(g, 2); }
-        // DMA issue order, measured: with plain b128 fragment reads (NT) issuing the refill first is best; with
-        // transposed reads (twice the LDS instructions) issuing it after the reads hides its issue slots in their latency
-        if constexpr (!(AKS || BKS)) issue(kb + NST - 1);
-        const char* ta = lds + (kb % NST) * STAGE;
-        const char* tb = ta + TA;
-        // all fragment reads of the k-tile are issued up front (one exposed LDS latency per tile, counted lgkmcnt waits
-        // after that), pinned ahead of the MFMA block
-        typename MM::Frag fa[ST::KSTEPS][MI], fb[ST::KSTEPS][NJ];
+        for (int s = 0; s < NST - 1; ++s) issue(s);
+        stamp(g, 1);
+        prefetch_epilogue_inputs();
+        for (int kb = 0; kb < nkb; ++kb) {
+            // stage kb has landed once all but the (NST-2) youngest stages' DMAs of this wave are done (2*PPW per stage per lane)
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NST - 2) * (PPA + PPB)) : "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kb == 0) stamp(g, 2);
+            // DMA issue order, measured: with plain b128 fragment reads (NT) issuing the refill first is best; with
+            // transposed reads (twice the LDS instructions) issuing it after the reads hides its issue slots in their latency
+            if constexpr (!(AKS || BKS)) issue(kb + NST - 1);
+            const char* ta = lds + (kb % NST) * STAGE;
+            const char* tb = ta + TA;
+            // all fragment reads of the k-tile are issued up front (one exposed LDS latency per tile, counted lgkmcnt waits
+            // after that), pinned ahead of the MFMA block
+            typename MM::Frag fa[ST::KSTEPS][MI], fb[ST::KSTEPS][NJ];
 #pragma unroll
-        for (int ks = 0; ks < ST::KSTEPS; ++ks) {
+            for (int ks = 0; ks < ST::KSTEPS; ++ks) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
-                fa[ks][i] = AKS ? ST::template ks_frag<BM>(ta, wm * (16 * MI) + 16 * i, ks, lane) : ST::kc_frag(ta, wm * (16 * MI) + 16 * i, ks, lane);
+                for (int i = 0; i < MI; ++i)
+                    fa[ks][i] = AKS ? ST::ks_frag(ta, wm * (16 * MI) + 16 * i, ks, lane) : ST::kc_frag(ta, wm * (16 * MI) + 16 * i, ks, lane);
 #pragma unroll
-            for (int i = 0; i < NJ; ++i)
-                fb[ks][i] = BKS ? ST::template ks_frag<BN>(tb, wn * (16 * NJ) + 16 * i, ks, lane) : ST::kc_frag(tb, wn * (16 * NJ) + 16 * i, ks, lane);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (AKS || BKS) {
-            issue(kb + NST - 1);              // refills the buffer every wave finished reading last iteration
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // swapped operands: accumulator reg r <-> 4 consecutive n, lane&15 <-> m  (row-contiguous C stores)
-#pragma unroll
-        for (int ks = 0; ks < ST::KSTEPS; ++ks)
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) acc[i][j] = MM::mma(fb[ks][j], fa[ks][i], acc[i][j]);
-    }
-    }
-    // no DMA may still be in flight, and every wave must be done reading the ring, before LDS is reused
-    if constexpr (!SK) stamp(g, 3);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    if constexpr (SK) {
-        // In-launch hand-off of partial sums (cdna_hip_programming.md, Guideline 16 R1): the payload is stored write-through
-        // (sc1, 16 B per lane), every storing wave drains its stores, the workgroup meets, ONE lane stores the flag (agent scope);
-        // the finishing workgroup polls that one word relaxed, makes ONE agent-scope acquire, waits for it, meets, then reads the
-        // slab with plain loads.  Results do not depend on dispatch order or XCD placement; a finisher only ever waits for
-        // workers with a LOWER block index, which process their contributed segment first (see gemm_sk_kernel).
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        typedef __attribute__((address_space(1))) unsigned gu32;
-        char* const slabs = g.sk_ws + SK_FLAG_BYTES;
-        const int lane_off = ((w * (MI * NJ)) * 64 + lane) * 16;
-        if (mode == SEG_PARTIAL) {
-            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slabs + (long long)worker * SK_SLAB_BYTES, 0, SK_SLAB_BYTES, 0x00020000);
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs, lane_off + (i * NJ + j) * 1024, 0, 16);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // EVERY storing wave drains ...
-            __syncthreads();                                            // ... before the one lane that signals for all of them
-            if (t == 0) __hip_atomic_store((gu32*)(g.sk_ws + (long long)worker * SK_FLAG_STRIDE), g.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
-        }
-        if (mode == SEG_FINISH) {
-            if (t == 0) {
-                for (int c = c_first; c < worker; c += SK_XCDS) {
-                    unsigned spins = 0;                                 // bounded (~2 s): a lost contributor must not hang the GPU; the
-                    while (__hip_atomic_load((gu32*)(g.sk_ws + (long long)c * SK_FLAG_STRIDE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != g.sk_epoch) {
-                        __builtin_amdgcn_s_sleep(4);                    // give-up word (last flag slot) tells the host the result is invalid
-                        if (++spins > (1u << 24)) {
-                            __hip_atomic_store((gu32*)(g.sk_ws + SK_FLAG_BYTES - SK_FLAG_STRIDE), g.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            break;
-                        }
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // ONE acquire after the last poll has matched
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (holds the barrier below until the invalidate has completed)
+                for (int i = 0; i < NJ; ++i)
+                    fb[ks][i] = BKS ? ST::ks_frag(tb, wn * (16 * NJ) + 16 * i, ks, lane) : ST::kc_frag(tb, wn * (16 * NJ) + 16 * i, ks, lane);
             }
-            __syncthreads();
-            for (int c = c_first; c < worker; c += SK_XCDS) {
-                const f32x4* sl = reinterpret_cast<const f32x4*>(slabs + (long long)c * SK_SLAB_BYTES + lane_off);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (AKS || BKS) {
+                issue(kb + NST - 1);              // refills the buffer every wave finished reading last iteration
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // swapped operands: accumulator reg r <-> 4 consecutive n, lane&15 <-> m  (row-contiguous C stores)
+#pragma unroll
+            for (int ks = 0; ks < ST::KSTEPS; ++ks)
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) acc[i][j] += sl[(i * NJ + j) * 64];
-            }
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = MM::mma(fb[ks][j], fa[ks][i], acc[i][j]);
         }
     }
-    if constexpr (NJ == 8) {
-        // 256-column tiles (the weight-gradient kernel): f32 output only, stored or atomically added; a wave owns 16 MI rows x 128
-        // columns and sends them through a 16 x 128 f32 slab, one row fragment at a time, so that every atomic wave-instruction is
-        // 256 contiguous bytes of one row.
-        float* cw = reinterpret_cast<float*>(lds) + w * (16 * 128);
-        const int g4 = lane >> 4, li = lane & 15;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            if (i) __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                f32x4 v = acc[i][j];
-                v *= g.alpha;
-                *reinterpret_cast<f32x4*>(cw + li * 128 + (((4 * j + g4) ^ (li & 7)) << 2)) = v;
-            }
-            __builtin_amdgcn_wave_barrier();
-            for (int rr = 0; rr < 16; ++rr) {
-                const int m = m0 + wm * (16 * MI) + 16 * i + rr;
-                if (m >= g.M) break;
-                float* crow = reinterpret_cast<float*>(g.C) + remap_off(m, g.c_rpb, g.c_bs, g.ldc);
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int cl = 64 * h + lane, n = n0 + wn * 128 + cl;
-                    const float v = cw[rr * 128 + (((cl >> 2) ^ (rr & 7)) << 2) + (cl & 3)];
-                    if (n < g.N) {
-                        if (g.atomic) atomicAdd(crow + n, v);
-                        else crow[n] = v;
-                    }
-                }
-            }
-        }
-    } else {
-    gemm_epilogue<T, MI, NWM, NP, NJ>(g, acc, lds, w, m0, n0, lane, zpre, use_zpre, bpre, use_bpre);
-    }
-    if constexpr (!SK) {
-        __syncthreads();
-        stamp(g, 4);
-    }
+    // no DMA may still be in flight, and every wave must be done reading the ring, before LDS is reused
+    stamp(g, 3);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    gemm_epilogue<T, MI, NWM, NP>(g, acc, lds, w, m0, n0, lane, zpre, use_zpre, bpre, use_bpre);
+#ifdef A8_STAMPS
+    __syncthreads();
+    stamp(g, 4);
+#endif
 }
 
-template <typename T, bool AKS, bool BKS, int KB, int NST, int NWM, int MIP = 0, int NJ = 4, bool A3 = false>
+template <typename T, bool AKS, bool BKS, int KB, int NST, int NWM, bool A3 = false>
 A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
     const int split = bid / (g.tiles_m * g.tiles_n);
     const int kbeg = split * g.kchunk;
-    gemm_core<T, AKS, BKS, KB, NST, NWM, MIP, NJ, A3, false>(g, bid - split * (g.tiles_m * g.tiles_n), kbeg, min(g.K, kbeg + g.kchunk), SEG_FULL, 0, 0);
-}
-
-// ---- stream-K (bf16 NT, 128 x 128 tiles): the launch's k-tile iterations (tiles x k-tiles, tile-major) are cut into gridDim.x equal
-// contiguous ranges, one per workgroup, so every co-resident slot of the chip gets the same amount of main-loop work whatever the
-// tile count (294 tiles of M = 6248, N = 768 otherwise leave 218 of 512 slots empty while 38 CUs run two tiles).  A range covers
-// the tail of one tile, whole tiles, and the head of another; it is processed BACKWARDS -- the head (whose partial sums another
-// workgroup is going to need) first, the tail (which needs other workgroups' partial sums) last -- so a finisher finds its
-// contributors' slabs already published.
-template <typename T>
-__global__ __launch_bounds__(512, 4) void gemm_sk_kernel(const GemmArgs g) {
-    constexpr int BK = 64;
-    // The tiles are first dealt to the 8 block classes b % 8 in contiguous, tile-aligned chunks (what xcd_remap does for the
-    // default kernel: the blocks of one XCD work on neighbouring tiles and share their operand panels in that XCD's L2); the
-    // k-tile iterations of a chunk are then cut into equal ranges for the class's workers j = b / 8.  A finisher waits for workers
-    // j' < j of its own class only: blocks b - 8, b - 16 ..., which were dispatched before it.
-    const unsigned x = blockIdx.x % SK_XCDS, j = blockIdx.x / SK_XCDS, WX = gridDim.x / SK_XCDS;
-    const unsigned ntile = g.tiles_m * g.tiles_n, q = ntile / SK_XCDS, r = ntile % SK_XCDS;
-    const unsigned t0 = x * q + (x < r ? x : r), nt = q + (x < r ? 1u : 0u);
-    const unsigned KT = (g.K + BK - 1) / BK;
-    const unsigned U = nt * KT;                                         // < 2^21 (host check): j * U fits 32 bits
-    const unsigned u0 = j * U / WX, u1 = (j + 1) * U / WX;
-    unsigned u = u1;
-    while (u > u0) {
-        const unsigned tl = (u - 1) / KT;                               // tile within the chunk
-        const unsigned tbase = tl * KT;
-        const unsigned lo = u0 > tbase ? u0 : tbase;
-        const int ka = (int)(lo - tbase), kb = (int)(u - tbase);
-        const int mode = (ka == 0 && kb == (int)KT) ? SEG_FULL : (kb == (int)KT ? SEG_FINISH : SEG_PARTIAL);
-        const unsigned tile = t0 + tl;
-        int c_first = (int)blockIdx.x;
-        if (mode == SEG_FINISH) {                      // the worker of this class whose range holds the tile's first iteration
-            unsigned e = tbase * WX / U;
-            while ((e + 1) * U / WX <= tbase) ++e;
-            while (e * U / WX > tbase) --e;
-            c_first = (int)(x + SK_XCDS * e);
-        }
-        gemm_core<T, false, false, 2, 2, 4, 0, 4, false, true>(g, (int)tile, ka * BK, min(g.K, kb * BK), mode, (int)blockIdx.x, c_first);
-        u = lo;
-    }
-}
-
-// ---- tall tiles for the products that would put between one and two 128 x 128 tiles on a CU (M = 6248, N = 768: 294 tiles on
-// 256 CUs -- the launch lasts as long as the 38 CUs that got two): 192 x 128 (198 tiles) or 256 x 128 with the same 8 waves
-// (4 x 2, each 48 / 64 rows x 64 columns: 0.58 / 0.5 KB of fragment reads and 0.21 / 0.19 LDS-DMA instructions per MFMA instead of
-// 0.75 / 0.25), ONE block per CU, 3-deep ring (two k-tiles in flight: a lone block has no co-resident block to hide a DMA behind).
-template <typename T, int MIP>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tall_kernel(const GemmArgs g) {
-    gemm_body<T, false, false, 2, 3, 4, MIP>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n * g.nsplit));
+    gemm_core<T, AKS, BKS, KB, NST, NWM, A3>(g, bid - split * (g.tiles_m * g.tiles_n), kbeg, min(g.K, kbeg + g.kchunk));
 }
 
 // ---- the default 128 x 128 NT tile with the asymmetric ring (A three deep, B two deep: gemm_body, A3)
 template <typename T>
 __global__ __launch_bounds__(512, 4) void gemm_a3_kernel(const GemmArgs g) {
-    gemm_body<T, false, false, 2, 2, 4, 0, 4, true>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n * g.nsplit));
-}
-
-// ---- 192 x 128 tiles, ONE block per CU, k-tiles of 128 (256-byte rows): a lone block pays one LDS-DMA round trip per k-tile whatever
-// the k-tile holds, so a twice deeper k-tile halves the round trips per FLOP; 2 x 80 KB ring = all of the LDS.
-template <typename T>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tall_k128_kernel(const GemmArgs g) {
-    gemm_body<T, false, false, 4, 2, 4, 3>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n * g.nsplit));
-}
-
-// ---- tall tiles, ONE block per CU, register-pipelined main loop (gemm_core, PIPE): 192 x 128 with a 3-deep ring
-template <typename T, int MIP>
-__global__ __launch_bounds__(512, 2) void gemm_lone_kernel(const GemmArgs g) {
-    gemm_core<T, false, false, 2, 3, 4, MIP, 4, false, false, true>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n), 0, g.K, SEG_FULL, 0, 0);
-}
-
-// ---- 256 x 256 tiles for the weight gradients (TN, bf16 operands, f32 output): dW = dY^T X has a small output and a huge reduction,
-// so its time is the operand bytes staged into LDS -- (rows + columns) / (rows x columns) per FLOP: half of the 128 x 128 tile's.
-// 8 waves of 64 x 128, K-strided [k][512 B] stage images read through ds_read_b64_tr_b16, 2 x 64 KB ring, one block per CU;
-// split-K sized by the host to about one block per CU.
-template <typename T>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tn256_kernel(const GemmArgs g) {
-    const int bid = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n * g.nsplit);
-    const int split = bid / (g.tiles_m * g.tiles_n);
-    const int kbeg = split * g.kchunk;
-    gemm_core<T, true, true, 2, 2, 4, 4, 8>(g, bid - split * (g.tiles_m * g.tiles_n), kbeg, min(g.K, kbeg + g.kchunk), SEG_FULL, 0, 0);
-}
-// ---- 96-column tiles (8 waves of 32 x 48) for the products whose 128 x 128 tiling leaves the chip between one and two tiles per CU:
-// M = 6248, N = 768 gives 294 tiles on 256 CUs, and the launch lasts as long as the 38 CUs that hold two; 49 x 8 = 392 tiles of
-// 128 x 96 put two co-resident blocks on more than half of the CUs and each finishes a quarter sooner.  Same ring, same k order
-// (bit-identical results); the B stage is 12 KB, so 4 of the 8 waves issue one DMA piece less per k-tile.
-template <typename T>
-__global__ __launch_bounds__(512, 2) void gemm_n96_kernel(const GemmArgs g) {
-    gemm_body<T, false, false, 2, 2, 4, 0, 3>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n * g.nsplit));
+    gemm_body<T, false, false, 2, 2, 4, true>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n * g.nsplit));
 }
 
 // ---- pipelined 256 x 256 main loop for large NT problems with N % 256 == 0 and K % 64 == 0 (the conv layers: N = 512):
@@ -929,141 +702,8 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs g) {
     }
 }
 
-// ---- full-width tile for the conv layers (NT, N a multiple of 512, K a multiple of 64): one block computes 128 rows x ALL 512 columns,
-// so every A row (the 0.4 GB conv activations) is fetched from HBM exactly once -- with 128-column tiles the four blocks that share a
-// row panel drift apart in K and the panel is re-fetched (2.3x measured on conv layer 1); the 1.5 MB weight matrix streams from L2.
-// 8 waves of 64 x 128 (0.375 KB of fragment reads and 0.16 LDS-DMA instructions per MFMA), one PERSISTENT block per CU walking its row
-// panels; k-tiles of 64 (128-byte LDS rows: whole cache lines per DMA row) through a 2-deep ring (2 x 80 KB: all of the LDS) that keeps
-// running ACROSS tiles: the DMAs of the next tile's first k-tile are in flight while this tile's accumulators go through the
-// epilogue (straight from registers, no LDS).  Walks K in the order of the default kernel (bit-identical results).
-template <typename T>
-__global__ __launch_bounds__(512, 2) void gemm_w512_kernel(const GemmArgs g) {
-    static_assert(sizeof(T) == 2, "16-bit operands");
-    typedef Mma<T> MM;
-    constexpr int KROW = 128, TA = 128 * KROW, TB = 512 * KROW, STAGE = TA + TB, SZ = 2;
-    __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
-    const int t = threadIdx.x, lane = t & 63;
-    const int w = __builtin_amdgcn_readfirstlane(t >> 6), wr = w >> 2, wc = w & 3;
-    const int nk = g.K / 64, ntiles = g.tiles_m * g.tiles_n;
-
-    // LDS-DMA sources: a piece = 8 rows x 128 B; lane -> row lane >> 3, 16-byte slot lane & 7 holding k-chunk slot ^ (row & 7)
-    const int prow = lane >> 3, pch = ((lane & 7) ^ prow) << 4;          // (piece rows start at multiples of 8: row & 7 = lane >> 3)
-    unsigned a_off[2] = {0, 0}, b_off[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    auto tile_offsets = [&](int tile) {
-        const int m0 = (tile / g.tiles_n) * 128, n0 = (tile % g.tiles_n) * 512;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) a_off[j] = (unsigned)(outer_off(g.A, min(m0 + 8 * (w + 8 * j) + prow, g.M - 1)) * SZ + pch);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) b_off[j] = (unsigned)((long long)(n0 + 8 * (w + 8 * j) + prow) * g.B.ld * SZ + pch);
-    };
-    // producer cursor: (ptile, pk) = the k-tile the next issue() stages; it runs one k-tile ahead of the consumer, across tiles
-    int ptile = blockIdx.x, pk = 0, pslot = 0;
-    if (ptile < ntiles) tile_offsets(ptile);
-    auto issue = [&]() {
-        if (ptile >= ntiles) return;
-        char* ta = lds + pslot * STAGE;
-        char* tb = ta + TA;
-        const unsigned ko = (unsigned)pk * KROW;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) glds16(g.A.p + (a_off[j] + ko), ta + (w + 8 * j) * 1024);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) glds16(g.B.p + (b_off[j] + ko), tb + (w + 8 * j) * 1024);
-        pslot ^= 1;
-        if (++pk == nk) {
-            pk = 0;
-            ptile += gridDim.x;
-            if (ptile < ntiles) tile_offsets(ptile);
-        }
-    };
-    auto frag = [&](const char* tl, int rb, int ks) {      // 16 rows x 32 k: lane & 15 = row, lane >> 4 = 16-byte chunk of the k-step
-        const int row = rb + (lane & 15);
-        return *reinterpret_cast<const typename MM::Frag*>(tl + row * KROW + (((ks * 4 + (lane >> 4)) ^ (row & 7)) << 4));
-    };
-    typedef T T4 __attribute__((ext_vector_type(4)));
-    auto zrow = [&](int m) -> long long { return remap_off(m, g.z_rpb, g.z_bs, g.ldz); };
-
-    issue();
-    int cslot = 0;
-    int stores_pending = 0;                                // the previous tile's epilogue stores (1: 32 of them, 2: 64) are younger than the DMAs waited for
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int m0 = (tile / g.tiles_n) * 128, n0 = (tile % g.tiles_n) * 512;
-        f32x4 acc[4][8];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int kt = 0; kt < nk; ++kt) {
-            // this k-tile's 10 DMAs are the oldest outstanding operations; right after an epilogue its stores (exactly 32, or 64 with zout,
-            // when no row was skipped) are younger and need not be waited for.  vmcnt counts DMAs and stores together, in issue order;
-            // its range ends at 63, where "all but 63" of 74 still covers the 10 DMAs.
-            if (kt == 0 && stores_pending == 2) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
-            else if (kt == 0 && stores_pending == 1) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            issue();                                       // refills the slot every wave finished reading in the previous k-tile
-            const char* ta = lds + cslot * STAGE;
-            const char* tb = ta + TA;
-            cslot ^= 1;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                typename MM::Frag fa[4], fb[8];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) fa[i] = frag(ta, 64 * wr + 16 * i, ks);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) fb[j] = frag(tb, 128 * wc + 16 * j, ks);
-                // swapped operands: accumulator register r <-> 4 consecutive n, lane & 15 <-> m
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[i][j] = MM::mma(fb[j], fa[i], acc[i][j]);
-            }
-        }
-        // ---- epilogue straight from the accumulators: register r of acc[i][j] is column 16 j + 4 (lane >> 4) + r of row 16 i + (lane & 15)
-        const int li = lane & 15, c4 = 4 * (lane >> 4);
-        const bool full = m0 + 64 * wr + 64 <= g.M;        // wave-uniform: every store below executes
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + 64 * wr + 16 * i + li;
-            if (m >= g.M) continue;
-            const long long crow = remap_off(m, g.c_rpb, g.c_bs, g.ldc);
-            const long long zr = (g.zout || g.zin) ? zrow(m) : 0;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int n = n0 + 128 * wc + 16 * j + c4;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * g.alpha;
-                if (g.zout) {
-                    T4 zv;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) zv[e] = from_f<T>(v[e]);
-                    *reinterpret_cast<T4*>(reinterpret_cast<T*>(g.zout) + zr + n) = zv;
-                }
-                if (g.act == A8_ACT_GELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
-                } else if (g.act == A8_ACT_MUL_GELU_GRAD) {
-                    const T4 zz = *reinterpret_cast<const T4*>(reinterpret_cast<const T*>(g.zin) + zr + n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(to_f(zz[e]));
-                } else if (g.act == A8_ACT_ADD) {
-                    const T4 zz = *reinterpret_cast<const T4*>(reinterpret_cast<const T*>(g.zin) + zr + n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += to_f(zz[e]);
-                }
-                T4 ov;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) ov[e] = from_f<T>(v[e]);
-                *reinterpret_cast<T4*>(reinterpret_cast<T*>(g.C) + crow + n) = ov;
-            }
-        }
-        // tail waves (rows skipped: fewer stores) and epilogues that load zin (the compiler drains for the loaded values) wait for everything
-        stores_pending = (full && !g.zin) ? (g.zout ? 2 : 1) : 0;
-    }
-}
-
 template <typename T, bool AKS, bool BKS, int KB, int NST, int NWM>
-__global__ __launch_bounds__(128 * NWM, NWM == 5 ? 3 : (KB == 1 && NST == 2) ? 4 : (NST * 2 * 8192 * KB <= 65536) ? NWM : NWM / 2) void gemm_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(128 * NWM, (NST * 2 * 8192 * KB <= 65536) ? NWM : NWM / 2) void gemm_kernel(const GemmArgs g) {
     gemm_body<T, AKS, BKS, KB, NST, NWM>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n * g.nsplit));
 }
 
@@ -1079,19 +719,6 @@ __global__ __launch_bounds__(128 * NWM, (NST * 2 * 8192 * KB <= 65536) ? NWM : N
     gemm_body<T, AKS, BKS, KB, NST, NWM>(g, bid - grp.start[i]);
 }
 
-// the grouped launch with the 256 x 256 weight-gradient tiles of gemm_tn256_kernel
-template <typename T>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_grouped_tn256_kernel(const GemmGroup grp) {
-    const int bid = xcd_remap(blockIdx.x, grp.start[grp.n]);
-    int i = 0;
-    while (i + 1 < grp.n && bid >= grp.start[i + 1]) ++i;
-    const GemmArgs g = grp.g[i];
-    const int lb = bid - grp.start[i];
-    const int split = lb / (g.tiles_m * g.tiles_n);
-    const int kbeg = split * g.kchunk;
-    gemm_core<T, true, true, 2, 2, 4, 4, 8>(g, lb - split * (g.tiles_m * g.tiles_n), kbeg, min(g.K, kbeg + g.kchunk), SEG_FULL, 0, 0);
-}
-
 // the grouped launch with the asymmetric ring of gemm_a3_kernel (bf16 NT; the conv data-gradient halves)
 template <typename T>
 __global__ __launch_bounds__(512, 4) void gemm_grouped_a3_kernel(const GemmGroup grp) {
@@ -1099,51 +726,43 @@ __global__ __launch_bounds__(512, 4) void gemm_grouped_a3_kernel(const GemmGroup
     int i = 0;
     while (i + 1 < grp.n && bid >= grp.start[i + 1]) ++i;
     const GemmArgs g = grp.g[i];
-    gemm_body<T, false, false, 2, 2, 4, 0, 4, true>(g, bid - grp.start[i]);
+    gemm_body<T, false, false, 2, 2, 4, true>(g, bid - grp.start[i]);
 }
 
-#define g_variant g_a8_tuning[0]
-                        // tuning knob (a8_set_tuning key 0): 5 = 128 B of K per row, 2-deep ring, 8 waves (default: measured best);
-                        // 2 = same with 4 waves; 1 = 64 B rows, 4-deep ring, 4 waves
+// bf16: 128 B of K per row, 2-deep ring, 8 waves (4 waves/SIMD at 2 blocks/CU);  f32: 64-byte rows, 4-deep ring, 4 waves
+template <typename T> struct Cfg;
+template <> struct Cfg<bf16> { static constexpr int KB = 2, NST = 2, NWM = 4; };
+template <> struct Cfg<float> { static constexpr int KB = 1, NST = 4, NWM = 2; };
 
-template <typename T, int KB, int NST, int NWM> int launch2(const a8_gemm_desc* d, const GemmArgs& g, int grid, hipStream_t s) {
-    const dim3 blk(128 * NWM);
+template <typename T> int launch(const a8_gemm_desc* d, const GemmArgs& g, int grid, hipStream_t s) {
+    typedef Cfg<T> C;
+    const dim3 blk(128 * C::NWM);
     switch (d->layout) {
-        case A8_GEMM_NT: hipLaunchKernelGGL((gemm_kernel<T, false, false, KB, NST, NWM>), dim3(grid), blk, 0, s, g); break;
-        case A8_GEMM_NN: hipLaunchKernelGGL((gemm_kernel<T, false, true, KB, NST, NWM>), dim3(grid), blk, 0, s, g); break;
-        case A8_GEMM_TN: hipLaunchKernelGGL((gemm_kernel<T, true, true, KB, NST, NWM>), dim3(grid), blk, 0, s, g); break;
+        case A8_GEMM_NT: hipLaunchKernelGGL((gemm_kernel<T, false, false, C::KB, C::NST, C::NWM>), dim3(grid), blk, 0, s, g); break;
+        case A8_GEMM_NN: hipLaunchKernelGGL((gemm_kernel<T, false, true, C::KB, C::NST, C::NWM>), dim3(grid), blk, 0, s, g); break;
+        case A8_GEMM_TN: hipLaunchKernelGGL((gemm_kernel<T, true, true, C::KB, C::NST, C::NWM>), dim3(grid), blk, 0, s, g); break;
         default: return a8_set_error(A8_ERR_ARG, "a8_gemm: bad layout %d", d->layout);
     }
     return a8_check_launch("a8_gemm");
 }
-template <typename T, int KB, int NST, int NWM> int launch2g(int layout, const GemmGroup& g, int grid, hipStream_t s) {
-    const dim3 blk(128 * NWM);
+template <typename T> int launch_grouped(int layout, const GemmGroup& g, int grid, hipStream_t s) {
+    typedef Cfg<T> C;
+    const dim3 blk(128 * C::NWM);
     switch (layout) {
-        case A8_GEMM_NT: hipLaunchKernelGGL((gemm_grouped_kernel<T, false, false, KB, NST, NWM>), dim3(grid), blk, 0, s, g); break;
-        case A8_GEMM_NN: hipLaunchKernelGGL((gemm_grouped_kernel<T, false, true, KB, NST, NWM>), dim3(grid), blk, 0, s, g); break;
-        case A8_GEMM_TN: hipLaunchKernelGGL((gemm_grouped_kernel<T, true, true, KB, NST, NWM>), dim3(grid), blk, 0, s, g); break;
+        case A8_GEMM_NT: hipLaunchKernelGGL((gemm_grouped_kernel<T, false, false, C::KB, C::NST, C::NWM>), dim3(grid), blk, 0, s, g); break;
+        case A8_GEMM_NN: hipLaunchKernelGGL((gemm_grouped_kernel<T, false, true, C::KB, C::NST, C::NWM>), dim3(grid), blk, 0, s, g); break;
+        case A8_GEMM_TN: hipLaunchKernelGGL((gemm_grouped_kernel<T, true, true, C::KB, C::NST, C::NWM>), dim3(grid), blk, 0, s, g); break;
         default: return a8_set_error(A8_ERR_ARG, "a8_gemm_grouped: bad layout %d", layout);
     }
     return a8_check_launch("a8_gemm_grouped");
 }
-template <typename T> int launch(const a8_gemm_desc* d, const GemmArgs& g, int grid, hipStream_t s) {
-    if constexpr (sizeof(T) == 2) {
-        switch (g_variant) {
-            case 1: return launch2<T, 1, 4, 2>(d, g, grid, s);
-            case 5: return launch2<T, 2, 2, 4>(d, g, grid, s);      // 8 waves per block (4 waves/SIMD at 2 blocks/CU)
-            case 6: return launch2<T, 1, 4, 4>(d, g, grid, s);      // 8 waves, 64-byte rows, 4-deep ring
-            case 7: return launch2<T, 1, 2, 2>(d, g, grid, s);      // 4 waves of 64x64, 64-byte rows, 2-deep ring: 32 KB of LDS, 4 blocks/CU
-            default: return launch2<T, 2, 2, 2>(d, g, grid, s);
-        }
-    } else {
-        return launch2<T, 1, 4, 2>(d, g, grid, s);
-    }
-}
 
 }  // namespace
 
+#ifdef A8_STAMPS
 static unsigned long long* g_stamps = nullptr;
 extern "C" int a8_debug_set_stamps(void* p) { g_stamps = (unsigned long long*)p; return A8_OK; }
+#endif
 
 // validates one descriptor and fills the kernel arguments; *grid = blocks it needs
 static int build_args(const a8_gemm_desc* d, GemmArgs& g, long long* grid) {
@@ -1160,7 +779,7 @@ static int build_args(const a8_gemm_desc* d, GemmArgs& g, long long* grid) {
     A8_REQUIRE(d->lda % epc == 0 && d->ldb % epc == 0 && d->ldc % 4 == 0, "a8_gemm: leading dimensions must keep 16-byte alignment");
     A8_REQUIRE(((uintptr_t)d->A % 16) == 0 && ((uintptr_t)d->B % 16) == 0 && ((uintptr_t)d->C % 16) == 0, "a8_gemm: pointers must be 16-byte aligned");
     A8_REQUIRE(d->a_bs % epc == 0 && d->b_bs % epc == 0, "a8_gemm: batch strides must keep 16-byte alignment");
-    const int bk = d->dtype == A8_BF16 ? ((g_variant == 1 || g_variant == 6 || g_variant == 7) ? 32 : 64) : 16;
+    const int bk = d->dtype == A8_BF16 ? 64 : 16;
     A8_REQUIRE(d->a_rpb >= 0 && d->b_rpb >= 0 && d->c_rpb >= 0 && d->z_rpb >= 0 && d->a_rpb < (1ll << 31) && d->b_rpb < (1ll << 31) &&
                d->c_rpb < (1ll << 31) && d->z_rpb < (1ll << 31), "a8_gemm: rows-per-batch remaps must fit 31 bits");
     g.A = Op{(const char*)d->A, d->lda, d->a_rpb, d->a_bs};
@@ -1176,10 +795,10 @@ static int build_args(const a8_gemm_desc* d, GemmArgs& g, long long* grid) {
     nsplit = d->K > 0 ? cdiv(d->K, kchunk) : 1;
     g.kchunk = kchunk; g.nsplit = nsplit;
     g.act = d->act; g.out_f32 = d->out_f32; g.alpha = d->alpha;
-    g.group_m = g_a8_tuning[12] > 0 ? g_a8_tuning[12] : 8;           // m-tiles per tile-order group (developer knob 12; 8 measured best)
-    g.sk_ws = (char*)d->sk_ws; g.sk_epoch = d->sk_epoch;
+    g.group_m = 8;                                                   // m-tiles per tile-order group (1..16 measured: 8)
+#ifdef A8_STAMPS
     g.stamps = g_stamps;
-    g.zpre = g_a8_tuning[15] == 0;                                   // developer knob 15: 1 = load zin in the epilogue (the round-1 form)
+#endif
     g.atomic = (nsplit > 1 || d->accumulate) ? 1 : 0;
     A8_REQUIRE(!(g.atomic && !d->out_f32), "a8_gemm: split-K / accumulate needs an f32 output");
     A8_REQUIRE(!(nsplit > 1 && (d->bias || d->act || d->zout || d->colsum)), "a8_gemm: split-K cannot carry a bias/activation/colsum epilogue");
@@ -1189,18 +808,17 @@ static int build_args(const a8_gemm_desc* d, GemmArgs& g, long long* grid) {
     return A8_OK;
 }
 
-// 256 x 256 weight-gradient tiles (a8_set_tuning key 18): eligibility, and the re-tiling of an argument block built for 128 x 128
-static bool tn256_eligible(const a8_gemm_desc* d, const GemmArgs& g) {
-    return d->dtype == A8_BF16 && d->layout == A8_GEMM_TN && g_variant == 5 && g_a8_tuning[18] > 0 && g.out_f32 && !d->bias && !d->act && !d->zout &&
-           !d->colsum && d->M >= 256 && d->N >= 256 && d->K >= 512;
-}
-static long long tn256_retile(const a8_gemm_desc* d, GemmArgs& g, int want_split) {
-    g.tiles_m = cdiv(d->M, 256); g.tiles_n = cdiv(d->N, 256);
-    int nsplit = g.atomic ? (want_split > 0 ? want_split : 1) : 1;
-    int kchunk = cdiv(cdiv(d->K, nsplit), 64) * 64;
-    nsplit = cdiv(d->K, kchunk);
-    g.kchunk = kchunk; g.nsplit = nsplit;
-    return (long long)g.tiles_m * g.tiles_n * nsplit;
+// the pipelined 256 x 256 kernel takes large bf16 NT problems with N % 256 == 0 and K % 64 == 0, 16-bit output, no bias / column sums
+// (a8_set_tuning key 5 = minimum number of 256 x 256 tiles; 0 = never)
+static bool p256_eligible(const a8_gemm_desc* d, const GemmArgs& g) {
+    if (!(d->dtype == A8_BF16 && d->layout == A8_GEMM_NT && g_a8_tuning[5] > 0 && d->N % 256 == 0 && d->K % 64 == 0 && d->K >= 64 &&
+          !d->out_f32 && !d->bias && !d->colsum && g.nsplit == 1 && !g.atomic && d->ldc % 4 == 0 && d->ldz % 4 == 0 && ((uintptr_t)d->C % 8) == 0))
+        return false;
+    // 32-bit byte offsets into A and B
+    const long long a_span = ((d->a_rpb ? (long long)((d->M - 1) / d->a_rpb) * d->a_bs + (long long)((d->M - 1) % d->a_rpb) * d->lda
+                                        : (long long)(d->M - 1) * d->lda) + d->K) * 2;
+    const long long b_span = ((long long)(d->N - 1) * d->ldb + d->K) * 2;
+    return (long long)cdiv(d->M, 256) * (d->N / 256) >= g_a8_tuning[5] && a_span < (1ll << 32) && b_span < (1ll << 32);
 }
 
 extern "C" int a8_gemm(const a8_gemm_desc* d, void* stream) {
@@ -1209,108 +827,15 @@ extern "C" int a8_gemm(const a8_gemm_desc* d, void* stream) {
     if (int e = build_args(d, g, &grid)) return e;
     if (d->M == 0) return A8_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (tn256_eligible(d, g)) {
-        const int t256 = cdiv(d->M, 256) * cdiv(d->N, 256);
-        const long long g256 = tn256_retile(d, g, 256 / t256 > 0 ? 256 / t256 : 1);      // about one block per CU
-        hipLaunchKernelGGL(gemm_tn256_kernel<bf16>, dim3((int)g256), dim3(512), 0, s, g);
+    if (p256_eligible(d, g)) {
+        g.tiles_m = cdiv(d->M, 256); g.tiles_n = d->N / 256;
+        hipLaunchKernelGGL(gemm_p256_kernel<bf16>, dim3(g.tiles_m * g.tiles_n), dim3(512), 0, s, g);
         return a8_check_launch("a8_gemm");
-    }
-    // large NT problems whose N is a multiple of 256 (the conv layers): the pipelined 256 x 256 kernel
-    // (a8_set_tuning key 5 = minimum number of 256 x 256 tiles; 0 = off)
-    if (d->dtype == A8_BF16 && d->layout == A8_GEMM_NT && g_a8_tuning[5] > 0 && g_variant == 5 && d->N % 256 == 0 && d->K % 64 == 0 &&
-        d->K >= 64 && !d->out_f32 && !d->bias && !d->colsum && g.nsplit == 1 && !g.atomic && d->ldc % 4 == 0 && (d->ldz % 4 == 0) &&
-        ((uintptr_t)d->C % 8) == 0) {
-        const int tm = cdiv(d->M, 256), tn = d->N / 256;
-        // 32-bit byte offsets into A and B
-        const long long a_span = ((d->a_rpb ? (long long)((d->M - 1) / d->a_rpb) * d->a_bs + (long long)((d->M - 1) % d->a_rpb) * d->lda
-                                            : (long long)(d->M - 1) * d->lda) + d->K) * 2;
-        const long long b_span = ((long long)(d->N - 1) * d->ldb + d->K) * 2;
-        if ((long long)tm * tn >= g_a8_tuning[5] && a_span < (1ll << 32) && b_span < (1ll << 32)) {
-            g.tiles_m = tm; g.tiles_n = tn;
-            hipLaunchKernelGGL(gemm_p256_kernel<bf16>, dim3(tm * tn), dim3(512), 0, s, g);
-            return a8_check_launch("a8_gemm");
-        }
-    }
-    // Full-width persistent tiles for the conv GEMMs (a8_set_tuning key 11 = minimum M; 0 = off)
-    if (d->dtype == A8_BF16 && d->layout == A8_GEMM_NT && g_variant == 5 && g_a8_tuning[11] > 0 && d->M >= g_a8_tuning[11] && d->N % 512 == 0 &&
-        d->K % 64 == 0 && d->K >= 64 && !d->out_f32 && !d->bias && !d->colsum && g.nsplit == 1 && !g.atomic && d->ldc % 4 == 0 && d->ldz % 4 == 0 &&
-        ((uintptr_t)d->C % 8) == 0 && ((uintptr_t)d->zout % 8) == 0 && ((uintptr_t)d->zin % 8) == 0) {
-        const long long a_span = ((d->a_rpb ? (long long)((d->M - 1) / d->a_rpb) * d->a_bs + (long long)((d->M - 1) % d->a_rpb) * d->lda
-                                            : (long long)(d->M - 1) * d->lda) + d->K) * 2;
-        const long long b_span = ((long long)(d->N - 1) * d->ldb + d->K) * 2;
-        if (a_span < (1ll << 32) && b_span < (1ll << 32)) {
-            g.tiles_m = cdiv(d->M, 128); g.tiles_n = d->N / 512;
-            const int nt = g.tiles_m * g.tiles_n;
-            hipLaunchKernelGGL(gemm_w512_kernel<bf16>, dim3(nt < 256 ? nt : 256), dim3(512), 0, s, g);
-            return a8_check_launch("a8_gemm");
-        }
-    }
-    // Stream-K (a8_set_tuning key 16: 0 = never, 1 = below three rounds of the 512 slots unless the tiles fill them exactly, 2 = whenever eligible)
-    if (d->dtype == A8_BF16 && d->layout == A8_GEMM_NT && g_variant == 5 && g_a8_tuning[16] > 0 && d->sk_ws && g.nsplit == 1 && !g.atomic &&
-        d->K >= 64) {
-        A8_REQUIRE(d->sk_ws_bytes >= A8_GEMM_SK_WS_BYTES && ((uintptr_t)d->sk_ws % 256) == 0 && d->sk_epoch != 0,
-                   "a8_gemm: the stream-K workspace needs %d bytes, 256-byte alignment and a non-zero epoch", (int)A8_GEMM_SK_WS_BYTES);
-        const long long units = grid * (long long)cdiv(d->K, 64);
-        const bool awkward = grid < 3 * A8_GEMM_SK_WORKERS && grid % A8_GEMM_SK_WORKERS != 0;
-        if ((g_a8_tuning[16] == 2 || awkward) && units >= 2 * A8_GEMM_SK_WORKERS && units < (1ll << 21)) {
-            hipLaunchKernelGGL(gemm_sk_kernel<bf16>, dim3(A8_GEMM_SK_WORKERS), dim3(512), 0, s, g);
-            return a8_check_launch("a8_gemm");
-        }
     }
     // Asymmetric ring (a8_set_tuning key 14: 0 = never, otherwise the minimum M; 1 = every bf16 NT problem)
-    if (d->dtype == A8_BF16 && d->layout == A8_GEMM_NT && g_variant == 5 && g_a8_tuning[14] > 0 && d->M >= g_a8_tuning[14]) {
+    if (d->dtype == A8_BF16 && d->layout == A8_GEMM_NT && g_a8_tuning[14] > 0 && d->M >= g_a8_tuning[14]) {
         hipLaunchKernelGGL(gemm_a3_kernel<bf16>, dim3((int)grid), dim3(512), 0, s, g);
         return a8_check_launch("a8_gemm");
-    }
-    // 96-column tiles (a8_set_tuning key 13: 0 = never, 1 = when 128-column tiles would leave 257..512 blocks and 96 divides N, 2 = whenever 96 divides N)
-    if (d->dtype == A8_BF16 && d->layout == A8_GEMM_NT && g_variant == 5 && g_a8_tuning[13] > 0 && d->N % 96 == 0) {
-        const long long t96 = (long long)g.tiles_m * (d->N / 96) * g.nsplit;
-        if (g_a8_tuning[13] == 2 || (grid > 256 && grid <= 512 && t96 <= 512)) {
-            g.tiles_n = d->N / 96;
-            hipLaunchKernelGGL(gemm_n96_kernel<bf16>, dim3((int)t96), dim3(512), 0, s, g);
-            return a8_check_launch("a8_gemm");
-        }
-    }
-    // Tall tiles (a8_set_tuning key 8: 0 = never, 1 = by the tile-count rule below, 3 / 4 = always 192 / 256 rows).
-    if (d->dtype == A8_BF16 && d->layout == A8_GEMM_NT && g_variant == 5 && g_a8_tuning[8] > 0 && d->K % 64 == 0) {
-        const int mode = g_a8_tuning[8];
-        const long long t128 = grid, t192 = (long long)cdiv(d->M, 192) * g.tiles_n * g.nsplit, t256 = (long long)cdiv(d->M, 256) * g.tiles_n * g.nsplit;
-        int mi = 0;
-        if (mode == 3 || mode == 4) mi = mode;
-        else if (mode == 1 && t128 > 256 && t128 <= 512) mi = t192 <= 256 ? 3 : (t256 <= 256 ? 4 : 0);
-        // modes 7 / 8: 192-row tiles with 128-element k-tiles, by the same tile-count rule / always
-        if ((mode == 8 || (mode == 7 && t128 > 256 && t128 <= 512 && t192 <= 256)) && g.nsplit == 1) {
-            g.tiles_m = cdiv(d->M, 192);
-            hipLaunchKernelGGL(gemm_tall_k128_kernel<bf16>, dim3((int)t192), dim3(512), 0, s, g);
-            return a8_check_launch("a8_gemm");
-        }
-        // modes 5 / 6: the register-pipelined 192-row kernel, by the same tile-count rule / always
-        if ((mode == 6 || (mode == 5 && t128 > 256 && t128 <= 512 && t192 <= 256)) && g.nsplit == 1) {
-            g.tiles_m = cdiv(d->M, 192);
-            hipLaunchKernelGGL((gemm_lone_kernel<bf16, 3>), dim3((int)t192), dim3(512), 0, s, g);
-            return a8_check_launch("a8_gemm");
-        }
-        if (mi) {
-            g.tiles_m = cdiv(d->M, 64 * mi);
-            const int gr = (int)(mi == 3 ? t192 : t256);
-            if (mi == 3) hipLaunchKernelGGL((gemm_tall_kernel<bf16, 3>), dim3(gr), dim3(512), 0, s, g);
-            else hipLaunchKernelGGL((gemm_tall_kernel<bf16, 4>), dim3(gr), dim3(512), 0, s, g);
-            return a8_check_launch("a8_gemm");
-        }
-    }
-    // Experiment, off by default (a8_set_tuning key 7: 0 = off; 2 / 3 / 4 = ring depth): between one and two 128-row tiles
-    // per CU (M = 6248, N = 768: 294 tiles on 256 CUs) the launch lasts as long as the 38 CUs that got two.  160-row tiles
-    // (10 waves) give 240 blocks, at most one per CU -- and the same time at any ring depth: a lone block's k-tile costs its
-    // LDS-read phase plus its MFMA phase in series (~0.8 us), which two co-resident blocks overlap (tools/tile160.py).
-    if (d->dtype == A8_BF16 && d->layout == A8_GEMM_NT && g_variant == 5 && g_a8_tuning[7] > 0 && grid > 256 && grid <= 512) {
-        const long long g160 = (long long)cdiv(d->M, 160) * g.tiles_n * g.nsplit;
-        if (g160 <= 256) {
-            g.tiles_m = cdiv(d->M, 160);
-            if (g_a8_tuning[7] == 2) hipLaunchKernelGGL((gemm_kernel<bf16, false, false, 2, 2, 5>), dim3((int)g160), dim3(640), 0, s, g);
-            else if (g_a8_tuning[7] == 3) hipLaunchKernelGGL((gemm_kernel<bf16, false, false, 2, 3, 5>), dim3((int)g160), dim3(640), 0, s, g);
-            else hipLaunchKernelGGL((gemm_kernel<bf16, false, false, 2, 4, 5>), dim3((int)g160), dim3(640), 0, s, g);
-            return a8_check_launch("a8_gemm");
-        }
     }
     return d->dtype == A8_BF16 ? launch<bf16>(d, g, (int)grid, s) : launch<float>(d, g, (int)grid, s);
 }
@@ -1332,40 +857,14 @@ extern "C" int a8_gemm_grouped(const a8_gemm_desc* descs, int n, void* stream) {
     }
     if (grp.n == 0) return A8_OK;
     hipStream_t s = (hipStream_t)stream;
-    {
-        bool all256 = true;
-        int t256 = 0;
-        for (int i = 0, k = 0; i < n; ++i) {
-            if (descs[i].M == 0) continue;
-            all256 = all256 && tn256_eligible(&descs[i], grp.g[k++]);
-            t256 += cdiv(descs[i].M, 256) * cdiv(descs[i].N, 256);
-        }
-        if (all256) {
-            long long tot = 0;
-            for (int i = 0, k = 0; i < n; ++i) {
-                if (descs[i].M == 0) continue;
-                tot += tn256_retile(&descs[i], grp.g[k], 256 / t256 > 0 ? 256 / t256 : 1);
-                grp.start[++k] = (int)tot;
-            }
-            hipLaunchKernelGGL(gemm_grouped_tn256_kernel<bf16>, dim3((int)tot), dim3(512), 0, s, grp);
+    if (descs[0].dtype == A8_BF16) {
+        bool a3 = descs[0].layout == A8_GEMM_NT && g_a8_tuning[14] > 0;
+        for (int i = 0; i < n && a3; ++i) a3 = descs[i].M == 0 || descs[i].M >= g_a8_tuning[14];
+        if (a3) {
+            hipLaunchKernelGGL(gemm_grouped_a3_kernel<bf16>, dim3((int)total), dim3(512), 0, s, grp);
             return a8_check_launch("a8_gemm_grouped");
         }
+        return launch_grouped<bf16>(descs[0].layout, grp, (int)total, s);
     }
-    if (descs[0].dtype == A8_BF16) {
-        switch (g_variant) {
-            case 1: return launch2g<bf16, 1, 4, 2>(descs[0].layout, grp, (int)total, s);
-            case 5: {
-                bool a3 = descs[0].layout == A8_GEMM_NT && g_a8_tuning[14] > 0;
-                for (int i = 0; i < n && a3; ++i) a3 = descs[i].M == 0 || descs[i].M >= g_a8_tuning[14];
-                if (a3) {
-                    hipLaunchKernelGGL(gemm_grouped_a3_kernel<bf16>, dim3((int)total), dim3(512), 0, s, grp);
-                    return a8_check_launch("a8_gemm_grouped");
-                }
-                return launch2g<bf16, 2, 2, 4>(descs[0].layout, grp, (int)total, s);
-            }
-            case 6: return launch2g<bf16, 1, 4, 4>(descs[0].layout, grp, (int)total, s);
-            default: return launch2g<bf16, 2, 2, 2>(descs[0].layout, grp, (int)total, s);
-        }
-    }
-    return launch2g<float, 1, 4, 2>(descs[0].layout, grp, (int)total, s);
+    return launch_grouped<float>(descs[0].layout, grp, (int)total, s);
 }

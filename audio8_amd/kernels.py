@@ -55,27 +55,10 @@ def _gemm_desc(layout, A, B, M, N, K, *, out=None, out_dtype=None, lda=None, ldb
     return d, out, alg_bytes
 
 
-# Stream-K workspaces: one per stream (a workspace may serve only one launch at a time), zero-filled once; the epoch counts its launches.
-_SK_WS = {}
-STREAM_K = False       # measured slower on this step's shapes: off; tests and tools/sk_bench.py switch it on
-
-
-def _sk_workspace(dev):
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
-    e = _SK_WS.get(key)
-    if e is None:
-        e = _SK_WS[key] = [torch.zeros(L.GEMM_SK_WS_BYTES, device=dev, dtype=torch.uint8), 0]
-    e[1] = e[1] % 0xFFFFFFF0 + 1
-    return e[0], e[1]
-
-
 def gemm(layout, A, B, M, N, K, **kw):
     """C[M,N] = epi(alpha * A.B^T + bias).  A/B are CUDA tensors of the activation dtype; the logical
     shapes and leading dimensions are given explicitly so strided views (conv-as-GEMM) need no copy."""
     d, out, alg_bytes = _gemm_desc(layout, A, B, M, N, K, **kw)
-    if STREAM_K and layout == L.NT and A.dtype == torch.bfloat16 and 256 < ((M + 127) // 128) * ((N + 127) // 128) < 1536:
-        ws, epoch = _sk_workspace(A.device)
-        d.sk_ws, d.sk_ws_bytes, d.sk_epoch = ws.data_ptr(), ws.numel(), epoch
     if GEMM_PROFILE is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()

