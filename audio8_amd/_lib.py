@@ -53,7 +53,9 @@ ARGTYPES = {
     "a8_gelu_bwd_bias": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p],
     "a8_attn_fwd": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_uint32, C.c_void_p],
     "a8_attn_bwd": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_uint32, C.c_void_p],
-    "a8_vq_select": [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p],
+    "a8_vq_select": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p],
+    "a8_zero": [C.c_void_p, C.c_int64, C.c_void_p],
+    "a8_conv_wgrad_fold": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "a8_vq_gather": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "a8_vq_ppl": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p],
     "a8_vq_bwd": [C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
@@ -168,5 +170,5 @@ EXPORTS = [
     "a8_vq_select", "a8_vq_gather", "a8_vq_ppl", "a8_vq_bwd",
     "a8_contrastive_fwd", "a8_contrastive_bwd", "a8_loss_combine", "a8_loss_combine_bwd", "a8_ctc_greedy_decode",
     "a8_ctc_pack_targets", "a8_ctc_fwd_bwd", "a8_log_softmax_fwd", "a8_log_softmax_bwd",
-    "a8_sumsq", "a8_adamw",
+    "a8_sumsq", "a8_adamw", "a8_zero", "a8_conv_wgrad_fold",
 ]

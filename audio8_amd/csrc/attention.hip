@@ -618,6 +618,227 @@ __global__ __launch_bounds__(NW * 64, MW) void attn_bwd_q_kernel(const AttnP P) 
     }
 }
 
+// ================================================================== forward, 16-bit: 32x32x16 MFMA, a wave owns 32 queries
+// Round 3.  The 16x16 kernels above spend 12.7 VALU instructions per MFMA on the softmax (profiles/r02_attn_sq_counters.txt): the
+// forward pass is bound by vector-instruction issue, not by the matrix pipe.  This kernel is built around instruction count:
+//  * S^T = K Q^T on v_mfma_f32_32x32x16_bf16: lane (query = lane & 31, half = lane >> 5) holds 16 of a key block's 32 scores of ITS
+//    query, so row statistics are lane-local (one permlane32 swap per kernel for the sum, one per rescale for the max), the score
+//    registers 8s .. 8s+7 ARE the B operand of O^T += V^T P^T for 16-key step s (k order (j & 3) + 8 (j >> 2) + 4 half, matched by
+//    the transposed V reads), and an MFMA blocks the vector issue for 8 of its 32 cycles instead of 8 of 16;
+//  * no running-max pass: p = exp2(s * c - m) against the reference m of the last rescale, and the tile's own row sum (needed
+//    anyway) doubles as the overflow test -- a lane whose 32 probabilities sum beyond 2^8 sends the wave through the rescale
+//    path (true max, O and l rescaled, scores recomputed from the K tile still in LDS); the first tile (m = -inf) takes it by itself;
+//  * K / V tiles arrive by LDS-DMA (global_load_lds, 16 B per lane) into a 3-deep ring: ONE barrier per 64-key tile, two tiles in
+//    flight, no staging registers or LDS stores; K image: 128-byte rows, 16-byte chunk c at c ^ ((row >> 1) & 7) (conflict-free
+//    b128 row reads of 32 rows); V image: 256-byte blocks [key quad][d half][4 keys x 32 d] -- a half-wave's transposed read
+//    (ds_read_b64_tr_b16) is exactly one block, all 64 banks once, and every V address is one lane constant + an immediate;
+//  * the dropout words are those of the kernels above (one 32-bit hash per key quad, an 8-bit field per key): backward
+//    regenerates the identical mask.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int F32_TILE = 16384;                 // K image 8 KB | V image 8 KB
+constexpr float F32_SUM_LIMIT = 256.0f;         // per-lane tile sum beyond this -> rescale path (every p <= 2^8 otherwise)
+
+__device__ __attribute__((aligned(16))) unsigned int g_attn_zero16[4] = {0u, 0u, 0u, 0u};      // DMA source of rows beyond T
+
+A8_DEV void attn_glds16(const char* src, char* lds_dst_wave_uniform) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_dst_wave_uniform, 16, 0, 0);
+}
+A8_DEV f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 3) void attn_fwd32_kernel(const AttnP P) {
+    constexpr int BQ = NW * 32, NBUF = 3;
+    __shared__ __attribute__((aligned(1024))) char lds[NBUF * F32_TILE + 1024];      // + a dummy page for the DMAs issued past the last tile
+    const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int blk, bh;
+    block_coords((P.T + BQ - 1) / BQ, P.B * P.H, blk, bh);
+    const int b = bh / P.H, h = bh % P.H;
+    const bf16* qb = reinterpret_cast<const bf16*>(P.q) + (long long)b * P.T * P.ld_qkv + h * DH;
+    const char* kb_ = reinterpret_cast<const char*>(reinterpret_cast<const bf16*>(P.k) + (long long)b * P.T * P.ld_qkv + h * DH);
+    const char* vb_ = reinterpret_cast<const char*>(reinterpret_cast<const bf16*>(P.v) + (long long)b * P.T * P.ld_qkv + h * DH);
+    const uint8_t* km = P.keymask ? P.keymask + (long long)b * P.T : nullptr;
+    const int ntiles = (P.T + BT - 1) / BT;
+    const long long row_bytes = P.ld_qkv * 2, tile_bytes = (long long)BT * row_bytes;
+    const char* zero = reinterpret_cast<const char*>(g_attn_zero16);
+
+    // ---- this wave's four DMA pieces of a tile (1 KB each; 16 per tile: 0..7 = K rows 8p.., 8..15 = V blocks 4(p-8)..; with 5 waves
+    // four pieces are staged twice -- same bytes, same place).  Rows beyond T are clamped to row T-1 (finite data whose
+    // probabilities are zero): only the last tile has any, and it takes its own, precomputed, offsets.
+    unsigned soff[4], soff_last[4]; int dst[4]; bool is_k[4];
+    const int last_rows = P.T - (ntiles - 1) * BT;           // valid rows of the last tile (1..64)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int pid = (wv + NW * j) & 15;
+        int row, chunk;
+        if (pid < 8) {                                   // K: lane -> row 8 pid + lane / 8, LDS slot lane % 8 holds chunk slot ^ key(row)
+            row = 8 * pid + (lane >> 3);
+            chunk = (lane & 7) ^ ((row >> 1) & 7);
+        } else {                                         // V: lane -> block 4 (pid - 8) + lane / 16 = (key quad, d half); key lane/4 % 4, chunk lane % 4
+            const int blkid = 4 * (pid - 8) + (lane >> 4);
+            row = 4 * (blkid >> 1) + ((lane >> 2) & 3);
+            chunk = 4 * (blkid & 1) + (lane & 3);
+        }
+        is_k[j] = pid < 8;
+        soff[j] = (unsigned)(row * (int)row_bytes + chunk * 16);
+        soff_last[j] = (unsigned)(min(row, last_rows - 1) * (int)row_bytes + chunk * 16);
+        dst[j] = pid * 1024;
+    }
+    auto issue = [&](int t, int slot) {
+        const bool live = t < ntiles;                    // wave-uniform
+        const int tt = live ? t : ntiles - 1;            // past the end: a harmless re-read of the last tile into the dummy page
+        const char* kbase = kb_ + (long long)tt * tile_bytes;
+        const char* vbase = vb_ + (long long)tt * tile_bytes;
+        char* base = live ? lds + slot * F32_TILE : lds + NBUF * F32_TILE;
+        const bool lastt = tt == ntiles - 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            attn_glds16((is_k[j] ? kbase : vbase) + (lastt ? soff_last[j] : soff[j]), base + (live ? dst[j] : 0));
+    };
+
+    // ---- Q fragments (B operand: lane holds Q[query][16 ks + 8 half + 0..7]); dropout word base; accumulators
+    const int q = blk * BQ + wv * 32 + r;
+    const bool q_ok = q < P.T;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+        qf[ks] = q_ok ? *reinterpret_cast<const bf16x8*>(qb + (long long)q * P.ld_qkv + 16 * ks + 8 * hh) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    issue(0, 0);
+    issue(1, 1);
+    f32x16 o[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    uint32_t hbase = (pair_base(bh, P.T, P.Th, q) + (uint32_t)hh + P.seed) * HC1;       // word of key quad 2 mq + half of key block 0, tile 0
+    const int kkey = (r >> 1) & 7;                                                       // K row read: row 32 kb + r, chunk (2 ks + half) ^ kkey
+    const int vlane = hh * 512 + ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+    int kaddr[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kaddr[ks] = r * 128 + (((2 * ks + hh) ^ kkey) << 4);
+
+    int slot = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");          // this wave's pieces of tile t have landed (tile t+1 may be in flight)
+        __builtin_amdgcn_s_barrier();                             // ... and everybody else's; nobody reads tile t-1's slot any more
+        int nslot = slot + 2; nslot = nslot >= NBUF ? nslot - NBUF : nslot;
+        issue(t + 2, nslot);
+        const char* kt = lds + slot * F32_TILE;
+        const char* vt = kt + 8192;
+        slot = slot + 1 == NBUF ? 0 : slot + 1;
+        f32x16 s[2], pp[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                s[kb] = mfma32(*reinterpret_cast<const bf16x8*>(kt + kb * 4096 + kaddr[ks]), qf[ks], s[kb]);
+        }
+        // ---- probabilities against the current reference max; the row sum is the overflow test
+        const bool edge = km != nullptr || (t + 1) * BT > P.T;    // wave-uniform
+        float tsum = 0.f, tsum2 = 0.f;
+        {
+            const float nb = -m;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float p = fast_exp2(__builtin_fmaf(s[kb][i], P.scale, nb));
+                    pp[kb][i] = p;
+                    if (i & 1) asm("v_add_f32 %0, %1, %2" : "=v"(tsum2) : "v"(tsum2), "v"(p));      // (plain adds: the vectoriser would pack them
+                    else asm("v_add_f32 %0, %1, %2" : "=v"(tsum) : "v"(tsum), "v"(p));            //  into v_pk_add_f32, which issues slower)
+                }
+        }
+        tsum += tsum2;
+        if (edge || __any(!(tsum <= F32_SUM_LIMIT))) {            // (also true for inf / NaN: the first tile, m = -inf)
+            float mt = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float x = s[kb][i] * P.scale;
+                    if (edge) {
+                        const int key = t * BT + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                        if (km && key < P.T && !km[key]) x = MASKED_LOG2;
+                        if (key >= P.T) x = -INFINITY;
+                    }
+                    s[kb][i] = x;
+                    mt = fmaxf(mt, x);
+                }
+            {   // the other half-wave holds the other 32 keys of the same query
+                auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
+                mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            }
+            const float mn = fmaxf(m, mt);                        // finite: every tile starts below T, masked keys are -1e9
+            const float alpha = fast_exp2(m - mn);                // first tile: exp2(-inf) = 0
+            m = mn;
+            l *= alpha;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+            tsum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float p = fast_exp2(s[kb][i] - m);
+                    pp[kb][i] = p;
+                    tsum += p;
+                }
+        }
+        l += tsum;
+        // ---- dropout (one hash word per key quad = 4 consecutive registers), bf16 packing, O^T += V^T P^T
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            if (P.thr) {
+#pragma unroll
+                for (int mq = 0; mq < 4; ++mq) {
+                    const uint32_t h0 = hfin(hbase + (uint32_t)(8 * kb + 2 * mq) * HC1);
+                    pp[kb][4 * mq + 0] = (h0 & 0xFFu) >= P.thr ? pp[kb][4 * mq + 0] : 0.f;
+                    pp[kb][4 * mq + 1] = ((h0 >> 8) & 0xFFu) >= P.thr ? pp[kb][4 * mq + 1] : 0.f;
+                    pp[kb][4 * mq + 2] = ((h0 >> 16) & 0xFFu) >= P.thr ? pp[kb][4 * mq + 2] : 0.f;
+                    pp[kb][4 * mq + 3] = (h0 >> 24) >= P.thr ? pp[kb][4 * mq + 3] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pf = (bf16x8){(bf16)pp[kb][8 * s2 + 0], (bf16)pp[kb][8 * s2 + 1], (bf16)pp[kb][8 * s2 + 2], (bf16)pp[kb][8 * s2 + 3],
+                                           (bf16)pp[kb][8 * s2 + 4], (bf16)pp[kb][8 * s2 + 5], (bf16)pp[kb][8 * s2 + 6], (bf16)pp[kb][8 * s2 + 7]};
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const char* va = vt + vlane + kb * 4096 + s2 * 2048 + db * 256;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, va));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, va + 1024));
+                    typedef short s16x8 __attribute__((ext_vector_type(8)));
+                    const s16x8 xv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    o[db] = mfma32(__builtin_bit_cast(bf16x8, xv), pf, o[db]);
+                }
+            }
+        }
+        hbase += (uint32_t)(BT / 4) * HC1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the dummy DMAs past the last tile
+    // ---- epilogue: the two half-waves of a query hold complementary halves of its row sum
+    {
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l), __float_as_uint(l), false, false);
+        l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+    if (q_ok) {
+        const float inv = P.pscale / l;                           // 1/(1-p) of the dropout is applied here, once
+        bf16* op = reinterpret_cast<bf16*>(P.out) + ((long long)b * P.T + q) * P.ld_o + h * DH + 4 * hh;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int mq = 0; mq < 4; ++mq)                        // registers 4 mq .. 4 mq + 3 = head-dim columns 32 db + 8 mq + 4 half + 0..3
+                store4<bf16>(op + 32 * db + 8 * mq, o[db][4 * mq] * inv, o[db][4 * mq + 1] * inv, o[db][4 * mq + 2] * inv, o[db][4 * mq + 3] * inv);
+        if (hh == 0) P.lse[(long long)bh * P.T + q] = m + log2f(l);       // log2-domain log-sum-exp
+    }
+}
+
 void set_softmax_params(AttnP& P, float scale, float p, uint32_t seed) {
     P.scale = scale * 1.4426950408889634f;
     P.dscale = scale;
@@ -670,6 +891,15 @@ extern "C" int a8_attn_fwd(int dtype, const void* q, const void* k, const void* 
     P.B = B; P.T = T_; P.H = H; P.ld_qkv = ld_qkv; P.ld_o = ld_o;
     set_softmax_params(P, scale, p, seed);
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == A8_BF16 && g_a8_tuning[2] < 10) {
+        // 32 queries per wave, 4 or 5 waves per block: whichever wastes fewer wave slots on the tail of T (781 = 24.4 x 32 -> 5 x 5 waves)
+        const int units = cdiv(T_, 32);
+        const int nw = g_a8_tuning[2] == 4 || g_a8_tuning[2] == 5 ? g_a8_tuning[2] : (cdiv(units, 5) * 5 < cdiv(units, 4) * 4 ? 5 : 4);
+        const dim3 grid(cdiv(T_, 32 * nw) * B * H);
+        if (nw == 5) hipLaunchKernelGGL(attn_fwd32_kernel<5>, grid, dim3(320), 0, s, P);
+        else hipLaunchKernelGGL(attn_fwd32_kernel<4>, grid, dim3(256), 0, s, P);
+        return a8_check_launch("a8_attn_fwd");
+    }
     A8_ATTN_LAUNCH(attn_fwd_kernel, 2, "a8_attn_fwd")
     return a8_check_launch("a8_attn_fwd");
 }

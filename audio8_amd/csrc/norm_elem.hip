@@ -449,7 +449,13 @@ __global__ void log_softmax_bwd_kernel(const float* __restrict__ y, const float*
 }
 
 // ------------------------------------------------------------------ grad-norm + AdamW
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long long n, float* __restrict__ out) {
+// Sum of squares in a FIXED order: every block writes its partial sum, a one-block kernel adds them in index order.  (One
+// atomicAdd per block gave each data-parallel rank its own summation order: clip coefficients that differ in the last bit and
+// replicas that drift apart by an ulp per step, although their reduced gradients are bit-identical.)
+constexpr int SUMSQ_MAX_BLOCKS = 4096;
+__device__ float g_sumsq_partial[SUMSQ_MAX_BLOCKS];       // per device (code object); one a8_sumsq in flight per device at a time
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long long n, float* __restrict__ partial) {
     __shared__ float red[4];
     float s = 0.f;
     const long long n4 = n >> 2;
@@ -459,7 +465,14 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = x[n4 * 4 + threadIdx.x]; s += v * v; }
     s = block_sum<4>(s, red);
-    if (threadIdx.x == 0) atomicAdd(out, s);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ partial, int nb, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 256) s += partial[i];
+    s = block_sum<4>(s, red);
+    if (threadIdx.x == 0) out[0] += s;
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
@@ -655,7 +668,11 @@ extern "C" int a8_log_softmax_bwd(const float* y, const float* dy, void* dx, int
 extern "C" int a8_sumsq(const float* x, int64_t n, float* out, void* stream) {
     if (n == 0) return A8_OK;
     A8_REQUIRE(((uintptr_t)x % 16) == 0, "a8_sumsq: x must be 16-byte aligned");
-    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4 + 1, 1024)), dim3(256), 0, (hipStream_t)stream, x, (long long)n, out);
+    const int nb = grid_for(n / 4 + 1, 1024);             // <= SUMSQ_MAX_BLOCKS
+    float* partial = nullptr;
+    if (hipGetSymbolAddress((void**)&partial, HIP_SYMBOL(g_sumsq_partial)) != hipSuccess) return a8_set_error(A8_ERR_LAUNCH, "a8_sumsq: no partial buffer");
+    hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, (long long)n, partial);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)partial, nb, out);
     return a8_check_launch("a8_sumsq");
 }
 extern "C" int a8_adamw(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,

@@ -15,7 +15,10 @@ constexpr int VMAX_PER_LANE = 8;   // V <= 512
 // row (no atomics: R*V same-address adds, LDS or global, were 25 of this kernel's 30 us); vq_avg_reduce_kernel sums the
 // partial rows into avg_probs.
 constexpr int VQ_ROWS = 16;
+// gumbel_gen != nullptr (and gumbel == nullptr): the Gumbel(0,1) noise of F.gumbel_softmax (-log E, E ~ Exp(1): torch's
+// `-empty.exponential_().log()`) is drawn here from a counter hash of (seed, element index) and written to gumbel_gen for backward.
 __global__ __launch_bounds__(64 * VQ_ROWS) void vq_select_kernel(const float* __restrict__ logits, const float* __restrict__ gumbel,
+                                                                 float* __restrict__ gumbel_gen, uint32_t seed,
                                                                  int32_t* __restrict__ codes, float* __restrict__ partial, int R, int V) {
     __shared__ float s_p[VQ_ROWS * 64 * VMAX_PER_LANE];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -31,7 +34,15 @@ __global__ __launch_bounds__(64 * VQ_ROWS) void vq_select_kernel(const float* __
             x[j] = v < V ? logits[(long long)row * V + v] : -INFINITY;
             mx = fmaxf(mx, x[j]);
             if (v < V) {
-                const float y = gumbel ? x[j] + gumbel[(long long)row * V + v] : x[j];
+                float y = x[j];
+                if (gumbel) y += gumbel[(long long)row * V + v];
+                else if (gumbel_gen) {
+                    const uint32_t h = a8_hash(seed, 0x6756u, (uint32_t)((long long)row * V + v));
+                    const float u = ((float)(h >> 8) + 0.5f) * 5.9604644775390625e-08f;          // uniform in (0, 1), 24 bits
+                    const float g = -__logf(-__logf(u));
+                    gumbel_gen[(long long)row * V + v] = g;
+                    y += g;
+                }
                 if (y > best) { best = y; bi = v; }
             }
         }
@@ -337,13 +348,14 @@ int gridw(int rows) { int b = (rows + 3) / 4; return b < 1 ? 1 : (b > 2048 ? 204
 
 }  // namespace
 
-extern "C" int a8_vq_select(const float* logits, const float* gumbel, float tau, int32_t* codes, float* avg_probs, float* scratch,
-                            int R, int V, void* stream) {
+extern "C" int a8_vq_select(const float* logits, const float* gumbel, float* gumbel_gen, uint32_t seed, float tau, int32_t* codes,
+                            float* avg_probs, float* scratch, int R, int V, void* stream) {
+    A8_REQUIRE(!(gumbel && gumbel_gen), "a8_vq_select: give the noise or ask for it, not both");
     A8_REQUIRE(V >= 1 && V <= 64 * VMAX_PER_LANE, "a8_vq_select: V=%d must be <= %d", V, 64 * VMAX_PER_LANE);
     A8_REQUIRE(tau > 0.f, "a8_vq_select: tau must be positive");
     A8_REQUIRE(R >= 0, "a8_vq_select: bad row count");
     const int nb = cdiv(R, VQ_ROWS);                    // (R = 0: avg_probs = 0)
-    if (nb) hipLaunchKernelGGL(vq_select_kernel, dim3(nb), dim3(64 * VQ_ROWS), 0, (hipStream_t)stream, logits, gumbel, codes, scratch, R, V);
+    if (nb) hipLaunchKernelGGL(vq_select_kernel, dim3(nb), dim3(64 * VQ_ROWS), 0, (hipStream_t)stream, logits, gumbel, gumbel_gen, seed, codes, scratch, R, V);
     hipLaunchKernelGGL(vq_avg_reduce_kernel, dim3(cdiv(V, 64)), dim3(1024), 0, (hipStream_t)stream, (const float*)scratch, avg_probs, nb, V);
     return a8_check_launch("a8_vq_select");
 }

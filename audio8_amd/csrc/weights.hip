@@ -116,6 +116,18 @@ __global__ __launch_bounds__(256) void wprep_multi_kernel(const a8_wprep_desc* _
     }
 }
 
+// grad[o][c][kk] += dw2[o][kk][c]; dw2[o][kk][c] = 0.  One thread per (o, c): reads are contiguous along c, the k writes of a thread are adjacent.
+__global__ __launch_bounds__(256) void conv_wgrad_fold_kernel(float* __restrict__ dw2, float* __restrict__ grad, int co, int cin, int k) {
+    const long long i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= (long long)co * cin) return;
+    const int o = (int)(i / cin), c = (int)(i - (long long)o * cin);
+    for (int kk = 0; kk < k; ++kk) {
+        float* src = dw2 + ((long long)o * k + kk) * cin + c;
+        grad[i * k + kk] += *src;
+        *src = 0.f;
+    }
+}
+
 }  // namespace
 
 extern "C" int a8_prepare_weights(int dtype, const a8_wprep_desc* descs, int n, void* stream) {
@@ -142,4 +154,18 @@ extern "C" int a8_prepare_weights_device(int dtype, const a8_wprep_desc* descs_d
     if (dtype == A8_BF16) hipLaunchKernelGGL(wprep_multi_kernel<bf16>, dim3(total_tiles), dim3(256), 0, s, descs_dev, tile_start_dev, n);
     else hipLaunchKernelGGL(wprep_multi_kernel<float>, dim3(total_tiles), dim3(256), 0, s, descs_dev, tile_start_dev, n);
     return a8_check_launch("a8_prepare_weights_device");
+}
+
+extern "C" int a8_zero(void* p, int64_t bytes, void* stream) {
+    A8_REQUIRE(bytes >= 0 && (p != nullptr || bytes == 0), "a8_zero: bad arguments");
+    if (bytes == 0) return A8_OK;
+    const hipError_t e = hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream);
+    if (e != hipSuccess) return a8_set_error(A8_ERR_LAUNCH, "a8_zero: %s", hipGetErrorString(e));
+    return A8_OK;
+}
+
+extern "C" int a8_conv_wgrad_fold(float* dw2, float* grad, int co, int cin, int k, void* stream) {
+    A8_REQUIRE(dw2 && grad && co >= 1 && cin >= 1 && k >= 1, "a8_conv_wgrad_fold: bad arguments");
+    hipLaunchKernelGGL(conv_wgrad_fold_kernel, dim3(cdiv((long long)co * cin, 256)), dim3(256), 0, (hipStream_t)stream, dw2, grad, co, cin, k);
+    return a8_check_launch("a8_conv_wgrad_fold");
 }

@@ -337,12 +337,28 @@ def attn_bwd(q, k, v, o, dout, lse, B, T, H, ld_qkv, scale, keymask=None, p=0.0,
 
 
 # ----------------------------------------------------------------------------- VQ
-def vq_select(logits, gumbel, tau):
+def zeros(shape, dtype, device):
+    """torch.zeros without an ATen fill kernel: the clear is a memset on the current stream (a8_zero)."""
+    t = torch.empty(shape, device=device, dtype=dtype)
+    L.check(L.lib().a8_zero(L.ptr(t), t.numel() * t.element_size(), L.stream()), "a8_zero")
+    return t
+
+
+def conv_wgrad_fold_(dw2, grad, co, cin, k):
+    """grad[co][cin][k] += dw2[co][k][cin]; dw2 is zero again afterwards."""
+    L.require_cuda(dw2, grad)
+    L.check(L.lib().a8_conv_wgrad_fold(L.ptr(dw2), L.ptr(grad), co, cin, k, L.stream()), "a8_conv_wgrad_fold")
+    return grad
+
+
+def vq_select(logits, gumbel, tau, gumbel_gen=None, seed=0):
+    """gumbel: the noise to add (None: none); gumbel_gen: an output buffer -- the kernel draws the noise itself and stores it there."""
     R, V = logits.shape
     codes = torch.empty((R,), device=logits.device, dtype=torch.int32)
     avg = torch.empty((V,), device=logits.device, dtype=torch.float32)
     scratch = torch.empty((((R + 15) // 16) * V,), device=logits.device, dtype=torch.float32)        # A8_VQ_SELECT_SCRATCH_FLOATS
-    L.check(L.lib().a8_vq_select(L.ptr(_c(logits)), L.ptr(_c(gumbel)), _f(tau), L.ptr(codes), L.ptr(avg), L.ptr(scratch), R, V, L.stream()), "a8_vq_select")
+    L.check(L.lib().a8_vq_select(L.ptr(_c(logits)), L.ptr(_c(gumbel)), L.ptr(gumbel_gen), _u32(seed), _f(tau), L.ptr(codes), L.ptr(avg),
+                                 L.ptr(scratch), R, V, L.stream()), "a8_vq_select")
     return codes, avg
 
 
@@ -373,7 +389,7 @@ def contrastive_fwd(ctx, lat, neg_idx):
     rows, Cn = ctx.shape
     N = neg_idx.shape[1]
     logits = torch.empty((rows, N + 1), device=ctx.device, dtype=torch.float32)
-    loss_sum = torch.zeros((1,), device=ctx.device, dtype=torch.float32)
+    loss_sum = zeros((1,), torch.float32, ctx.device)
     inv_norms = torch.empty((2, rows), device=ctx.device, dtype=torch.float32)
     L.check(L.lib().a8_contrastive_fwd(L.dt(ctx), L.ptr(_c(ctx)), L.ptr(_c(lat)), L.ptr(_c(neg_idx)), L.ptr(logits), L.ptr(loss_sum),
                                        L.ptr(inv_norms), rows, N, Cn, L.stream()), "a8_contrastive_fwd")
@@ -386,7 +402,7 @@ def contrastive_bwd(ctx, lat, neg_idx, logits, gscale, rows_per_group=0, inv_nor
     rows, Cn = ctx.shape
     N = neg_idx.shape[1]
     dctx = torch.empty((rows, Cn), device=ctx.device, dtype=torch.float32)
-    dlat = torch.zeros((rows, Cn), device=ctx.device, dtype=torch.float32)
+    dlat = zeros((rows, Cn), torch.float32, ctx.device)
     scratch = torch.empty((rows * (2 + 2 * (N + 1) + 1 + int(rows_per_group) + 7 + 768) + 32,), device=ctx.device, dtype=torch.float32)    # A8_CONTRASTIVE_BWD_SCRATCH_FLOATS
     L.check(L.lib().a8_contrastive_bwd(L.dt(ctx), L.ptr(_c(ctx)), L.ptr(_c(lat)), L.ptr(_c(neg_idx)), L.ptr(logits), L.ptr(gscale), L.ptr(inv_norms),
                                        L.ptr(dctx), L.ptr(dlat), L.ptr(scratch), rows, N, Cn, int(rows_per_group), L.stream()), "a8_contrastive_bwd")

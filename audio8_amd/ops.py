@@ -433,7 +433,7 @@ class GatherRowsFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         (idx,) = ctx.saved_tensors
-        dx = torch.zeros((ctx.rows, dy.shape[1]), device=dy.device, dtype=dy.dtype)
+        dx = K.zeros((ctx.rows, dy.shape[1]), dy.dtype, dy.device)
         K.scatter_add_rows_(dx, idx, dy.contiguous())
         return dx, None
 
@@ -566,8 +566,15 @@ class ConvStackFn(torch.autograd.Function):
                 if tgt is not None:
                     # off the critical path: wgrad GEMM + re-layout [co][k][cin] -> [co][cin][k] + accumulate on the side stream
                     def run(dz=dz, a=a_prev, co=co, k=k, cin=cin, M=M, s=s, Lout=Lout, Lin=Lin, akw=akw, tgt=tgt, p=ws[i]):
-                        dw2 = wgrad(dz, a, co, k * cin, M, ldb=s * cin, b_rpb=Lout, b_bs=Lin * cin, lda=co, **akw)
-                        tgt.add_(dw2.view(co, k, cin).permute(0, 2, 1))
+                        # split-K partial sums land in a buffer kept across steps (the fold kernel clears it behind its read:
+                        # no fill launch), then fold into the parameter's [co][cin][k] layout
+                        key = (co, k, cin, dz.device)
+                        dw2 = _CONV_DW_CACHE.get(key)
+                        if dw2 is None:
+                            dw2 = _CONV_DW_CACHE[key] = torch.zeros((co, k * cin), device=dz.device, dtype=torch.float32)
+                        K.gemm(L.TN, dz, a, co, k * cin, M, out=dw2, splitk=_splitk(_tiles(co, k * cin), M), ldb=s * cin, b_rpb=Lout,
+                               b_bs=Lin * cin, lda=co, **akw)
+                        K.conv_wgrad_fold_(dw2, tgt, co, cin, k)
                         if last:                       # the gradient is complete once the last chunk's share is enqueued
                             _ready(p)
                     _on_side(run, dz, a_prev)
@@ -638,6 +645,9 @@ class ConvStackFn(torch.autograd.Function):
             dw0 = dgw = dgb = None
         grads[0] = dw0
         return (None, dgw, dgb, None, *grads)
+
+
+_CONV_DW_CACHE = {}        # (co, k, cin, device) -> f32 [co, k*cin] split-K landing buffer of a conv weight gradient, zero between uses
 
 
 # Utterance chunking of the conv stack's big leading layers (layer 0's output is 51 MB per utterance at 250 k samples): with
@@ -931,10 +941,12 @@ class VQFn(torch.autograd.Function):
         e = cached_weights(wp, y.dtype)
         wpc, wpt = e if e is not None else (_wcast(wp, y.dtype).contiguous(), None)
         logits = K.gemm(L.NT, y, wpc, N, G * V, Cin, bias=bp.detach(), out_dtype=torch.float32).view(N * G, V)
-        if training and gumbel is None:
-            gumbel = -torch.empty_like(logits).exponential_().log()
         vars2d = vars_.detach().reshape(G * V, D)
-        codes, avg = K.vq_select(logits, gumbel if training else None, tau)
+        if training and gumbel is None:        # the noise of F.gumbel_softmax, drawn inside the select kernel (seeded from torch's seed)
+            gumbel = torch.empty_like(logits)
+            codes, avg = K.vq_select(logits, None, tau, gumbel_gen=gumbel, seed=next_seed())
+        else:
+            codes, avg = K.vq_select(logits, gumbel if training else None, tau)
         q = K.vq_gather(vars2d, codes, N, G, V, D, y.dtype)
         ppl, dppl = K.vq_ppl(avg)
         ctx.save_for_backward(y, wpc, logits, gumbel if training else None, codes, vars2d, dppl)

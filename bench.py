@@ -102,6 +102,29 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4")))
 
 
+def dry_run(args):
+    """The N-rank contract without a GPU: every rank joins a gloo group from the launcher's environment, exchanges a tensor, meets
+    at a barrier; rank 0 prints ONE JSON line.  Rehearses `--gpus 8` (spawn, rendezvous on 127.0.0.1, exit codes) where eight
+    processes may not share the one test GPU."""
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group(backend="gloo", init_method="env://", rank=rank, world_size=world)
+    if os.environ.get("A8_BENCH_FAIL_AFTER_INIT") == str(rank):
+        raise RuntimeError("bench.py: injected failure of rank %d after init_process_group" % rank)
+    t = torch.tensor([float(rank + 1)])
+    if world > 1:
+        dist.all_reduce(t)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (launcher / rendezvous rehearsal, no GPU work)", "value": None, "n_gpus": world, "dry_run": True,
+                          "rank_sum": float(t.item()), "config": {"global_batch": world * args.batch, "parallelism": "dp%d" % world}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,9 +142,15 @@ def main():
     ap.add_argument("--h2d-steps", type=int, default=10, help="extra steps fed from host memory through the on-ramp (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--bucket-mb", type=float, default=32.0)
+    ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous rehearsal on CPU ranks (gloo): no GPU work, no metric")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
+    # fault injection for the launcher tests: the named rank dies before / after the rendezvous (never set in a measurement)
+    if os.environ.get("A8_BENCH_FAIL_BEFORE_INIT") == os.environ.get("RANK", "0"):
+        raise RuntimeError("bench.py: injected failure of rank %s before init_process_group" % os.environ.get("RANK", "0"))
+    if args.dry_run:
+        return dry_run(args)
 
     from audio8_amd import _lib as L
     from audio8_amd import ops, wav2vec2 as W, kernels as K
@@ -157,14 +186,24 @@ def main():
         L.check(L.lib().a8_set_tuning(int(k), int(v)), "a8_set_tuning")
     x = synth(args.batch, args.samples, rank).to(dev)
 
+    host_s = {"fwd": 0.0, "bwd": 0.0, "draws": 0.0, "wait": 0.0, "opt": 0.0}      # host time per phase (enqueue cost; "wait" = loss.item())
+
     def one_step():
+        c0 = time.perf_counter()
         stepper.zero_grad()
         loss = loss_fn(model, x)
+        c1 = time.perf_counter()
         loss.backward()
+        c2 = time.perf_counter()
         if prefetch:
             W.prefetch_host_draws(model, loss_fn, x.shape, dev)   # next step's numpy draws, while the GPU runs this backward
+        c3 = time.perf_counter()
         lv = loss.item()                       # audio8/pretrain.py:180
+        c4 = time.perf_counter()
         stepper.step()
+        c5 = time.perf_counter()
+        for k_, v_ in zip(("fwd", "bwd", "draws", "wait", "opt"), (c1 - c0, c2 - c1, c3 - c2, c4 - c3, c5 - c4)):
+            host_s[k_] += v_
         return lv
 
     def fence():
@@ -175,15 +214,19 @@ def main():
     for _ in range(args.warmup):
         lv = one_step()
     fence()
+    for k_ in host_s:
+        host_s[k_] = 0.0
     t0 = time.time()
     for _ in range(args.steps):
         lv = one_step()
     fence()
     dt = time.time() - t0
+    host_ms = {k_: v_ / args.steps * 1e3 for k_, v_ in host_s.items()}
     if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([dt] + [host_ms[k_] for k_ in sorted(host_ms)], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        dt = float(tmax[0].item())
+        host_ms = {k_: float(v_) for k_, v_ in zip(sorted(host_ms), tmax[1:].tolist())}
     ms_per_step = dt / args.steps * 1e3
     value = world * args.batch * args.samples / SAMPLE_RATE / (dt / args.steps)
 
@@ -320,6 +363,7 @@ def main():
                                       % (args.model, args.batch, args.samples, args.dropout),
                           "global_batch": world * args.batch, "samples_per_clip": args.samples, "parallelism": "dp%d" % world,
                           "last_loss": round(float(lv), 5),
+                          "host_ms_per_step": {k_: round(v_, 3) for k_, v_ in host_ms.items()},     # max over ranks: enqueue time per phase ("wait" = loss.item())
                           "ms_per_step_with_h2d": round(ms_h2d, 3) if ms_h2d is not None else None,
                           "h2d_note": "same step with the batch handed over as host arrays every step (audio8/pretrain.py:172-177 times "
                                       "next(train_itr) + batch.to(device) too): pinned double-buffered on-ramp, %d steps" % args.h2d_steps},

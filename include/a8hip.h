@@ -199,13 +199,23 @@ typedef struct a8_encoder_layer_bwd_desc {
 } a8_encoder_layer_bwd_desc;
 int a8_encoder_layer_bwd(const a8_encoder_layer_bwd_desc* e, void* stream);
 
+/* ---- small runtime helpers of the step (no ATen kernels between the first conv launch and the optimizer) ------------------
+ * a8_zero: bytes of device memory := 0 on the stream (hipMemsetAsync).
+ * a8_conv_wgrad_fold: the strided-conv weight gradient leaves its split-K GEMM as dw2 f32 [co][k][cin] (reduction index kk*cin + ci);
+ * the parameter (nn.Conv1d weight, audio8/wav2vec2.py:425-429) is [co][cin][k]:  grad[o][c][kk] += dw2[o][kk][c], and dw2 := 0 behind the
+ * read (the caller keeps dw2 across steps: no fill launch). */
+int a8_zero(void* p, int64_t bytes, void* stream);
+int a8_conv_wgrad_fold(float* dw2, float* grad, int co, int cin, int k, void* stream);
+
 /* ---- Gumbel-softmax product quantiser (GumbelVectorQuantizer.forward audio8/wav2vec2.py:547-576) ----
- * logits f32 [R, V] (R = B*Tm*G rows), gumbel f32 [R,V] or NULL (eval: plain argmax);
+ * logits f32 [R, V] (R = B*Tm*G rows), gumbel f32 [R,V] or NULL; gumbel_gen f32 [R,V] or NULL: when gumbel is NULL and gumbel_gen
+ * is not, the Gumbel(0,1) noise of F.gumbel_softmax is drawn inside the kernel from a counter hash of (seed, element) and written to
+ * gumbel_gen (backward reads it); both NULL: eval, plain argmax;
  * codes i32 [R]; avg_probs f32 [V] = mean over rows of softmax(logits) (written, not accumulated);
  * scratch: f32 [A8_VQ_SELECT_SCRATCH_FLOATS(R, V)] (per-block partial rows: no atomics anywhere) */
 #define A8_VQ_SELECT_SCRATCH_FLOATS(R, V) ((((size_t)(R) + 15) / 16) * (size_t)(V))
-int a8_vq_select(const float* logits, const float* gumbel, float tau, int32_t* codes, float* avg_probs, float* scratch,
-                 int R, int V, void* stream);
+int a8_vq_select(const float* logits, const float* gumbel, float* gumbel_gen, uint32_t seed, float tau, int32_t* codes,
+                 float* avg_probs, float* scratch, int R, int V, void* stream);
 /* q[n, g*D + :] = vars[g*V + codes[n*G+g], :]  (codebook gather; vars f32 [G*V, D]); q dtype [N, G*D] */
 int a8_vq_gather(int dtype, const float* vars, const int32_t* codes, void* q, int N, int G, int V, int D, void* stream);
 /* prob_ppl = sum exp(-sum p log(p + 1e-7)) over avg_probs[V] -> ppl[0]; dppl_davg[V] */

@@ -234,3 +234,37 @@ def test_wav2vec2_module_dp_contract_gloo_world2():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# bench.py's launcher contract at N = 8 (the driver's scaling run), rehearsed on CPU ranks: `--dry-run` takes the same path through
+# spawn_ranks / torch.distributed.run / the 127.0.0.1 rendezvous, but the ranks only join a gloo group (eight processes may not share
+# the single test GPU).
+def _bench(args, env_extra=None, timeout=300):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(OMP_NUM_THREADS="1", **(env_extra or {}))
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout, cwd=root)
+
+
+def test_bench_gpus_8_dry_run_is_eight_ranks_and_one_json_line():
+    import json
+    r = _bench(["--gpus", "8", "--dry-run"])
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["rank_sum"] == 36.0 and out["config"]["global_batch"] == 64 and out["config"]["parallelism"] == "dp8"
+
+
+@pytest.mark.parametrize("when", ["A8_BENCH_FAIL_BEFORE_INIT", "A8_BENCH_FAIL_AFTER_INIT"])
+def test_bench_rank_failure_makes_the_launcher_exit_nonzero(when):
+    """One rank raising -- before it reaches init_process_group, or after the group exists -- must end the whole launch with a
+    non-zero exit code instead of leaving seven ranks waiting in the rendezvous (fresh child processes only: the launcher itself
+    never initialises a GPU and never re-executes itself)."""
+    r = _bench(["--gpus", "8", "--dry-run"], {when: "3"}, timeout=240)
+    assert r.returncode != 0
+    assert "injected failure of rank 3" in (r.stderr + r.stdout)
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -198,6 +198,10 @@ torch.cuda.synchronize()
 both = [torch.empty_like(st4.state.flat_p) for _ in range(world)]
 dist.all_gather(both, st4.state.flat_p)
 out["layerdrop_params_identical"] = bool(all(torch.equal(b, both[0]) for b in both))
+out["layerdrop_max_param_diff"] = float(max((b - both[0]).abs().max() for b in both))
+gb = [torch.empty_like(st4.state.flat_m) for _ in range(world)]
+dist.all_gather(gb, st4.state.flat_m)
+out["layerdrop_max_moment_diff"] = float(max((b - gb[0]).abs().max() for b in gb))
 out["layerdrop_local_drop_counts"] = [int(sum(d)) for d in drops]
 out["layerdrop_param_steps"] = sorted(set(st4.param_steps))
 out["layerdrop_finite"] = bool(torch.isfinite(st4.state.flat_p).all())

@@ -283,18 +283,19 @@ def _attn_ref(q, k, v, keymask, scale, drop_keep=None, p=0.0):
     return torch.matmul(a, v)
 
 
-@pytest.fixture(params=[41, 22, 42])
+@pytest.fixture(params=[41, 22, 42, 4, 5])
 def attn_geometry(request):
-    """Launch geometry of the three attention kernels (waves per block * 10 + 16-row groups per wave)."""
+    """Launch geometry of the three attention kernels: 41 / 22 / 42 = the 16x16-MFMA kernels (waves per block * 10 + 16-row groups
+    per wave) for forward, dK/dV and dQ; 4 / 5 = the 32x32-MFMA 16-bit forward kernel with 4 / 5 waves of 32 queries (backward: 41)."""
     from audio8_amd import _lib as L
     for key in (2, 3, 4):
-        L.check(L.lib().a8_set_tuning(key, request.param), "a8_set_tuning")
+        L.check(L.lib().a8_set_tuning(key, request.param if (request.param > 9 or key == 2) else 41), "a8_set_tuning")
     yield request.param
     for key, v in ((2, ATTN_DEFAULT[0]), (3, ATTN_DEFAULT[1]), (4, ATTN_DEFAULT[2])):
         L.check(L.lib().a8_set_tuning(key, v), "a8_set_tuning")
 
 
-ATTN_DEFAULT = (41, 41, 41)
+ATTN_DEFAULT = (0, 41, 41)       # forward: 0 = the 32x32 kernel for 16-bit data, wave count chosen from T
 
 
 @pytest.mark.parametrize("dtype", DT)
@@ -433,6 +434,58 @@ def test_attention_running_max_rescale(attn_geometry):
     close(dq.reshape(B, T, H, 64), qr.grad.permute(0, 2, 1, 3), 1e-4, "attn dq (rescale)")
     close(dk.reshape(B, T, H, 64), kr.grad.permute(0, 2, 1, 3), 1e-4, "attn dk (rescale)")
     close(dv.reshape(B, T, H, 64), vr.grad.permute(0, 2, 1, 3), 1e-4, "attn dv (rescale)")
+
+
+@pytest.mark.parametrize("nw", [4, 5])
+def test_attention_fwd32_rescale_paths_bf16(nw):
+    """The 16-bit forward kernel has no running-max pass: probabilities are referred to the max of the last rescale and the tile's row
+    sum is the overflow test (> 2^8 per lane -> rescale path).  Inputs that FORCE each branch at chosen tiles, checked over the full
+    tensor against an fp64 softmax of the same bf16 inputs: scores that jump far past the limit (even queries: +30 nats over the
+    sequence, and one spiked key in the third tile), scores that creep up inside the margin (odd queries), a key mask, a ragged tail
+    (T = 333: last tile has 13 keys), and dropout on top (mask extracted from the kernel itself)."""
+    from audio8_amd import kernels as K, _lib as L
+    B, H, T = 2, 2, 333
+    d = H * 64
+    torch.manual_seed(5)
+    q = torch.randn(B, H, T, 64)
+    k = torch.randn(B, H, T, 64) * 0.3
+    ramp = torch.linspace(0.0, 6.0, T)
+    u = torch.nn.functional.normalize(torch.randn(64), dim=0)
+    k = k + ramp[None, None, :, None] * u
+    k[:, :, 150] += 9.0 * u                                  # a spike inside tile 2: + 0.125 * 40 * 9 = 45 nats for the even queries
+    q[:, :, ::2] += 40.0 * u
+    q[:, :, 1::2] += 4.0 * u
+    v = torch.randn(B, H, T, 64)
+    bf = torch.bfloat16
+    qkv = torch.stack([q, k, v], 0).permute(1, 3, 0, 2, 4).reshape(B * T, 3 * d).to(bf)
+    f = qkv.double().view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    qd, kd, vd = f[0], f[1], f[2]
+    keymask = torch.ones(B, T, dtype=torch.uint8)
+    keymask[1, 300:] = 0
+    g = qkv.to("cuda")
+    L.check(L.lib().a8_set_tuning(2, nw), "tune")
+    try:
+        for km in (None, keymask):
+            sc = torch.matmul(qd, kd.transpose(-2, -1)) * 0.125
+            if km is not None:
+                sc = sc.masked_fill(km[:, None, None, :] == 0, -1e9)
+            oref = torch.matmul(sc.softmax(-1), vd)
+            o, lse = K.attn_fwd(g[:, :d], g[:, d:2 * d], g[:, 2 * d:], B, T, H, 3 * d, 0.125, None if km is None else km.cuda())
+            close(o.float().view(B, T, H, 64), oref.float().permute(0, 2, 1, 3), 2e-2, "fwd32 o")
+            close(lse.view(B, H, T), (torch.logsumexp(sc, -1) * 1.4426950408889634).float(), 2e-3, "fwd32 lse")
+        # dropout: the kernel's own mask, extracted with uniform probabilities (same hash words as the 16x16 kernels)
+        p, seed = 0.1, 91
+        keep = _extract_keep(K, B, H, T, p, seed, bf)
+        L.check(L.lib().a8_set_tuning(2, 41), "tune")
+        keep_old = _extract_keep(K, B, H, T, p, seed, bf)
+        L.check(L.lib().a8_set_tuning(2, nw), "tune")
+        assert torch.equal(keep, keep_old)                    # backward (16x16 kernels) regenerates exactly this mask
+        sc = torch.matmul(qd, kd.transpose(-2, -1)) * 0.125
+        oref = torch.matmul(sc.softmax(-1) * keep.double() / (1 - round(p * 256) / 256), vd)
+        o, _ = K.attn_fwd(g[:, :d], g[:, d:2 * d], g[:, 2 * d:], B, T, H, 3 * d, 0.125, None, p=p, seed=seed)
+        close(o.float().view(B, T, H, 64), oref.float().permute(0, 2, 1, 3), 2e-2, "fwd32 o (dropout)")
+    finally:
+        L.check(L.lib().a8_set_tuning(2, ATTN_DEFAULT[0]), "tune")
 
 
 # ------------------------------------------------------------------ VQ (golden G4)

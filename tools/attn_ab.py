@@ -32,15 +32,19 @@ def bwd():
     return K.attn_bwd(qkv[:, :dm], qkv[:, dm:2 * dm], qkv[:, 2 * dm:], o, dout, lse, B, T, H, 3 * dm, 0.125, None, p=p, seed=3, dqkv=dq)
 
 
+tune(2, 41)
 ref_o = fwd()[0].clone()
+ref_lse = fwd()[1].clone()
 ref_d = bwd()[3].clone()
 for rnd in range(3):
     out = []
-    for v in (41, 441, 541, 42):
+    for v in (41, 0, 4, 5):                     # 41: the 16x16 kernel (4 waves x 16 queries); 0 / 4 / 5: the 32x32 kernel (auto / 4 / 5 waves x 32 queries)
         tune(2, v)
-        assert torch.equal(fwd()[0], ref_o), v
-        out.append("fwd %d: %.1f" % (v, timeit(fwd, iters=30)))
-    tune(2, 41)
+        got, lse_ = fwd()[:2]
+        err = (got.float() - ref_o.float()).abs().max().item()
+        assert err < 2e-2 and (lse_ - ref_lse).abs().max().item() < 1e-3, (v, err)
+        out.append("fwd %d: %.1f (max |d| %.1e)" % (v, timeit(fwd, iters=30), err))
+    tune(2, 0)
     for kq in (41, 441):
         for kk in (41, 441):
             tune(4, kq); tune(3, kk)
