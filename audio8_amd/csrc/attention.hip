@@ -638,7 +638,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int F32_TILE = 16384;                 // K image 8 KB | V image 8 KB
 constexpr float F32_SUM_LIMIT = 256.0f;         // per-lane tile sum beyond this -> rescale path (every p <= 2^8 otherwise)
 
-__device__ __attribute__((aligned(16))) unsigned int g_attn_zero16[4] = {0u, 0u, 0u, 0u};      // DMA source of rows beyond T
 
 A8_DEV void attn_glds16(const char* src, char* lds_dst_wave_uniform) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -661,7 +660,6 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd32_kernel(const AttnP P) {
     const uint8_t* km = P.keymask ? P.keymask + (long long)b * P.T : nullptr;
     const int ntiles = (P.T + BT - 1) / BT;
     const long long row_bytes = P.ld_qkv * 2, tile_bytes = (long long)BT * row_bytes;
-    const char* zero = reinterpret_cast<const char*>(g_attn_zero16);
 
     // ---- this wave's four DMA pieces of a tile (1 KB each; 16 per tile: 0..7 = K rows 8p.., 8..15 = V blocks 4(p-8)..; with 5 waves
     // four pieces are staged twice -- same bytes, same place).  Rows beyond T are clamped to row T-1 (finite data whose
@@ -700,12 +698,17 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd32_kernel(const AttnP P) {
     // ---- Q fragments (B operand: lane holds Q[query][16 ks + 8 half + 0..7]); dropout word base; accumulators
     const int q = blk * BQ + wv * 32 + r;
     const bool q_ok = q < P.T;
+    const bool wave_live = blk * BQ + wv * 32 < P.T;           // wave-uniform
     bf16x8 qf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
         qf[ks] = q_ok ? *reinterpret_cast<const bf16x8*>(qb + (long long)q * P.ld_qkv + 16 * ks + 8 * hh) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
     issue(0, 0);
     issue(1, 1);
+    // The Q loads are older than the eight DMAs: retire them HERE, with a wait the compiler's counter pass can see (an inline-asm wait
+    // is invisible to it) -- otherwise it protects the first use of qf inside the loop with a vmcnt(0) that would drain the ring's
+    // prefetches in every iteration.
+    __builtin_amdgcn_s_waitcnt(0x0F78);          // vmcnt(8) alone (expcnt 7, lgkmcnt 15)
     f32x16 o[2];
 #pragma unroll
     for (int db = 0; db < 2; ++db)
@@ -724,10 +727,10 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd32_kernel(const AttnP P) {
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");          // this wave's pieces of tile t have landed (tile t+1 may be in flight)
         __builtin_amdgcn_s_barrier();                             // ... and everybody else's; nobody reads tile t-1's slot any more
         int nslot = slot + 2; nslot = nslot >= NBUF ? nslot - NBUF : nslot;
-        issue(t + 2, nslot);
         const char* kt = lds + slot * F32_TILE;
         const char* vt = kt + 8192;
         slot = slot + 1 == NBUF ? 0 : slot + 1;
+        if (wave_live) {                                          // (a wave whose 32 queries all lie beyond T only stages and synchronises)
         f32x16 s[2], pp[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -739,7 +742,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd32_kernel(const AttnP P) {
         }
         // ---- probabilities against the current reference max; the row sum is the overflow test
         const bool edge = km != nullptr || (t + 1) * BT > P.T;    // wave-uniform
-        float tsum = 0.f, tsum2 = 0.f;
+        float tsum = 0.f;
         {
             const float nb = -m;
 #pragma unroll
@@ -748,11 +751,9 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd32_kernel(const AttnP P) {
                 for (int i = 0; i < 16; ++i) {
                     const float p = fast_exp2(__builtin_fmaf(s[kb][i], P.scale, nb));
                     pp[kb][i] = p;
-                    if (i & 1) asm("v_add_f32 %0, %1, %2" : "=v"(tsum2) : "v"(tsum2), "v"(p));      // (plain adds: the vectoriser would pack them
-                    else asm("v_add_f32 %0, %1, %2" : "=v"(tsum) : "v"(tsum), "v"(p));            //  into v_pk_add_f32, which issues slower)
-                }
-        }
-        tsum += tsum2;
+                    tsum += p;       // ONE dependent chain on purpose: independent partial sums get packed into v_pk_add_f32, which issues
+                }                    // slower than two plain adds, and a wave issues at most one vector instruction per ~4 cycles anyway.
+        }                            // (No inline asm here: hipcc pads no transcendental -> VALU hazard for an asm consumer.)
         if (edge || __any(!(tsum <= F32_SUM_LIMIT))) {            // (also true for inf / NaN: the first tile, m = -inf)
             float mt = -INFINITY;
 #pragma unroll
@@ -820,6 +821,11 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd32_kernel(const AttnP P) {
             }
         }
         hbase += (uint32_t)(BT / 4) * HC1;
+        }
+        // Tile t+2 goes into the slot tile t-1 was read from (free since this iteration's barrier).  Issued at the END of the body:
+        // the transposed-read builtin carries no alias information, so hipcc drains every pending LDS-DMA (vmcnt(0)) in front of the
+        // first V read that follows one -- placed here, that wait falls in the NEXT iteration, a whole K phase + softmax after the issue.
+        issue(t + 2, nslot);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the dummy DMAs past the last tile
     // ---- epilogue: the two half-waves of a query hold complementary halves of its row sum
@@ -827,16 +833,24 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd32_kernel(const AttnP P) {
         auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l), __float_as_uint(l), false, false);
         l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
     }
-    if (q_ok) {
-        const float inv = P.pscale / l;                           // 1/(1-p) of the dropout is applied here, once
-        bf16* op = reinterpret_cast<bf16*>(P.out) + ((long long)b * P.T + q) * P.ld_o + h * DH + 4 * hh;
+    // Registers 4 mq .. 4 mq + 3 hold head-dim columns 32 db + 8 mq + 4 half + 0..3 of the lane's query: 8 bytes of bf16 per (db, mq), the
+    // other half-wave holding the adjacent 8.  One permlane32 swap per pair (mq, mq + 1) and dword leaves lanes 0..31 with columns
+    // 8 mq .. 8 mq + 7 and lanes 32..63 with 8 (mq + 1) .. + 7: 16-byte stores, half as many store instructions.
+    const float inv = P.pscale / l;                               // 1/(1-p) of the dropout is applied here, once
+    bf16* op = reinterpret_cast<bf16*>(P.out) + ((long long)b * P.T + q) * P.ld_o + h * DH + 8 * hh;
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+    for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int mq = 0; mq < 4; ++mq)                        // registers 4 mq .. 4 mq + 3 = head-dim columns 32 db + 8 mq + 4 half + 0..3
-                store4<bf16>(op + 32 * db + 8 * mq, o[db][4 * mq] * inv, o[db][4 * mq + 1] * inv, o[db][4 * mq + 2] * inv, o[db][4 * mq + 3] * inv);
-        if (hh == 0) P.lse[(long long)bh * P.T + q] = m + log2f(l);       // log2-domain log-sum-exp
-    }
+        for (int mq = 0; mq < 4; mq += 2) {
+            u32x2 a = __builtin_bit_cast(u32x2, (bf16x4){(bf16)(o[db][4 * mq] * inv), (bf16)(o[db][4 * mq + 1] * inv), (bf16)(o[db][4 * mq + 2] * inv), (bf16)(o[db][4 * mq + 3] * inv)});
+            u32x2 c = __builtin_bit_cast(u32x2, (bf16x4){(bf16)(o[db][4 * mq + 4] * inv), (bf16)(o[db][4 * mq + 5] * inv), (bf16)(o[db][4 * mq + 6] * inv), (bf16)(o[db][4 * mq + 7] * inv)});
+            auto x0 = __builtin_amdgcn_permlane32_swap(a[0], c[0], false, false);      // vdst = group mq, src = group mq + 1
+            auto x1 = __builtin_amdgcn_permlane32_swap(a[1], c[1], false, false);
+            // lanes 0..31: {own a | upper's a} = columns 8 mq + 0..7;  lanes 32..63: {lower's c | own c} = columns 8 (mq + 1) + 0..7
+            const u32x4 v = {x0[0], x1[0], x0[1], x1[1]};
+            if (q_ok) *reinterpret_cast<u32x4*>(op + 32 * db + 8 * mq) = v;
+        }
+    if (q_ok && hh == 0) P.lse[(long long)bh * P.T + q] = m + log2f(l);       // log2-domain log-sum-exp
 }
 
 void set_softmax_params(AttnP& P, float scale, float p, uint32_t seed) {
@@ -866,7 +880,8 @@ int check_common(const char* what, int dtype, int B, int T_, int H, long long ld
 // (+ 100 * W: the 4 x 1 geometry compiled for at least W = 4 or 5 waves per SIMD, i.e. a 128 / 96 register cap)
 #define A8_ATTN_LAUNCH(KERN, key, what)                                                                                       \
     {                                                                                                                          \
-        const int geo = g_a8_tuning[key] % 100, mw = g_a8_tuning[key] / 100, nw = geo / 10, grp = geo % 10, rows = nw * grp * 16; \
+        const int tun = g_a8_tuning[key] >= 10 ? g_a8_tuning[key] : 41;            /* (< 10 selects the 32x32 16-bit forward kernel; f32 data: 4 x 1) */ \
+        const int geo = tun % 100, mw = tun / 100, nw = geo / 10, grp = geo % 10, rows = nw * grp * 16; \
         const dim3 grid(cdiv(T_, rows) * B * H), blk(nw * 64);                                                                 \
         if (dtype == A8_BF16) {                                                                                                \
             if (geo == 41 && mw == 5) hipLaunchKernelGGL((KERN<bf16, 4, 1, 5>), grid, blk, 0, s, P);                          \
@@ -894,7 +909,8 @@ extern "C" int a8_attn_fwd(int dtype, const void* q, const void* k, const void* 
     if (dtype == A8_BF16 && g_a8_tuning[2] < 10) {
         // 32 queries per wave, 4 or 5 waves per block: whichever wastes fewer wave slots on the tail of T (781 = 24.4 x 32 -> 5 x 5 waves)
         const int units = cdiv(T_, 32);
-        const int nw = g_a8_tuning[2] == 4 || g_a8_tuning[2] == 5 ? g_a8_tuning[2] : (cdiv(units, 5) * 5 < cdiv(units, 4) * 4 ? 5 : 4);
+        const int nw = g_a8_tuning[2] == 5 ? 5 : 4;       // (4 measured faster than 5 even at T = 781 = 24.4 x 32, where 5 x 5 waves waste none)
+        (void)units;
         const dim3 grid(cdiv(T_, 32 * nw) * B * H);
         if (nw == 5) hipLaunchKernelGGL(attn_fwd32_kernel<5>, grid, dim3(320), 0, s, P);
         else hipLaunchKernelGGL(attn_fwd32_kernel<4>, grid, dim3(256), 0, s, P);

@@ -662,3 +662,50 @@ def test_ctc_greedy_decode_matches_host(dtype):
     m_host = Cc.ctc_metrics(lp.float(), target, sample_lens, vocab)
     m_dev = Cc.ctc_metrics(lp.cuda(), target.cuda(), sample_lens.cuda(), vocab)
     assert m_host == m_dev and m_host["c_total"] == B * 30
+
+
+# ------------------------------------------------------------------ in-kernel Gumbel noise, conv weight-gradient fold, memset
+def test_vq_select_draws_its_own_gumbel_noise():
+    """F.gumbel_softmax adds -log(E), E ~ Exp(1) (torch/nn/functional.py:2163; audio8/wav2vec2.py:556).  With gumbel_gen the select kernel
+    draws that noise itself from a counter hash: check its distribution (mean = Euler's gamma, variance = pi^2 / 6, CDF at three
+    points), that the stored noise is what the argmax used, and that the seed changes it."""
+    from audio8_amd import kernels as K
+    R, V = 2944 * 2, 320
+    logits = rnd((R, V), 3).cuda()
+    g = torch.empty_like(logits)
+    codes, avg = K.vq_select(logits, None, 0.5, gumbel_gen=g, seed=123)
+    gc = g.double().cpu()
+    assert abs(gc.mean().item() - 0.5772) < 5e-3 and abs(gc.var().item() - 1.6449) < 2e-2
+    for x in (-1.0, 0.0, 1.5):                                   # CDF of Gumbel(0, 1): exp(-exp(-x))
+        assert abs((gc < x).double().mean().item() - float(np.exp(-np.exp(-x)))) < 3e-3
+    assert torch.equal(codes.cpu().long(), (logits + g).argmax(-1).cpu())
+    codes2, avg2 = K.vq_select(logits, g, 0.5)                   # handing the same noise back in reproduces the codes
+    assert torch.equal(codes, codes2) and torch.equal(avg, avg2)
+    g2 = torch.empty_like(logits)
+    K.vq_select(logits, None, 0.5, gumbel_gen=g2, seed=124)
+    assert (g2 != g).float().mean().item() > 0.99
+    # neighbouring elements are uncorrelated
+    assert abs(float(np.corrcoef(gc[:, :-1].reshape(-1)[:200000].numpy(), gc[:, 1:].reshape(-1)[:200000].numpy())[0, 1])) < 0.01
+
+
+@pytest.mark.parametrize("k", [2, 3])
+def test_conv_wgrad_fold(k):
+    from audio8_amd import kernels as K
+    co, cin = 512, 512
+    dw2 = rnd((co, k * cin), 4).cuda()
+    grad0 = rnd((co, cin, k), 5).cuda()
+    grad = grad0.clone()
+    K.conv_wgrad_fold_(dw2.clone(), grad, co, cin, k)
+    want = grad0 + dw2.view(co, k, cin).permute(0, 2, 1)
+    assert torch.equal(grad, want)
+    buf = dw2.clone()
+    K.conv_wgrad_fold_(buf, grad, co, cin, k)
+    assert float(buf.abs().max()) == 0.0                          # cleared behind the read: the caller keeps it across steps
+
+
+def test_zeros_helper():
+    from audio8_amd import kernels as K
+    t = K.zeros((3, 1001), torch.float32, "cuda")
+    assert t.shape == (3, 1001) and float(t.abs().max()) == 0.0
+    e = K.zeros((0, 5), torch.bfloat16, "cuda")
+    assert e.numel() == 0
