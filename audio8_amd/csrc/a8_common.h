@@ -108,10 +108,18 @@ A8_DEV uint32_t a8_mix(uint32_t seed, uint32_t idx) {
     return h;
 }
 
-// keep-mask: true with probability (1 - p); thr = p * 2^32
-A8_DEV bool a8_keep(uint32_t seed, uint32_t stream, uint32_t idx, uint32_t thr) {
-    return a8_hash(seed, stream, idx) >= thr;
+// Activation dropout (LayerNorm inputs, feature / input dropout): the keep decisions of the 8 consecutive elements of 16-byte chunk
+// `c8` come from TWO hash words, a 7-bit field per element (the drop probability is realised in 1/128 steps, thr7 = round(128 p), and the
+// survivors are scaled by 128 / (128 - thr7): unbiased for the realised rate) -- a quarter of the hash work of one word per element.
+// Bit 8 e + 7 of the returned word t[e >> 2] is 1 when element e is KEPT: (field | 0x80) - thr7 borrows out of bit 7 exactly when field < thr7.
+struct Keep8 { uint32_t t0, t1; };
+A8_DEV Keep8 a8_keep8(uint32_t seed, uint32_t stream, uint32_t c8, uint32_t thr7x4 /* thr7 * 0x01010101 */) {
+    Keep8 k;
+    k.t0 = ((a8_hash(seed, stream, 2u * c8) & 0x7F7F7F7Fu) | 0x80808080u) - thr7x4;
+    k.t1 = ((a8_hash(seed, stream, 2u * c8 + 1u) & 0x7F7F7F7Fu) | 0x80808080u) - thr7x4;
+    return k;
 }
+A8_DEV bool a8_kept(const Keep8& k, int e) { return (((e < 4 ? k.t0 : k.t1) >> (8 * (e & 3) + 7)) & 1u) != 0u; }
 
 // ---------------------------------------------------------------- vector load/store of 16 bytes
 template <typename T> struct Vec16;                 // 16-byte chunk of T

@@ -743,7 +743,8 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd32_kernel(const AttnP P) {
         // ---- probabilities against the current reference max; the row sum is the overflow test
         const bool edge = km != nullptr || (t + 1) * BT > P.T;    // wave-uniform
         float tsum = 0.f;
-        {
+        bool rescale = edge || t == 0;                            // (the first tile has no reference max yet: straight to the rescale path)
+        if (!rescale) {
             const float nb = -m;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -753,8 +754,10 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd32_kernel(const AttnP P) {
                     pp[kb][i] = p;
                     tsum += p;       // ONE dependent chain on purpose: independent partial sums get packed into v_pk_add_f32, which issues
                 }                    // slower than two plain adds, and a wave issues at most one vector instruction per ~4 cycles anyway.
-        }                            // (No inline asm here: hipcc pads no transcendental -> VALU hazard for an asm consumer.)
-        if (edge || __any(!(tsum <= F32_SUM_LIMIT))) {            // (also true for inf / NaN: the first tile, m = -inf)
+                                     // (No inline asm here: hipcc pads no transcendental -> VALU hazard for an asm consumer.)
+            rescale = __any(!(tsum <= F32_SUM_LIMIT));            // (also true for inf / NaN)
+        }
+        if (rescale) {
             float mt = -INFINITY;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)

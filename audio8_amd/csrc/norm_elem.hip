@@ -33,11 +33,14 @@ template <> A8_DEV void store8<float>(float* p, const float (&v)[8]) {
 
 constexpr int MAXC = 3;   // chunks of 8 columns per lane -> cols <= 1536
 
-struct Drop { float scale; uint32_t thr, seed, stream; };
+struct Drop { float scale; uint32_t thr, seed, stream; };     // thr = thr7 * 0x01010101 (0 = dropout off), see a8_keep8
 static Drop make_drop(float p, uint32_t seed, uint32_t stream) {
     Drop d;
-    d.scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
-    d.thr = p > 0.f ? (uint32_t)((double)p * 4294967296.0) : 0u;
+    uint32_t t7 = p > 0.f ? (uint32_t)(p * 128.0f + 0.5f) : 0u;       // the drop probability is realised as t7 / 128
+    if (p > 0.f && t7 == 0) t7 = 1;
+    if (t7 > 127u) t7 = 127u;
+    d.scale = t7 ? 128.0f / (128.0f - (float)t7) : 1.0f;
+    d.thr = t7 * 0x01010101u;
     d.seed = seed; d.stream = stream;
     return d;
 }
@@ -69,8 +72,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
                 const long long off = (long long)row * cols + ch * 8;
                 load8(x + off, v[c]);
                 if (dr.thr) {
+                    const Keep8 kp = a8_keep8(dr.seed, dr.stream, (uint32_t)(off >> 3), dr.thr);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) v[c][i] = a8_keep(dr.seed, dr.stream, (uint32_t)(off + i), dr.thr) ? v[c][i] * dr.scale : 0.f;
+                    for (int i = 0; i < 8; ++i) v[c][i] = a8_kept(kp, i) ? v[c][i] * dr.scale : 0.f;
                 }
                 if (res) {
                     float r[8];
@@ -165,24 +169,20 @@ __global__ __launch_bounds__(NW * 64, MC <= 2 ? 4 : 2) void ln_bwd_kernel(const 
     for (int row = blockIdx.x * NW + (threadIdx.x >> 6); row < rows; row += gridDim.x * NW) {
         const float mu = mean[row], rs = rstd[row];
         float xh[MC][8], g[MC][8];
-        uint32_t keep[MC];                       // the dropout mask of this row's chunks: hashed once, used for x and for dx
+        Keep8 keep[MC];                          // the dropout mask of this row's chunks: hashed once, used for x and for dx
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int c = 0; c < MC; ++c) {
             const int ch = lane + 64 * c;
-            keep[c] = 0xFFu;
+            keep[c] = Keep8{0u, 0u};
             if (ch < nch) {
                 const long long off = (long long)row * cols + ch * 8;
                 float v[8], gm[8];
                 load8(x + off, v);
                 if (dr.thr) {
-                    keep[c] = 0;
+                    keep[c] = a8_keep8(dr.seed, dr.stream, (uint32_t)(off >> 3), dr.thr);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const bool kp = a8_keep(dr.seed, dr.stream, (uint32_t)(off + i), dr.thr);
-                        keep[c] |= (kp ? 1u : 0u) << i;
-                        v[i] = kp ? v[i] * dr.scale : 0.f;
-                    }
+                    for (int i = 0; i < 8; ++i) v[i] = a8_kept(keep[c], i) ? v[i] * dr.scale : 0.f;
                 }
                 if (res) {
                     float r[8];
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(NW * 64, MC <= 2 ? 4 : 2) void ln_bwd_kernel(const 
                 if (dres) store8(dres + off, o);
                 if (dr.thr) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) o[i] = ((keep[c] >> i) & 1u) ? o[i] * dr.scale : 0.f;
+                    for (int i = 0; i < 8; ++i) o[i] = a8_kept(keep[c], i) ? o[i] * dr.scale : 0.f;
                 }
                 if (dx) store8(dx + off, o);
                 if (dbias) {
@@ -375,8 +375,9 @@ __global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, long 
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
         float v[8];
         load8(x + i * 8, v);
+        const Keep8 kp = a8_keep8(dr.seed, dr.stream, (uint32_t)i, dr.thr);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = a8_keep(dr.seed, dr.stream, (uint32_t)(i * 8 + j), dr.thr) ? v[j] * dr.scale : 0.f;
+        for (int j = 0; j < 8; ++j) v[j] = a8_kept(kp, j) ? v[j] * dr.scale : 0.f;
         store8(y + i * 8, v);
     }
 }

@@ -38,7 +38,9 @@ __global__ __launch_bounds__(64 * VQ_ROWS) void vq_select_kernel(const float* __
                 if (gumbel) y += gumbel[(long long)row * V + v];
                 else if (gumbel_gen) {
                     const uint32_t h = a8_hash(seed, 0x6756u, (uint32_t)((long long)row * V + v));
-                    const float u = ((float)(h >> 8) + 0.5f) * 5.9604644775390625e-08f;          // uniform in (0, 1), 24 bits
+                    // uniform in (0, 1) from 23 bits: (k + 0.5) / 2^23 is exact in f32 for every k < 2^23 -- with 24 bits the top value
+                    // rounds to 1.0, whose noise is -log(-log 1) = +inf (an inf - inf = NaN in the straight-through softmax of backward)
+                    const float u = ((float)(h >> 9) + 0.5f) * 1.1920928955078125e-07f;
                     const float g = -__logf(-__logf(u));
                     gumbel_gen[(long long)row * V + v] = g;
                     y += g;
@@ -59,7 +61,8 @@ __global__ __launch_bounds__(64 * VQ_ROWS) void vq_select_kernel(const float* __
         for (int j = 0; j < VMAX_PER_LANE; ++j) { x[j] = (lane + 64 * j < V) ? __expf(x[j] - mx) : 0.f; s += x[j]; }
         s = wave_sum(s);
         inv = 1.0f / ((float)R * s);
-        if (lane == 0) codes[row] = bi;
+        if (lane == 0) codes[row] = (unsigned)bi < (unsigned)V ? bi : 0;      // (all-NaN logits compare false everywhere: never hand an out-of-range
+                                                                               //  index to the codebook gather)
     }
 #pragma unroll
     for (int j = 0; j < VMAX_PER_LANE; ++j)

@@ -217,6 +217,17 @@ def _target(p):
     return None
 
 
+# The first gradient written into a parameter's slot of a clean flat buffer may be STORED instead of atomically added (f32 atomics
+# run at ~1.3 TB/s chip-wide: 64 KB per 128 x 128 tile is ~13 us of a weight-gradient block's life; a plain row store ~2 us).
+# GRAD_FIRST_TOUCH(p) -> True when p has received nothing since the last zero_grad (set by trainer.Stepper; None: always accumulate).
+GRAD_FIRST_TOUCH = None
+WGRAD_STORE_FIRST = True      # A/B knob
+
+
+def _first_touch(*ps):
+    return WGRAD_STORE_FIRST and GRAD_FIRST_TOUCH is not None and all(GRAD_FIRST_TOUCH(p) for p in ps)
+
+
 def _ready(*ps):
     if GRAD_READY_HOOK is not None:
         for p in ps:
@@ -261,9 +272,13 @@ class WgradGroup:
         items, self.items = self.items, []
         extra, self.extra = self.extra, []
 
+        # (decided NOW, on the autograd thread, before the gradients are reported ready: no split-K in the grouped launch, so a
+        # first-touch product may overwrite its zero-filled target)
+        acc = [not _first_touch(*params) for params, *_ in items]
+
         def run():
             if items:
-                K.gemm_grouped(L.TN, [(dy, x, n_out, n_in, m, dict(out=tgt, accumulate=True)) for _, tgt, dy, x, n_out, n_in, m in items])
+                K.gemm_grouped(L.TN, [(dy, x, n_out, n_in, m, dict(out=tgt, accumulate=a)) for (_, tgt, dy, x, n_out, n_in, m), a in zip(items, acc)])
                 for params, *_ in items:
                     _ready(*params)
             for fn in extra:

