@@ -61,7 +61,7 @@ ARGTYPES = {
     "a8_vq_bwd": [C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "a8_contrastive_fwd": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "a8_contrastive_bwd": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
-    "a8_ctc_pack_targets": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "a8_ctc_pack_targets": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "a8_ctc_fwd_bwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "a8_log_softmax_fwd": [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "a8_log_softmax_bwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
@@ -88,7 +88,7 @@ class GemmDesc(C.Structure):
 
 class EncoderLayerDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("dtype", "B", "T", "H", "d", "dff")] + [("p", C.c_float), ("eps", C.c_float)] + \
-               [(n, C.c_uint32) for n in ("seed_attn", "seed1", "seed2")] + \
+               [(n, C.c_uint32) for n in ("seed_attn", "seed1", "seed2")] + [("b0", C.c_int)] + \
                [(n, C.c_void_p) for n in ("x", "keymask", "wqkv", "wo", "w1", "w2", "bqkv", "bo", "b1", "b2", "g1", "be1", "g2", "be2",
                                           "qkv", "o", "ao", "x1", "z1", "h", "f", "x2", "lse", "mean2", "rstd2", "mean1", "rstd1")]
 

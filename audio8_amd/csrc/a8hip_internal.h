@@ -6,3 +6,9 @@
 // [5] min 256 x 256 tiles for the pipelined NT GEMM (0 = off), [6] posconv wgrad loop splits, [9] conv layer 0 on the VALU,
 // [14] min M for the asymmetric-ring NT GEMM; the rest spare
 extern int g_a8_tuning[32];
+
+// forward entry points with a dropout-counter origin (used by composite.hip for calls on a slice of the batch)
+int a8i_layernorm_fwd(int dtype, const void* x, const void* res, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                      int rows, int cols, float eps, float p, uint32_t seed, uint32_t rng_stream, int64_t rng_elem0, void* stream);
+int a8i_attn_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* keymask, int B, int T, int H,
+                 int64_t ld_qkv, int64_t ld_o, float scale, float p, uint32_t seed, int bh0, void* stream);

@@ -199,6 +199,8 @@ struct AttnP {
     float lazy;                    // raise the running max only past this margin (log2 units)
     uint32_t thr, seed;            // thr: 8-bit keep threshold (0 = dropout off)
     int Th;                        // key quads per query row = ceil(T / 4)
+    int bh0;                       // forward only: (batch, head) index of this call's first pair in the LOGICAL batch the dropout counters
+                                   // belong to (a call on utterances [b0, b0 + B) of a larger batch passes b0 * H: same mask as the whole-batch call)
 };
 
 constexpr uint32_t HC1 = 0x9E3779B1u, HC2 = 0x2C1B3C6Du;
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(NW * 64, MW) void attn_fwd_kernel(const AttnP P) {
         qi[j] = blk * BQ + (wv * G + j) * 16 + li;
         qf[j].load(qb + (long long)qi[j] * P.ld_qkv, qi[j] < P.T, lane);
         m[j] = -INFINITY; l[j] = 0.f;
-        hb[j] = (pair_base(bh, P.T, P.Th, qi[j]) + (uint32_t)g + P.seed) * HC1;
+        hb[j] = (pair_base(bh + P.bh0, P.T, P.Th, qi[j]) + (uint32_t)g + P.seed) * HC1;
 #pragma unroll
         for (int i = 0; i < 4; ++i) oacc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
@@ -715,7 +717,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd32_kernel(const AttnP P) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
     float m = -INFINITY, l = 0.f;
-    uint32_t hbase = (pair_base(bh, P.T, P.Th, q) + (uint32_t)hh + P.seed) * HC1;       // word of key quad 2 mq + half of key block 0, tile 0
+    uint32_t hbase = (pair_base(bh + P.bh0, P.T, P.Th, q) + (uint32_t)hh + P.seed) * HC1;       // word of key quad 2 mq + half of key block 0, tile 0
     const int kkey = (r >> 1) & 7;                                                       // K row read: row 32 kb + r, chunk (2 ks + half) ^ kkey
     const int vlane = hh * 512 + ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
     int kaddr[4];
@@ -901,13 +903,14 @@ int check_common(const char* what, int dtype, int B, int T_, int H, long long ld
 
 }  // namespace
 
-extern "C" int a8_attn_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* keymask,
-                           int B, int T_, int H, int64_t ld_qkv, int64_t ld_o, float scale, float p, uint32_t seed, void* stream) {
+int a8i_attn_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* keymask,
+                 int B, int T_, int H, int64_t ld_qkv, int64_t ld_o, float scale, float p, uint32_t seed, int bh0, void* stream) {
     if (int e = check_common("a8_attn_fwd", dtype, B, T_, H, ld_qkv, ld_o, p)) return e;
     AttnP P = {};
     P.q = (const char*)q; P.k = (const char*)k; P.v = (const char*)v; P.out = (char*)o; P.lse = lse; P.keymask = keymask;
     P.B = B; P.T = T_; P.H = H; P.ld_qkv = ld_qkv; P.ld_o = ld_o;
     set_softmax_params(P, scale, p, seed);
+    P.bh0 = bh0;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == A8_BF16 && g_a8_tuning[2] < 10) {
         // 32 queries per wave, 4 or 5 waves per block: whichever wastes fewer wave slots on the tail of T (781 = 24.4 x 32 -> 5 x 5 waves)
@@ -921,6 +924,11 @@ extern "C" int a8_attn_fwd(int dtype, const void* q, const void* k, const void* 
     }
     A8_ATTN_LAUNCH(attn_fwd_kernel, 2, "a8_attn_fwd")
     return a8_check_launch("a8_attn_fwd");
+}
+
+extern "C" int a8_attn_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* keymask,
+                           int B, int T_, int H, int64_t ld_qkv, int64_t ld_o, float scale, float p, uint32_t seed, void* stream) {
+    return a8i_attn_fwd(dtype, q, k, v, o, lse, keymask, B, T_, H, ld_qkv, ld_o, scale, p, seed, 0, stream);
 }
 
 extern "C" int a8_attn_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,

@@ -32,24 +32,27 @@ a8_gemm_desc nt_desc(int dtype, const void* A, const void* B, void* C, int M, in
 //   h = gelu(z1 = x1 W1^T + b1);  f = h W2^T + b2;  x2 = LN1(x1 + drop(f))
 extern "C" int a8_encoder_layer_fwd(const a8_encoder_layer_desc* e, void* stream) {
     A8_REQUIRE(e != nullptr, "a8_encoder_layer_fwd: null descriptor");
-    A8_REQUIRE(e->B > 0 && e->T > 0 && e->H > 0 && e->d == e->H * 64 && e->dff > 0, "a8_encoder_layer_fwd: bad sizes B=%d T=%d H=%d d=%d dff=%d",
-               e->B, e->T, e->H, e->d, e->dff);
+    A8_REQUIRE(e->B > 0 && e->T > 0 && e->H > 0 && e->d == e->H * 64 && e->dff > 0 && e->b0 >= 0, "a8_encoder_layer_fwd: bad sizes B=%d T=%d H=%d d=%d dff=%d b0=%d",
+               e->B, e->T, e->H, e->d, e->dff, e->b0);
     const int M = e->B * e->T, d = e->d, esz = e->dtype == A8_BF16 ? 2 : 4;
     a8_gemm_desc g = nt_desc(e->dtype, e->x, e->wqkv, e->qkv, M, 3 * d, d, e->bqkv);
     if (int rc = a8_gemm(&g, stream)) return rc;
     const char* q = (const char*)e->qkv;
-    if (int rc = a8_attn_fwd(e->dtype, q, q + (size_t)d * esz, q + (size_t)2 * d * esz, e->o, e->lse, e->keymask, e->B, e->T, e->H, 3 * d, d,
-                             1.0f / std::sqrt((float)(d / e->H)), e->p, e->seed_attn, stream))
+    // e->b0: this call covers utterances [b0, b0 + B) of a larger logical batch (the two halves of a batch on two streams): the
+    // dropout counters start there, so forward draws the masks the whole-batch backward regenerates
+    if (int rc = a8i_attn_fwd(e->dtype, q, q + (size_t)d * esz, q + (size_t)2 * d * esz, e->o, e->lse, e->keymask, e->B, e->T, e->H, 3 * d, d,
+                              1.0f / std::sqrt((float)(d / e->H)), e->p, e->seed_attn, e->b0 * e->H, stream))
         return rc;
     g = nt_desc(e->dtype, e->o, e->wo, e->ao, M, d, d, e->bo);
     if (int rc = a8_gemm(&g, stream)) return rc;
-    if (int rc = a8_layernorm_fwd(e->dtype, e->ao, e->x, e->g2, e->be2, e->x1, e->mean2, e->rstd2, M, d, e->eps, e->p, e->seed1, 3, stream)) return rc;
+    const int64_t rng0 = (int64_t)e->b0 * e->T * d;
+    if (int rc = a8i_layernorm_fwd(e->dtype, e->ao, e->x, e->g2, e->be2, e->x1, e->mean2, e->rstd2, M, d, e->eps, e->p, e->seed1, 3, rng0, stream)) return rc;
     g = nt_desc(e->dtype, e->x1, e->w1, e->h, M, e->dff, d, e->b1);
     g.act = A8_ACT_GELU; g.zout = e->z1;
     if (int rc = a8_gemm(&g, stream)) return rc;
     g = nt_desc(e->dtype, e->h, e->w2, e->f, M, d, e->dff, e->b2);
     if (int rc = a8_gemm(&g, stream)) return rc;
-    return a8_layernorm_fwd(e->dtype, e->f, e->x1, e->g1, e->be1, e->x2, e->mean1, e->rstd1, M, d, e->eps, e->p, e->seed2, 4, stream);
+    return a8i_layernorm_fwd(e->dtype, e->f, e->x1, e->g1, e->be1, e->x2, e->mean1, e->rstd1, M, d, e->eps, e->p, e->seed2, 4, rng0, stream);
 }
 
 // The data-gradient chain of the same layer's backward up to and including the attention core, on one stream (the weight gradients

@@ -213,45 +213,45 @@ __global__ __launch_bounds__(64) void ctc_greedy_kernel(const T* __restrict__ lp
 // every entry that is neither PAD nor EOS, row-major) plus the per-utterance offsets (exclusive prefix sum of target_lengths).
 // One block: wave w counts / compacts rows w, w + 4, ...; nothing goes through the host.
 __global__ __launch_bounds__(256) void ctc_pack_kernel(const long long* __restrict__ targets, const int32_t* __restrict__ tlen,
-                                                       int32_t* __restrict__ flat, int32_t* __restrict__ off, int B, int S, int pad, int eos) {
-    extern __shared__ int cnt[];             // cnt[B]: valid entries per row, then their exclusive prefix
+                                                       int32_t* __restrict__ flat, int32_t* __restrict__ off, int32_t* __restrict__ status,
+                                                       int B, int S, int pad, int eos) {
+    extern __shared__ int cnt[];             // cnt[B]: label-list offset of each row (exclusive prefix of target_lengths)
+    __shared__ int s_bad, s_max;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int b = w; b < B; b += 4) {
-        int c = 0;
-        for (int s0 = 0; s0 < S; s0 += 64) {
-            const int s = s0 + lane;
-            const long long v = s < S ? targets[(long long)b * S + s] : pad;
-            c += __popcll(__ballot(s < S && v != pad && v != eos));
-        }
-        if (lane == 0) cnt[b] = c;
-    }
-    __syncthreads();
     if (threadIdx.x == 0) {
-        int run = 0, lrun = 0;
-        for (int b = 0; b < B; ++b) { const int c = cnt[b]; cnt[b] = run; run += c; off[b] = lrun; lrun += tlen[b]; }
+        int lrun = 0, mx = 0;
+        for (int b = 0; b < B; ++b) { cnt[b] = lrun; off[b] = lrun; lrun += tlen[b]; mx = max(mx, tlen[b]); }
         off[B] = lrun;
+        s_bad = 0; s_max = mx;
     }
     __syncthreads();
+    // Every row lands at ITS offset and is cut at target_lengths[b]: a row whose PAD/EOS count disagrees with its stated length can
+    // no longer shift the labels of the rows behind it (it is counted in status[0], which the host checks one call later).
     for (int b = w; b < B; b += 4) {
-        int pos = cnt[b];
+        int pos = 0;
+        const int base = cnt[b], lim = tlen[b];
         for (int s0 = 0; s0 < S; s0 += 64) {
             const int s = s0 + lane;
             const long long v = s < S ? targets[(long long)b * S + s] : pad;
             const bool keep = s < S && v != pad && v != eos;
             const unsigned long long m = __ballot(keep);
-            if (keep) flat[pos + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)v;
+            const int at = pos + __popcll(m & ((1ull << lane) - 1ull));
+            if (keep && at < lim) flat[base + at] = (int32_t)v;
             pos += __popcll(m);
         }
+        if (lane == 0 && pos != lim) atomicAdd(&s_bad, 1);
     }
+    __syncthreads();
+    if (threadIdx.x == 0 && status) { status[0] = s_bad; status[1] = s_max; }
 }
 
 }  // namespace
 
-extern "C" int a8_ctc_pack_targets(const int64_t* targets, const int32_t* target_lengths, int32_t* flat, int32_t* tgt_off,
+extern "C" int a8_ctc_pack_targets(const int64_t* targets, const int32_t* target_lengths, int32_t* flat, int32_t* tgt_off, int32_t* status,
                                    int B, int S, int pad, int eos, void* stream) {
     A8_REQUIRE(B >= 1 && S >= 0 && B <= 8192, "a8_ctc_pack_targets: bad sizes B=%d S=%d", B, S);
     hipLaunchKernelGGL(ctc_pack_kernel, dim3(1), dim3(256), sizeof(int) * B, (hipStream_t)stream, (const long long*)targets, target_lengths,
-                       flat, tgt_off, B, S, pad, eos);
+                       flat, tgt_off, status, B, S, pad, eos);
     return a8_check_launch("a8_ctc_pack_targets");
 }
 

@@ -52,7 +52,7 @@ template <typename T, int MC>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
-                                                     int rows, int cols, float eps, Drop dr) {
+                                                     int rows, int cols, float eps, Drop dr, long long rng0) {
     const int lane = threadIdx.x & 63, nch = cols >> 3;
     const float inv = 1.0f / (float)cols;
     float gm[MC][8], bt[MC][8];
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
                 const long long off = (long long)row * cols + ch * 8;
                 load8(x + off, v[c]);
                 if (dr.thr) {
-                    const Keep8 kp = a8_keep8(dr.seed, dr.stream, (uint32_t)(off >> 3), dr.thr);
+                    const Keep8 kp = a8_keep8(dr.seed, dr.stream, (uint32_t)((off + rng0) >> 3), dr.thr);     // rng0: see a8i_layernorm_fwd
 #pragma unroll
                     for (int i = 0; i < 8; ++i) v[c][i] = a8_kept(kp, i) ? v[c][i] * dr.scale : 0.f;
                 }
@@ -531,17 +531,25 @@ int grid_for(long long work, int per_block) {
         else return a8_set_error(A8_ERR_ARG, "bad dtype %d", (dtype));     \
     } while (0)
 
-extern "C" int a8_layernorm_fwd(int dtype, const void* x, const void* res, const float* gamma, const float* beta, void* y,
-                                float* mean, float* rstd, int rows, int cols, float eps, float p, uint32_t seed, uint32_t rng_stream, void* stream) {
+// rng_elem0: element offset of row 0 in the LOGICAL activation the dropout counters belong to (a multiple of 8): a call on rows
+// [r0, r0 + rows) of a larger batch passes r0 * cols and draws exactly the mask the whole-batch call (and its backward) draws there.
+int a8i_layernorm_fwd(int dtype, const void* x, const void* res, const float* gamma, const float* beta, void* y,
+                      float* mean, float* rstd, int rows, int cols, float eps, float p, uint32_t seed, uint32_t rng_stream, int64_t rng_elem0,
+                      void* stream) {
     A8_REQUIRE(cols % 8 == 0 && cols <= MAXC * 512, "a8_layernorm_fwd: cols=%d must be a multiple of 8 and <= %d", cols, MAXC * 512);
     A8_REQUIRE(p >= 0.f && p < 1.f, "a8_layernorm_fwd: bad dropout p");
+    A8_REQUIRE(rng_elem0 % 8 == 0, "a8_layernorm_fwd: the counter offset must be a multiple of 8");
     if (rows == 0) return A8_OK;
     const Drop dr = make_drop(p, seed, rng_stream);
 #define LN_FWD(MC) DISPATCH_T(dtype, hipLaunchKernelGGL((ln_fwd_kernel<T, MC>), dim3(grid_for(rows, 4)), dim3(256), 0, (hipStream_t)stream, \
-                                         (const T*)x, (const T*)res, gamma, beta, (T*)y, mean, rstd, rows, cols, eps, dr))
+                                         (const T*)x, (const T*)res, gamma, beta, (T*)y, mean, rstd, rows, cols, eps, dr, (long long)rng_elem0))
     if (cols <= 512) LN_FWD(1); else if (cols <= 1024) LN_FWD(2); else LN_FWD(MAXC);
 #undef LN_FWD
     return a8_check_launch("a8_layernorm_fwd");
+}
+extern "C" int a8_layernorm_fwd(int dtype, const void* x, const void* res, const float* gamma, const float* beta, void* y,
+                                float* mean, float* rstd, int rows, int cols, float eps, float p, uint32_t seed, uint32_t rng_stream, void* stream) {
+    return a8i_layernorm_fwd(dtype, x, res, gamma, beta, y, mean, rstd, rows, cols, eps, p, seed, rng_stream, 0, stream);
 }
 
 extern "C" int a8_layernorm_bwd(int dtype, const void* dy, const void* dy2, const void* x, const void* res, const float* gamma,

@@ -87,6 +87,15 @@ class CTCLoss(torch.nn.Module):
             raise ValueError(f"unknown reduction {reduction_type}")
         self.zero_infinity = zero_infinity
         self.reduction_type = reduction_type
+        self._pending_status = None
+
+    def _check_deferred(self):
+        """The device-side target packing reports rows whose non-PAD/EOS count differs from target_lengths (the reference's
+        masked_select + F.ctc_loss would fail on them): raised at the NEXT call, when the flag has long arrived."""
+        st, self._pending_status = self._pending_status, None
+        if st is not None and int(st[0].item()) != 0:
+            raise RuntimeError("CTCLoss: %d utterance(s) of the previous batch had target_lengths that did not match their non-PAD/EOS "
+                               "targets (their labels were cut / zero-filled)" % int(st[0].item()))
 
     def forward(self, log_prob, input_lengths, targets, target_lengths):
         dev = log_prob.device
@@ -98,8 +107,18 @@ class CTCLoss(torch.nn.Module):
                 tl_dev = target_lengths.to(device=dev, dtype=torch.int32) if target_lengths.is_cuda else ops.host_i32(target_lengths.numpy(), dev)
             else:
                 tl_dev = ops.host_i32(np.asarray(target_lengths), dev)
-            flat, off = K.ctc_pack_targets(targets.to(torch.int64).contiguous(), tl_dev.contiguous(), Offsets.PAD, Offsets.EOS)
-            smax = max(1, int(targets.shape[1]))
+            self._check_deferred()                       # last call's consistency flag (read one call late: no sync on this one)
+            flat, off, status = K.ctc_pack_targets(targets.to(torch.int64).contiguous(), tl_dev.contiguous(), Offsets.PAD, Offsets.EOS)
+            self._pending_status = status
+            # label bound of the alpha/beta kernel (<= 511 labels): the true maximum when target_lengths lives on the host (the
+            # drivers' batches, audio8/train.py:30-39), else the padded width of `targets` -- and only if that is too wide, one sync
+            if not (torch.is_tensor(target_lengths) and target_lengths.is_cuda):
+                tl_host = np.asarray(target_lengths.detach().numpy() if torch.is_tensor(target_lengths) else target_lengths)
+                smax = int(max(1, tl_host.max() if tl_host.size else 1))
+            else:
+                smax = max(1, int(targets.shape[1]))
+                if smax > 511:
+                    smax = int(max(1, int(target_lengths.max().item())))
             tl = None
         else:
             t = np.asarray(targets.detach().cpu().numpy() if torch.is_tensor(targets) else targets)

@@ -70,7 +70,7 @@ def gemm(layout, A, B, M, N, K, **kw):
     return out
 
 
-def encoder_layer_fwd(x, keymask, B, T, H, p, eps, seeds, wqkv, bqkv, wo, bo, w1, b1, w2, b2, g1, be1, g2, be2):
+def encoder_layer_fwd(x, keymask, B, T, H, p, eps, seeds, wqkv, bqkv, wo, bo, w1, b1, w2, b2, g1, be1, g2, be2, aux_stream=None):
     """a8_encoder_layer_fwd: the whole post-LN encoder layer forward in one C call.  Returns the tensors backward needs:
     (x2, qkv, o, lse, ao, x1, mean2, rstd2, z1, h, f, mean1, rstd1)."""
     M, d = x.shape
@@ -84,13 +84,30 @@ def encoder_layer_fwd(x, keymask, B, T, H, p, eps, seeds, wqkv, bqkv, wo, bo, w1
     stats = torch.empty((4, M), device=dev, dtype=torch.float32)
     mean2, rstd2, mean1, rstd1 = stats.unbind(0)
     sp, fsz = stats.data_ptr(), 4 * M
-    e = L.EncoderLayerDesc(L.dt(x), B, T, H, d, dff, p, eps, _u32(seeds[0]), _u32(seeds[1]), _u32(seeds[2]),
-                           x.data_ptr(), keymask.data_ptr() if keymask is not None else None,
-                           wqkv.data_ptr(), wo.data_ptr(), w1.data_ptr(), w2.data_ptr(),
-                           bqkv.data_ptr(), bo.data_ptr(), b1.data_ptr(), b2.data_ptr(), g1.data_ptr(), be1.data_ptr(), g2.data_ptr(), be2.data_ptr(),
-                           qkv.data_ptr(), o.data_ptr(), ao.data_ptr(), x1.data_ptr(), z1.data_ptr(), h.data_ptr(), f.data_ptr(), x2.data_ptr(),
-                           lse.data_ptr(), sp, sp + fsz, sp + 2 * fsz, sp + 3 * fsz)
-    L.check(L.lib().a8_encoder_layer_fwd(C.byref(e), L.stream()), "a8_encoder_layer_fwd")
+
+    def desc(b0, nb):
+        """descriptor of utterances [b0, b0 + nb): every buffer advanced to their rows"""
+        r0, es = b0 * T, x.element_size()
+        return L.EncoderLayerDesc(L.dt(x), nb, T, H, d, dff, p, eps, _u32(seeds[0]), _u32(seeds[1]), _u32(seeds[2]), b0,
+                                  x.data_ptr() + r0 * d * es, keymask.data_ptr() + b0 * T if keymask is not None else None,
+                                  wqkv.data_ptr(), wo.data_ptr(), w1.data_ptr(), w2.data_ptr(),
+                                  bqkv.data_ptr(), bo.data_ptr(), b1.data_ptr(), b2.data_ptr(), g1.data_ptr(), be1.data_ptr(), g2.data_ptr(), be2.data_ptr(),
+                                  qkv.data_ptr() + r0 * 3 * d * es, o.data_ptr() + r0 * d * es, ao.data_ptr() + r0 * d * es, x1.data_ptr() + r0 * d * es,
+                                  z1.data_ptr() + r0 * dff * es, h.data_ptr() + r0 * dff * es, f.data_ptr() + r0 * d * es, x2.data_ptr() + r0 * d * es,
+                                  lse.data_ptr() + 4 * b0 * H * T, sp + 4 * r0, sp + fsz + 4 * r0, sp + 2 * fsz + 4 * r0, sp + 3 * fsz + 4 * r0)
+    if aux_stream is not None and B >= 2:
+        # Two halves of the batch as two launch sequences on two streams (rows are independent through the whole layer): each half's
+        # under-filled launches (294-tile products, latency-bound LayerNorms, the tails of every grid) run beside the other half's.
+        # The caller orders the two streams at the ends of the encoder stack; inside it half A lives on the current stream, half B on aux.
+        nb = B // 2
+        ea, eb = desc(0, nb), desc(nb, B - nb)
+        for t_ in (x, qkv, o, z1, lse, stats) + ((keymask,) if keymask is not None else ()):     # (o / z1 stand for their slabs' storage)
+            t_.record_stream(aux_stream)          # allocated on the current stream, used on aux too: no reuse before aux is done with them
+        L.check(L.lib().a8_encoder_layer_fwd(C.byref(ea), L.stream()), "a8_encoder_layer_fwd")
+        L.check(L.lib().a8_encoder_layer_fwd(C.byref(eb), aux_stream.cuda_stream), "a8_encoder_layer_fwd")
+    else:
+        e = desc(0, B)
+        L.check(L.lib().a8_encoder_layer_fwd(C.byref(e), L.stream()), "a8_encoder_layer_fwd")
     return x2, qkv, o, lse, ao, x1, mean2, rstd2, z1, h, f, mean1, rstd1
 
 
@@ -440,14 +457,16 @@ def ctc_greedy_decode(lprobs, in_len_i32, blank=0):
 
 
 def ctc_pack_targets(targets_i64, tlen_i32, pad, eos):
-    """targets [B,S] int64 (device) -> (flat i32 [B*S] with the non-PAD/EOS entries in front, offsets i32 [B+1])."""
+    """targets [B,S] int64 (device) -> (flat i32 labels, row b at offsets[b]; offsets i32 [B+1]; status i32 [2] = (rows whose
+    PAD/EOS count disagrees with target_lengths, max(target_lengths)) for a deferred check)."""
     L.require_cuda(targets_i64, tlen_i32)
     B, S = targets_i64.shape
-    flat = torch.empty((max(1, B * S),), device=targets_i64.device, dtype=torch.int32)
+    flat = zeros((max(1, B * S),), torch.int32, targets_i64.device)          # (labels of a short row stay defined)
     off = torch.empty((B + 1,), device=targets_i64.device, dtype=torch.int32)
-    L.check(L.lib().a8_ctc_pack_targets(L.ptr(_c(targets_i64)), L.ptr(tlen_i32), L.ptr(flat), L.ptr(off), B, S, int(pad), int(eos), L.stream()),
-            "a8_ctc_pack_targets")
-    return flat, off
+    status = torch.empty((2,), device=targets_i64.device, dtype=torch.int32)
+    L.check(L.lib().a8_ctc_pack_targets(L.ptr(_c(targets_i64)), L.ptr(tlen_i32), L.ptr(flat), L.ptr(off), L.ptr(status), B, S, int(pad), int(eos),
+                                        L.stream()), "a8_ctc_pack_targets")
+    return flat, off, status
 
 
 def ctc_fwd_bwd(lp, targets_flat_i32, tgt_off_i32, in_len_i32, Smax, blank=0, zero_infinity=True):

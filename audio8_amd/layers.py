@@ -197,10 +197,22 @@ class TransformerEncoderStack(nn.Module):
         # one np.random.random() per layer per forward (eight_mile's layer-drop draw), taken up front -- or handed over by
         # wav2vec2.prefetch_host_draws, which took them in the same order while the GPU was busy with the previous step
         draws = ops.take_layer_draws(len(self.encoders)) if self.layerdrop_rng_draws else [1.0] * len(self.encoders)
-        for layer, pdrop in zip(self.encoders, draws):
-            if self.training and pdrop < self.layer_drop:
-                continue
-            h = layer((h, mask_u8, B, T))
+        # two half-batches on two streams through the whole stack (ops.HALF_BATCH_STREAMS): half A's launches stay on the current
+        # stream, half B's go to an auxiliary one; the streams meet only here, before the first and after the last layer
+        aux = ops.half_stream(x.device) if (x.is_cuda and B >= 2 and h.dtype == torch.bfloat16 and h.is_contiguous()) else None
+        cur = torch.cuda.current_stream() if aux is not None else None
+        if aux is not None:
+            aux.wait_stream(cur)
+        ops.HALF_STREAM = aux
+        try:
+            for layer, pdrop in zip(self.encoders, draws):
+                if self.training and pdrop < self.layer_drop:
+                    continue
+                h = layer((h, mask_u8, B, T))
+        finally:
+            ops.HALF_STREAM = None
+            if aux is not None:
+                cur.wait_stream(aux)
         return h.view(B, T, d)
 
 

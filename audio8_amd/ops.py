@@ -665,6 +665,23 @@ class ConvStackFn(torch.autograd.Function):
 _CONV_DW_CACHE = {}        # (co, k, cin, device) -> f32 [co, k*cin] split-K landing buffer of a conv weight gradient, zero between uses
 
 
+# Encoder forward as two half-batches on two streams (layers.TransformerEncoderStack sets HALF_STREAM around its layer loop when
+# HALF_BATCH_STREAMS is on; a8_encoder_layer_fwd then runs once per half).  Backward stays whole-batch: forward draws the same dropout masks.
+HALF_BATCH_STREAMS = True
+HALF_STREAM = None
+_HALF_AUX = {}
+
+
+def half_stream(device):
+    """The auxiliary stream of the half-batch forward (one per device), or None when the feature is off."""
+    if not HALF_BATCH_STREAMS or not COMPOSITE_ENCODER_FWD or K.GEMM_PROFILE is not None:
+        return None
+    s = _HALF_AUX.get(device)
+    if s is None:
+        s = _HALF_AUX[device] = torch.cuda.Stream(device=device)
+    return s
+
+
 # Utterance chunking of the conv stack's big leading layers (layer 0's output is 51 MB per utterance at 250 k samples): with
 # CONV_CHUNK_UTTS utterances per chunk, layers 0 .. CONV_CHUNK_LAYERS-1 run chunk by chunk so that a layer reads its input
 # while it is still resident in the 256 MB Infinity Cache; the remaining (small) layers run on the whole batch.  0 = off.
@@ -730,7 +747,7 @@ class PosConvFn(torch.autograd.Function):
         dgain = tg if direct else torch.zeros(pg.shape, device=x.device, dtype=torch.float32)
 
         def wgrad_chain():
-            dwg = torch.zeros((G, dg, k, dg), device=x.device, dtype=torch.float32)
+            dwg = K.zeros((G, dg, k, dg), torch.float32, x.device)
             K.posconv_wgrad(x, dz, dwg, G, k, ctx.pad_left)
             K.weightnorm_bwd_(dwg, pv.detach(), pg.detach(), inv_norm, dv, dgain, G)
             if direct:
@@ -791,7 +808,8 @@ class EncoderLayerFn(torch.autograd.Function):
             # roofline steps of bench.py (per-GEMM events) and as the readable statement of the sequence
             seed_a, seed1, seed2 = (next_seed(), next_seed(), next_seed()) if p > 0 else (0, 0, 0)
             x2, qkv, o, lse, ao, x1, mean2, rstd2, z1, h, f, mean1, rstd1 = K.encoder_layer_fwd(
-                x, keymask, B, T, H, p, eps, (seed_a, seed1, seed2), wqkv_c, bqkv, wo_c, bo, w1_c, b1, w2_c, b2, g1, be1, g2, be2)
+                x, keymask, B, T, H, p, eps, (seed_a, seed1, seed2), wqkv_c, bqkv, wo_c, bo, w1_c, b1, w2_c, b2, g1, be1, g2, be2,
+                aux_stream=HALF_STREAM)
             ctx.save_for_backward(x, keymask, qkv, o, lse, ao, x1, mean2, rstd2, z1, h, f, mean1, rstd1,
                                   wqkv_c, wo_c, w1_c, w2_c, g1, g2)
             ctx.cfg = (B, T, H, p, seed_a, seed1, seed2)
@@ -970,6 +988,7 @@ class VQFn(torch.autograd.Function):
         ctx.wts = (wpt, ev[0] if ev is not None else None)
         ctx.params = (wp, bp, vars_)
         ctx.mark_non_differentiable(codes)
+        ctx.set_materialize_grads(False)         # (backward tests dppl_out for None; no zero-filled gradient of the codes)
         return q, ppl, codes
 
     @staticmethod
@@ -978,6 +997,8 @@ class VQFn(torch.autograd.Function):
         G, V, D, tau, training, vshape = ctx.cfg
         N, Cin = y.shape
         dev, dt = y.device, y.dtype
+        if dq is None:                            # (only the perplexity was used downstream)
+            dq = K.zeros((N, G * D), dt, dev)
         dqc = dq.contiguous()
         if dqc.dtype != dt:
             dqc = K.cast(dqc, dt)
@@ -1013,12 +1034,15 @@ class ContrastiveXEFn(torch.autograd.Function):
         ctx.rows_per_group, ctx.mean = rows_per_group, mean
         rows = ctx_rows.shape[0]
         ctx.mark_non_differentiable(logits)
+        ctx.set_materialize_grads(False)         # (no zero-filled [rows, N+1] "gradient" of the logits handed to backward)
         return (loss_sum[0] / rows if mean else loss_sum), logits
 
     @staticmethod
     def backward(ctx, dloss, _dlogits):
         c, q, neg_idx, logits, inv_norms = ctx.saved_tensors
         rows = c.shape[0]
+        if dloss is None:
+            return None, None, None, None, None
         gscale = (dloss.float() / rows).reshape(1).contiguous() if ctx.mean else dloss.reshape(1)
         dctx, dlat = K.contrastive_bwd(c.contiguous(), q.contiguous(), neg_idx, logits, gscale, ctx.rows_per_group, inv_norms)
         if c.dtype != torch.float32:

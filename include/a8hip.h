@@ -172,6 +172,9 @@ typedef struct a8_encoder_layer_desc {
     int dtype, B, T, H, d, dff;
     float p, eps;
     uint32_t seed_attn, seed1, seed2;
+    int b0;                  /* 0, or the index of this call's first utterance in the logical batch: a call on utterances [b0, b0 + B) (all pointers
+                                already advanced to them) draws the dropout masks the whole-batch call would draw there -- two such calls on two
+                                streams overlap each other's under-filled launches */
     const void* x; const uint8_t* keymask;
     const void *wqkv, *wo, *w1, *w2;
     const float *bqkv, *bo, *b1, *b2, *g1, *be1, *g2, *be2;
@@ -255,8 +258,9 @@ int a8_contrastive_bwd(int dtype, const void* ctx, const void* lat, const int32_
  * alpha is scratch f32 [B, T, 2*Smax+2]; grad f32 [T,B,V] = d nll_b / d lp (zero_infinity applied). */
 /* targets i64 [B,S] padded with PAD / EOS (audio8/ctc.py:193-194 `targets.masked_select(pad_mask)`) -> flat i32 [<= B*S] and
  * tgt_off i32 [B+1] = exclusive prefix sum of target_lengths i32 [B]; everything on the device (the reference's masked_select
- * is a host sync). */
-int a8_ctc_pack_targets(const int64_t* targets, const int32_t* target_lengths, int32_t* flat, int32_t* tgt_off,
+ * is a host sync).  Row b's labels land at tgt_off[b], cut at target_lengths[b]; status (optional, i32 [2]) = {rows whose count of
+ * non-PAD/EOS entries differs from target_lengths[b], max(target_lengths)} for a deferred host check. */
+int a8_ctc_pack_targets(const int64_t* targets, const int32_t* target_lengths, int32_t* flat, int32_t* tgt_off, int32_t* status,
                         int B, int S, int pad, int eos, void* stream);
 int a8_ctc_fwd_bwd(const float* lp, const int32_t* targets, const int32_t* tgt_off, const int32_t* in_len,
                    float* nll, float* grad, float* alpha, int T, int B, int V, int Smax, int blank, int zero_infinity,

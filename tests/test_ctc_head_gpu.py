@@ -127,6 +127,43 @@ def test_ctc_loss_device_targets_match_host_targets():
         np.testing.assert_allclose(res[0][1].numpy(), xr.grad.numpy(), rtol=2e-3, atol=2e-5)
 
 
+def test_ctc_loss_device_targets_wide_padding_and_deferred_length_check():
+    """Device targets padded far wider than any real label sequence (width 700 > the kernel's 511-label bound): the bound comes from
+    target_lengths, not from the padding.  A row whose stated length disagrees with its non-PAD/EOS count must not shift the other
+    rows' labels (each row is packed at its own offset) and is reported at the next call."""
+    from audio8_amd import ctc as Cc
+    Tn, Bn, V = 120, 4, 32
+    g = torch.Generator().manual_seed(2)
+    lp = torch.randn(Tn, Bn, V, generator=g).log_softmax(-1)
+    tl = torch.tensor([30, 12, 45, 5])
+    il = torch.tensor([120, 100, 120, 90])
+    targets = torch.full((Bn, 700), 1, dtype=torch.long)
+    for b in range(Bn):
+        targets[b, : tl[b]] = torch.randint(4, V, (int(tl[b]),), generator=g)
+        targets[b, tl[b]] = 2
+    flat = targets[(targets != 1) & (targets != 2)]
+    loss_fn = Cc.CTCLoss(reduction_type="sum")
+    for tlen in (tl, tl.cuda()):                            # host lengths: exact bound; device lengths: one sync because 700 > 511
+        x = lp.clone().cuda().requires_grad_(True)
+        loss = loss_fn(x, il.cuda(), targets.cuda(), tlen)
+        loss.backward()
+        xr = lp.clone().requires_grad_(True)
+        want = F.ctc_loss(xr, flat, il, tl, blank=0, reduction="sum", zero_infinity=True)
+        want.backward()
+        np.testing.assert_allclose(loss.item(), want.item(), rtol=1e-5)
+        np.testing.assert_allclose(x.grad.cpu().numpy(), xr.grad.numpy(), rtol=2e-3, atol=2e-5)
+    # row 1 claims 10 labels but holds 12: rows 0, 2, 3 keep their exact per-utterance losses; the mismatch surfaces one call later
+    bad_tl = tl.clone()
+    bad_tl[1] = 10
+    per = Cc.CTCLoss(reduction_type="none")
+    nll_bad = per(lp.cuda(), il.cuda(), targets.cuda(), bad_tl).cpu()
+    nll_ok = F.ctc_loss(lp, flat, il, tl, blank=0, reduction="none", zero_infinity=True)
+    np.testing.assert_allclose(nll_bad[[0, 2, 3]].numpy(), nll_ok[[0, 2, 3]].numpy(), rtol=1e-5)
+    with pytest.raises(RuntimeError, match="did not match"):
+        per(lp.cuda(), il.cuda(), targets.cuda(), tl)
+    assert torch.isfinite(per(lp.cuda(), il.cuda(), targets.cuda(), tl)).all()          # the flag was consumed; a clean batch runs
+
+
 def test_stepper_leaves_gradless_parameters_alone(restore_dtype):
     """train.py starts with the encoder frozen (`model.freeze = True`): only `proj` receives gradients.  torch's AdamW skips
     `p.grad is None`; the fused update must too -- no weight decay, no moment decay, own step count -- and a parameter

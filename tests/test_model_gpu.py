@@ -600,3 +600,41 @@ def test_rccl_exchange_path_on_one_rank(tmp_path):
     # bf16 backward with atomics: the two runs agree to rounding noise, not bit for bit
     np.testing.assert_allclose(out["with"], out["without"], rtol=2e-2)
     assert out["max_param_diff"] < 5e-3
+
+
+def test_half_batch_two_stream_forward_is_bit_identical(restore_dtype):
+    """ops.HALF_BATCH_STREAMS runs the encoder stack's forward as two half-batches on two HIP streams (one a8_encoder_layer_fwd call per
+    half and layer, dropout counters continued across the halves).  Rows are independent through the stack and every product walks K
+    in the same order, so loss and gradients must equal the whole-batch run bit for bit -- with dropout on, an odd batch (3 = 1 + 2)
+    and in eval mode under no_grad (where intermediate buffers are recycled while the auxiliary stream may still read them)."""
+    from audio8_amd import ops, wav2vec2 as W
+    ops.set_compute_dtype(torch.bfloat16)
+    old = ops.HALF_BATCH_STREAMS
+
+    def run(half, B, train=True):
+        ops.HALF_BATCH_STREAMS = half
+        torch.manual_seed(0)
+        ops.reset_seed_stream()
+        model = W.create_model(num_layers=3, dropout=0.1).cuda()
+        model.train(train)
+        loss_fn = W.create_loss(640, 100)
+        x = synth(B, 24000, 5).cuda()
+        np.random.seed(3)
+        if not train:
+            with torch.no_grad():
+                return loss_fn(model, x).item(), None
+        loss = loss_fn(model, x)
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.item(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    try:
+        for B in (4, 3):
+            l0, g0 = run(False, B)
+            l1, g1 = run(True, B)
+            assert l0 == l1, (B, l0, l1)
+            assert g0.keys() == g1.keys()
+            for k in g0:
+                assert torch.equal(g0[k], g1[k]), (B, k)
+        assert run(False, 4, train=False)[0] == run(True, 4, train=False)[0]
+    finally:
+        ops.HALF_BATCH_STREAMS = old

@@ -45,6 +45,7 @@ def apply(d):
     ops.COMPOSITE_ENCODER_FWD = bool(d.get("compfwd", 1))
     ops.COMPOSITE_ENCODER_BWD = bool(d.get("compbwd", 1))
     ops.WGRAD_STORE_FIRST = bool(d.get("storefirst", 1))
+    ops.HALF_BATCH_STREAMS = bool(d.get("half", 1))
     ops.SPLITK_SLOTS = d.get("skslots", 512)
     ops.SPLITK_MIN_ROWS = d.get("skrows", 800)
 
