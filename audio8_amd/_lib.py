@@ -95,7 +95,7 @@ class EncoderLayerDesc(C.Structure):
 
 class EncoderLayerBwdDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("dtype", "B", "T", "H", "d", "dff")] + [("p", C.c_float)] + \
-               [(n, C.c_uint32) for n in ("seed_attn", "seed1", "seed2")] + \
+               [(n, C.c_uint32) for n in ("seed_attn", "seed1", "seed2")] + [("b0", C.c_int)] + \
                [(n, C.c_void_p) for n in ("dx2", "x", "qkv", "o", "ao", "x1", "z1", "f", "keymask", "lse", "mean2", "rstd2", "mean1", "rstd1", "g1", "g2",
                                           "w2_t", "w1_t", "wo_t", "dg1", "dbe1", "dg2", "dbe2", "db2", "db1", "dbo",
                                           "df", "dx1_res", "dz1", "dx1_ffn", "dao", "dx_res", "dout_o", "dqkv", "delta")]

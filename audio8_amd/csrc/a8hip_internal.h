@@ -12,3 +12,9 @@ int a8i_layernorm_fwd(int dtype, const void* x, const void* res, const float* ga
                       int rows, int cols, float eps, float p, uint32_t seed, uint32_t rng_stream, int64_t rng_elem0, void* stream);
 int a8i_attn_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* keymask, int B, int T, int H,
                  int64_t ld_qkv, int64_t ld_o, float scale, float p, uint32_t seed, int bh0, void* stream);
+int a8i_layernorm_bwd(int dtype, const void* dy, const void* dy2, const void* x, const void* res, const float* gamma, const float* mean,
+                      const float* rstd, void* dx, void* dres, float* dgamma, float* dbeta, float* dbias, int rows, int cols, float p,
+                      uint32_t seed, uint32_t rng_stream, int64_t rng_elem0, void* stream);
+int a8i_attn_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                 const uint8_t* keymask, void* dq, void* dk, void* dv, float* delta, float* dbias, int B, int T, int H, int64_t ld_qkv,
+                 int64_t ld_o, int64_t ld_dqkv, float scale, float p, uint32_t seed, int bh0, void* stream);

@@ -199,7 +199,7 @@ struct AttnP {
     float lazy;                    // raise the running max only past this margin (log2 units)
     uint32_t thr, seed;            // thr: 8-bit keep threshold (0 = dropout off)
     int Th;                        // key quads per query row = ceil(T / 4)
-    int bh0;                       // forward only: (batch, head) index of this call's first pair in the LOGICAL batch the dropout counters
+    int bh0;                       // (batch, head) index of this call's first pair in the LOGICAL batch the dropout counters
                                    // belong to (a call on utterances [b0, b0 + B) of a larger batch passes b0 * H: same mask as the whole-batch call)
 };
 
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(NW * 64, MW) void attn_bwd_kv_kernel(const AttnP P)
         kf[j].load(kb + (long long)key[j] * P.ld_qkv, ok, lane);
         vf[j].load(vb + (long long)key[j] * P.ld_qkv, ok, lane);
         key_masked[j] = P.keymask && ok && !P.keymask[(long long)b * P.T + key[j]];
-        hk[j] = (pair_base(bh, P.T, P.Th, 4 * g) + (uint32_t)(key[j] >> 2) + P.seed) * HC1;
+        hk[j] = (pair_base(bh + P.bh0, P.T, P.Th, 4 * g) + (uint32_t)(key[j] >> 2) + P.seed) * HC1;
         hc2[j] = HC2 << (8 * (3 - (key[j] & 3)));
 #pragma unroll
         for (int i = 0; i < 4; ++i) { dk[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(NW * 64, MW) void attn_bwd_q_kernel(const AttnP P) 
             ndelta[j] = -dl;
             if (ok && g == 0) P.delta[(long long)bh * P.T + qi[j]] = dl;
         }
-        hb[j] = (pair_base(bh, P.T, P.Th, qi[j]) + (uint32_t)g + P.seed) * HC1;
+        hb[j] = (pair_base(bh + P.bh0, P.T, P.Th, qi[j]) + (uint32_t)g + P.seed) * HC1;
 #pragma unroll
         for (int i = 0; i < 4; ++i) dq[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
@@ -931,9 +931,9 @@ extern "C" int a8_attn_fwd(int dtype, const void* q, const void* k, const void* 
     return a8i_attn_fwd(dtype, q, k, v, o, lse, keymask, B, T_, H, ld_qkv, ld_o, scale, p, seed, 0, stream);
 }
 
-extern "C" int a8_attn_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
-                           const uint8_t* keymask, void* dq, void* dk, void* dv, float* delta, float* dbias, int B, int T_, int H, int64_t ld_qkv,
-                           int64_t ld_o, int64_t ld_dqkv, float scale, float p, uint32_t seed, void* stream) {
+int a8i_attn_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                 const uint8_t* keymask, void* dq, void* dk, void* dv, float* delta, float* dbias, int B, int T_, int H, int64_t ld_qkv,
+                 int64_t ld_o, int64_t ld_dqkv, float scale, float p, uint32_t seed, int bh0, void* stream) {
     if (int e = check_common("a8_attn_bwd", dtype, B, T_, H, ld_qkv, ld_o, p)) return e;
     AttnP P = {};
     P.q = (const char*)q; P.k = (const char*)k; P.v = (const char*)v; P.o = (const char*)o; P.dout = (const char*)dout;
@@ -941,9 +941,16 @@ extern "C" int a8_attn_bwd(int dtype, const void* q, const void* k, const void* 
     P.dq = (char*)dq; P.dk = (char*)dk; P.dv = (char*)dv;
     P.B = B; P.T = T_; P.H = H; P.ld_qkv = ld_qkv; P.ld_o = ld_o; P.ld_d = ld_dqkv;
     set_softmax_params(P, scale, p, seed);
+    P.bh0 = bh0;
     hipStream_t s = (hipStream_t)stream;
     // dQ first: it computes delta = rowsum(dO * O) for its own query rows and publishes it for the dK/dV kernel
     A8_ATTN_LAUNCH(attn_bwd_q_kernel, 4, "a8_attn_bwd")
     A8_ATTN_LAUNCH(attn_bwd_kv_kernel, 3, "a8_attn_bwd")
     return a8_check_launch("a8_attn_bwd");
+}
+
+extern "C" int a8_attn_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                           const uint8_t* keymask, void* dq, void* dk, void* dv, float* delta, float* dbias, int B, int T_, int H, int64_t ld_qkv,
+                           int64_t ld_o, int64_t ld_dqkv, float scale, float p, uint32_t seed, void* stream) {
+    return a8i_attn_bwd(dtype, q, k, v, o, dout, lse, keymask, dq, dk, dv, delta, dbias, B, T_, H, ld_qkv, ld_o, ld_dqkv, scale, p, seed, 0, stream);
 }

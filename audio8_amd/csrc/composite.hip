@@ -68,22 +68,23 @@ extern "C" int a8_encoder_layer_bwd(const a8_encoder_layer_bwd_desc* e, void* st
     A8_REQUIRE(e->p > 0.f || (e->dx1_res == e->df && e->dx_res == e->dao), "a8_encoder_layer_bwd: with p = 0, dx1_res / dx_res must alias df / dao");
     const int M = e->B * e->T, d = e->d, esz = e->dtype == A8_BF16 ? 2 : 4;
     const bool drop = e->p > 0.f;
-    if (int rc = a8_layernorm_bwd(e->dtype, e->dx2, nullptr, e->f, e->x1, e->g1, e->mean1, e->rstd1, e->df, drop ? e->dx1_res : nullptr,
-                                  e->dg1, e->dbe1, e->db2, M, d, e->p, e->seed2, 4, stream))
+    const int64_t rng0 = (int64_t)e->b0 * e->T * d;          // dropout counters of utterances [b0, b0 + B) of the logical batch (see the forward)
+    if (int rc = a8i_layernorm_bwd(e->dtype, e->dx2, nullptr, e->f, e->x1, e->g1, e->mean1, e->rstd1, e->df, drop ? e->dx1_res : nullptr,
+                                   e->dg1, e->dbe1, e->db2, M, d, e->p, e->seed2, 4, rng0, stream))
         return rc;
     a8_gemm_desc g = nt_desc(e->dtype, e->df, e->w2_t, e->dz1, M, e->dff, d, nullptr);
     g.act = A8_ACT_MUL_GELU_GRAD; g.zin = e->z1; g.ldz = e->dff; g.colsum = e->db1;
     if (int rc = a8_gemm(&g, stream)) return rc;
     g = nt_desc(e->dtype, e->dz1, e->w1_t, e->dx1_ffn, M, d, e->dff, nullptr);
     if (int rc = a8_gemm(&g, stream)) return rc;
-    if (int rc = a8_layernorm_bwd(e->dtype, e->dx1_res, e->dx1_ffn, e->ao, e->x, e->g2, e->mean2, e->rstd2, e->dao, drop ? e->dx_res : nullptr,
-                                  e->dg2, e->dbe2, e->dbo, M, d, e->p, e->seed1, 3, stream))
+    if (int rc = a8i_layernorm_bwd(e->dtype, e->dx1_res, e->dx1_ffn, e->ao, e->x, e->g2, e->mean2, e->rstd2, e->dao, drop ? e->dx_res : nullptr,
+                                   e->dg2, e->dbe2, e->dbo, M, d, e->p, e->seed1, 3, rng0, stream))
         return rc;
     g = nt_desc(e->dtype, e->dao, e->wo_t, e->dout_o, M, d, d, nullptr);
     if (int rc = a8_gemm(&g, stream)) return rc;
     const char* q = (const char*)e->qkv;
     char* dq = (char*)e->dqkv;
-    return a8_attn_bwd(e->dtype, q, q + (size_t)d * esz, q + (size_t)2 * d * esz, e->o, e->dout_o, e->lse, e->keymask, dq, dq + (size_t)d * esz,
-                       dq + (size_t)2 * d * esz, e->delta, nullptr, e->B, e->T, e->H, 3 * d, d, 3 * d, 1.0f / std::sqrt((float)(d / e->H)), e->p,
-                       e->seed_attn, stream);
+    return a8i_attn_bwd(e->dtype, q, q + (size_t)d * esz, q + (size_t)2 * d * esz, e->o, e->dout_o, e->lse, e->keymask, dq, dq + (size_t)d * esz,
+                        dq + (size_t)2 * d * esz, e->delta, nullptr, e->B, e->T, e->H, 3 * d, d, 3 * d, 1.0f / std::sqrt((float)(d / e->H)), e->p,
+                        e->seed_attn, e->b0 * e->H, stream);
 }

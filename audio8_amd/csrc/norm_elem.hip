@@ -157,7 +157,7 @@ __global__ __launch_bounds__(NW * 64, MC <= 2 ? 4 : 2) void ln_bwd_kernel(const 
                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, T* __restrict__ dx, T* __restrict__ dres,
                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dbias,
-                                                         int rows, int cols, Drop dr) {
+                                                         int rows, int cols, Drop dr, long long rng0) {
     __shared__ __attribute__((aligned(16))) float lds[(NW < 8 ? NW : 8) * MC * 512];
     const int lane = threadIdx.x & 63, nch = cols >> 3;
     const float inv = 1.0f / (float)cols;
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(NW * 64, MC <= 2 ? 4 : 2) void ln_bwd_kernel(const 
                 float v[8], gm[8];
                 load8(x + off, v);
                 if (dr.thr) {
-                    keep[c] = a8_keep8(dr.seed, dr.stream, (uint32_t)(off >> 3), dr.thr);
+                    keep[c] = a8_keep8(dr.seed, dr.stream, (uint32_t)((off + rng0) >> 3), dr.thr);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) v[i] = a8_kept(keep[c], i) ? v[i] * dr.scale : 0.f;
                 }
@@ -552,9 +552,10 @@ extern "C" int a8_layernorm_fwd(int dtype, const void* x, const void* res, const
     return a8i_layernorm_fwd(dtype, x, res, gamma, beta, y, mean, rstd, rows, cols, eps, p, seed, rng_stream, 0, stream);
 }
 
-extern "C" int a8_layernorm_bwd(int dtype, const void* dy, const void* dy2, const void* x, const void* res, const float* gamma,
-                                const float* mean, const float* rstd, void* dx, void* dres, float* dgamma, float* dbeta, float* dbias,
-                                int rows, int cols, float p, uint32_t seed, uint32_t rng_stream, void* stream) {
+int a8i_layernorm_bwd(int dtype, const void* dy, const void* dy2, const void* x, const void* res, const float* gamma,
+                      const float* mean, const float* rstd, void* dx, void* dres, float* dgamma, float* dbeta, float* dbias,
+                      int rows, int cols, float p, uint32_t seed, uint32_t rng_stream, int64_t rng_elem0, void* stream) {
+    A8_REQUIRE(rng_elem0 % 8 == 0, "a8_layernorm_bwd: the counter offset must be a multiple of 8");
     A8_REQUIRE(cols % 8 == 0 && cols <= MAXC * 512, "a8_layernorm_bwd: cols=%d must be a multiple of 8 and <= %d", cols, MAXC * 512);
     A8_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "a8_layernorm_bwd: dgamma and dbeta go together");
     if (rows == 0) return A8_OK;
@@ -565,13 +566,19 @@ extern "C" int a8_layernorm_bwd(int dtype, const void* dy, const void* dy2, cons
     const int grid = cdiv(rows, nw * rpw);
 #define LN_BWD2(NW, MC) DISPATCH_T(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T, NW, MC>), dim3(grid), dim3(NW * 64), 0, (hipStream_t)stream, \
                                          (const T*)dy, (const T*)dy2, (const T*)x, (const T*)res, gamma, mean, rstd, (T*)dx, (T*)dres, \
-                                         dgamma, dbeta, dbias, rows, cols, dr))
+                                         dgamma, dbeta, dbias, rows, cols, dr, (long long)rng_elem0))
 #define LN_BWD(NW) do { if (cols <= 1024) LN_BWD2(NW, 2); else LN_BWD2(NW, MAXC); } while (0)
     if (nw == 4) LN_BWD(4); else if (nw == 8) LN_BWD(8); else if (nw == 16) LN_BWD(16);
     else return a8_set_error(A8_ERR_ARG, "a8_layernorm_bwd: bad tuning %d", g_a8_tuning[1]);
 #undef LN_BWD
 #undef LN_BWD2
     return a8_check_launch("a8_layernorm_bwd");
+}
+
+extern "C" int a8_layernorm_bwd(int dtype, const void* dy, const void* dy2, const void* x, const void* res, const float* gamma,
+                                const float* mean, const float* rstd, void* dx, void* dres, float* dgamma, float* dbeta, float* dbias,
+                                int rows, int cols, float p, uint32_t seed, uint32_t rng_stream, void* stream) {
+    return a8i_layernorm_bwd(dtype, dy, dy2, x, res, gamma, mean, rstd, dx, dres, dgamma, dbeta, dbias, rows, cols, p, seed, rng_stream, 0, stream);
 }
 
 extern "C" int a8_gelu_bwd_bias(int dtype, const void* dy, const void* z, void* dz, float* dbias, int rows, int cols, void* stream) {

@@ -112,29 +112,48 @@ def encoder_layer_fwd(x, keymask, B, T, H, p, eps, seeds, wqkv, bqkv, wo, bo, w1
 
 
 def encoder_layer_bwd(dx2, x, keymask, qkv, o, lse, ao, x1, mean2, rstd2, z1, f, mean1, rstd1, g1, g2, w2_t, w1_t, wo_t,
-                      dg1, dbe1, dg2, dbe2, db2, db1, dbo, B, T, H, p, seeds):
-    """a8_encoder_layer_bwd: LN1 bwd, FFN data gradients, LN2 bwd, output-projection data gradient and attention backward in one C call.
+                      dg1, dbe1, dg2, dbe2, db2, db1, dbo, B, T, H, p, seeds, aux_stream=None):
+    """a8_encoder_layer_bwd: LN1 bwd, FFN data gradients, LN2 bwd, output-projection data gradient and attention backward in one C call
+    (two calls, utterances [0, B/2) on the current stream and [B/2, B) on aux_stream, when one is given: the parameter gradients the
+    chain produces are atomic column sums, the rest is row-local).
     Returns (df, dz1, dao, dqkv, dx_res): the weight-gradient operands and the residual-branch gradient of the layer input."""
     M, d = x.shape
     dff = z1.shape[1]
     dev, dt = x.device, x.dtype
     L.require_cuda(dx2, x, keymask, qkv, o, lse, ao, x1, z1, f, w2_t, w1_t, wo_t, dg1, dbe1, dg2, dbe2, db2, db1, dbo)
     n_d = 6 if p > 0 else 4
-    slabs = torch.empty((n_d, M, d), device=dev, dtype=dt).unbind(0)
+    slab = torch.empty((n_d, M, d), device=dev, dtype=dt)
+    slabs = slab.unbind(0)
     df, dx1_ffn, dao, dout_o = slabs[:4]
     dx1_res, dx_res = (slabs[4], slabs[5]) if p > 0 else (df, dao)
     dz1 = torch.empty((M, dff), device=dev, dtype=dt)
     dqkv = torch.empty((M, 3 * d), device=dev, dtype=dt)
     delta = torch.empty((B, H, T), device=dev, dtype=torch.float32)
-    e = L.EncoderLayerBwdDesc(L.dt(x), B, T, H, d, dff, p, _u32(seeds[0]), _u32(seeds[1]), _u32(seeds[2]),
-                              dx2.data_ptr(), x.data_ptr(), qkv.data_ptr(), o.data_ptr(), ao.data_ptr(), x1.data_ptr(), z1.data_ptr(), f.data_ptr(),
-                              keymask.data_ptr() if keymask is not None else None,
-                              lse.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(), mean1.data_ptr(), rstd1.data_ptr(), g1.data_ptr(), g2.data_ptr(),
-                              w2_t.data_ptr(), w1_t.data_ptr(), wo_t.data_ptr(),
-                              dg1.data_ptr(), dbe1.data_ptr(), dg2.data_ptr(), dbe2.data_ptr(), db2.data_ptr(), db1.data_ptr(), dbo.data_ptr(),
-                              df.data_ptr(), dx1_res.data_ptr(), dz1.data_ptr(), dx1_ffn.data_ptr(), dao.data_ptr(), dx_res.data_ptr(), dout_o.data_ptr(),
-                              dqkv.data_ptr(), delta.data_ptr())
-    L.check(L.lib().a8_encoder_layer_bwd(C.byref(e), L.stream()), "a8_encoder_layer_bwd")
+    es = x.element_size()
+
+    def desc(b0, nb):
+        r0 = b0 * T
+        rd, rf = r0 * d * es, r0 * dff * es
+        return L.EncoderLayerBwdDesc(L.dt(x), nb, T, H, d, dff, p, _u32(seeds[0]), _u32(seeds[1]), _u32(seeds[2]), b0,
+                                     dx2.data_ptr() + rd, x.data_ptr() + rd, qkv.data_ptr() + 3 * rd, o.data_ptr() + rd, ao.data_ptr() + rd,
+                                     x1.data_ptr() + rd, z1.data_ptr() + rf, f.data_ptr() + rd,
+                                     keymask.data_ptr() + r0 if keymask is not None else None,
+                                     lse.data_ptr() + 4 * b0 * H * T, mean2.data_ptr() + 4 * r0, rstd2.data_ptr() + 4 * r0,
+                                     mean1.data_ptr() + 4 * r0, rstd1.data_ptr() + 4 * r0, g1.data_ptr(), g2.data_ptr(),
+                                     w2_t.data_ptr(), w1_t.data_ptr(), wo_t.data_ptr(),
+                                     dg1.data_ptr(), dbe1.data_ptr(), dg2.data_ptr(), dbe2.data_ptr(), db2.data_ptr(), db1.data_ptr(), dbo.data_ptr(),
+                                     df.data_ptr() + rd, dx1_res.data_ptr() + rd, dz1.data_ptr() + rf, dx1_ffn.data_ptr() + rd, dao.data_ptr() + rd,
+                                     dx_res.data_ptr() + rd, dout_o.data_ptr() + rd, dqkv.data_ptr() + 3 * rd, delta.data_ptr() + 4 * b0 * H * T)
+    if aux_stream is not None and B >= 2:
+        nb = B // 2
+        ea, eb = desc(0, nb), desc(nb, B - nb)
+        for t_ in (dx2, slab, dz1, dqkv, delta):
+            t_.record_stream(aux_stream)          # (the saved forward tensors carry aux in their stream set since the forward)
+        L.check(L.lib().a8_encoder_layer_bwd(C.byref(ea), L.stream()), "a8_encoder_layer_bwd")
+        L.check(L.lib().a8_encoder_layer_bwd(C.byref(eb), aux_stream.cuda_stream), "a8_encoder_layer_bwd")
+    else:
+        e = desc(0, B)
+        L.check(L.lib().a8_encoder_layer_bwd(C.byref(e), L.stream()), "a8_encoder_layer_bwd")
     return df, dz1, dao, dqkv, dx_res
 
 

@@ -204,6 +204,9 @@ class TransformerEncoderStack(nn.Module):
         if aux is not None:
             aux.wait_stream(cur)
         ops.HALF_STREAM = aux
+        edges = aux is not None and ops.HALF_BATCH_BWD and torch.is_grad_enabled() and h.requires_grad
+        if edges:
+            h = ops.HalfEdgeFn.apply(h, aux, False)          # backward: the caller's stream waits for the second halves
         try:
             for layer, pdrop in zip(self.encoders, draws):
                 if self.training and pdrop < self.layer_drop:
@@ -213,6 +216,8 @@ class TransformerEncoderStack(nn.Module):
             ops.HALF_STREAM = None
             if aux is not None:
                 cur.wait_stream(aux)
+        if edges:
+            h = ops.HalfEdgeFn.apply(h, aux, True)           # backward: aux waits for the incoming gradient
         return h.view(B, T, d)
 
 

@@ -195,15 +195,20 @@ WGRAD_SIDE_STREAM = None
 
 
 def _on_side(fn, *inputs):
-    """Run fn() on the wgrad side stream after everything enqueued so far on the current stream."""
+    """Run fn() on the wgrad side stream after everything enqueued so far on the current stream (and on the half-batch stream
+    while a split backward is in flight: the operands' second halves were written there)."""
     side = WGRAD_SIDE_STREAM
     if side is None:
+        if _BWD_AUX_LIVE is not None:
+            torch.cuda.current_stream().wait_stream(_BWD_AUX_LIVE)
         fn()
         return
     cur = torch.cuda.current_stream()
     ev = torch.cuda.Event()
     ev.record(cur)
     side.wait_event(ev)
+    if _BWD_AUX_LIVE is not None:
+        side.wait_stream(_BWD_AUX_LIVE)
     with torch.cuda.stream(side):
         fn()
     for t in inputs:
@@ -666,9 +671,52 @@ _CONV_DW_CACHE = {}        # (co, k, cin, device) -> f32 [co, k*cin] split-K lan
 
 
 # Encoder forward as two half-batches on two streams (layers.TransformerEncoderStack sets HALF_STREAM around its layer loop when
-# HALF_BATCH_STREAMS is on; a8_encoder_layer_fwd then runs once per half).  Backward stays whole-batch: forward draws the same dropout masks.
+# HALF_BATCH_STREAMS is on; a8_encoder_layer_fwd then runs once per half).  The dropout counters carry each half's origin in the
+# logical batch, so the masks are those of the whole-batch launch.  With HALF_BATCH_BWD the layers' backward chains split the same way:
+# HalfEdgeFn marks the two ends of the stack in the autograd graph, its backward at the top lets aux wait for the incoming gradient, the
+# one at the bottom makes the caller's stream wait for aux; a layer that cannot split (see EncoderLayerFn._backward) joins first.
 HALF_BATCH_STREAMS = True
+HALF_BATCH_BWD = True
 HALF_STREAM = None
+_BWD_AUX_LIVE = None      # the aux stream while second-half gradients are in flight on it (autograd thread only)
+
+
+def _bwd_fork(aux):
+    """aux will run second-half backward work: order it behind the gradients enqueued so far on the current stream (once)."""
+    global _BWD_AUX_LIVE
+    if _BWD_AUX_LIVE is None:
+        aux.wait_stream(torch.cuda.current_stream())
+        _BWD_AUX_LIVE = aux
+
+
+def _bwd_join():
+    """Whole-batch work follows on the current stream: wait for the second halves."""
+    global _BWD_AUX_LIVE
+    if _BWD_AUX_LIVE is not None:
+        torch.cuda.current_stream().wait_stream(_BWD_AUX_LIVE)
+        _BWD_AUX_LIVE = None
+
+
+class HalfEdgeFn(torch.autograd.Function):
+    """Identity at the two ends of the encoder stack; its backward forks (top) or joins (bottom) the half-batch backward streams."""
+
+    @staticmethod
+    def forward(ctx, x, aux, top):
+        ctx.aux, ctx.top = aux, top
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        global _BWD_AUX_LIVE
+        if ctx.top:
+            _BWD_AUX_LIVE = None                      # (a backward pass that died half-way may have left it set)
+            if HALF_BATCH_BWD and WGRAD_SIDE_STREAM is not None:
+                dy = dy.contiguous()
+                dy.record_stream(ctx.aux)
+                _bwd_fork(ctx.aux)
+        else:
+            _bwd_join()
+        return dy, None, None
 _HALF_AUX = {}
 
 
@@ -815,7 +863,9 @@ class EncoderLayerFn(torch.autograd.Function):
             ctx.cfg = (B, T, H, p, seed_a, seed1, seed2)
             ctx.wts = (wqkv_t, wo_t, w1_t, w2_t)
             ctx.params = (wq, bq, wk, bk, wv, bv, wo, bo, w1, b1, w2, b2, g1, be1, g2, be2)
+            ctx.half_aux = HALF_STREAM if B >= 2 else None
             return x2
+        ctx.half_aux = None
         qkv = K.gemm(L.NT, x, wqkv_c, M, 3 * d, d, bias=bqkv)
         seed_a = next_seed() if p > 0 else 0
         o, lse = K.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, T, H, 3 * d, 1.0 / math.sqrt(d // H), keymask, p, seed_a)
@@ -863,8 +913,12 @@ class EncoderLayerFn(torch.autograd.Function):
                 and all(t is not None for t in (tb2, tbo, tb1, wqkv_t, wo_t, w1_t, w2_t, _target(w1), _target(w2), _target(wo)))):
             # the data-gradient chain up to the attention core behind one C call (a8_encoder_layer_bwd); the statement of the sequence,
             # and every other case (no direct gradient targets, no prepared transposes, instrumented steps), is the code below
+            aux = _BWD_AUX_LIVE if (_BWD_AUX_LIVE is not None and _BWD_AUX_LIVE is ctx.half_aux) else None
+            if aux is None:
+                _bwd_join()
             df, dz1, dao, dqkv, dx_res = K.encoder_layer_bwd(dx2, x, keymask, qkv, o, lse, ao, x1, mean2, rstd2, z1, f, mean1, rstd1, g1, g2,
-                                                             w2_t, w1_t, wo_t, dg1, dbe1, dg2, dbe2, tb2, tb1, tbo, B, T, H, p, (seed_a, seed1, seed2))
+                                                             w2_t, w1_t, wo_t, dg1, dbe1, dg2, dbe2, tb2, tb1, tbo, B, T, H, p, (seed_a, seed1, seed2),
+                                                             aux_stream=aux)
             _ready(pg1, pbe1, b2, b1, pg2, pbe2, bo)
             wg = WgradGroup()
             wg.add((w2,), _target(w2), df, h, d, dff, M)
@@ -881,8 +935,17 @@ class EncoderLayerFn(torch.autograd.Function):
                 _ready(bq, bk, bv)
             wg.add((wq, wk, wv), _span3(tw[0], (3 * d, d)), dqkv, x, 3 * d, d, M)
             wg.flush()
-            dx = _dgrad(dqkv, wqkv_c, wqkv_t, M, d, 3 * d, act=L.ACT_ADD, zin=dx_res, ldz=d)
+            if aux is None:
+                dx = _dgrad(dqkv, wqkv_c, wqkv_t, M, d, 3 * d, act=L.ACT_ADD, zin=dx_res, ldz=d)
+            else:
+                dx = torch.empty((M, d), device=dev, dtype=x.dtype)
+                dx.record_stream(aux)
+                ra = (B // 2) * T
+                _dgrad(dqkv[:ra], wqkv_c, wqkv_t, ra, d, 3 * d, act=L.ACT_ADD, zin=dx_res[:ra], ldz=d, out=dx[:ra])
+                with torch.cuda.stream(aux):
+                    _dgrad(dqkv[ra:], wqkv_c, wqkv_t, M - ra, d, 3 * d, act=L.ACT_ADD, zin=dx_res[ra:], ldz=d, out=dx[ra:])
             return (dx,) + (None,) * 22
+        _bwd_join()
         df, dx1_res = K.layernorm_bwd(dx2, None, f, x1, g1.detach(), mean1, rstd1, dg1, dbe1, p, seed2, 4, want_dx=True, want_dres=p > 0, dbias=tb2)
         if p == 0:
             dx1_res = df

@@ -442,7 +442,9 @@ class Stepper:
         ops.GRAD_FIRST_TOUCH = self.reducer.first_touch
         self.wgrad_stream = torch.cuda.Stream() if (wgrad_side_stream and self.state.flat_p.is_cuda) else None
         ops.WGRAD_SIDE_STREAM = self.wgrad_stream
-        self.reducer.extra_streams = [self.wgrad_stream, torch.cuda.current_stream() if self.state.flat_p.is_cuda else None]
+        # (the half-batch stream too: a split layer backward leaves the second halves' bias / LayerNorm gradients in flight there)
+        self.reducer.extra_streams = [self.wgrad_stream, torch.cuda.current_stream() if self.state.flat_p.is_cuda else None,
+                                      ops.half_stream(self.state.flat_p.device) if self.state.flat_p.is_cuda else None]
         self.wcache = None
         if self.state.flat_p.is_cuda and ops.compute_dtype() == torch.bfloat16:
             self.wcache = WeightCache(model, torch.bfloat16)

@@ -193,6 +193,7 @@ typedef struct a8_encoder_layer_bwd_desc {
     int dtype, B, T, H, d, dff;
     float p;
     uint32_t seed_attn, seed1, seed2;
+    int b0;                  /* as in a8_encoder_layer_desc: first utterance of this call in the logical batch (dropout counters) */
     const void *dx2, *x, *qkv, *o, *ao, *x1, *z1, *f; const uint8_t* keymask;
     const float *lse, *mean2, *rstd2, *mean1, *rstd1, *g1, *g2;
     const void *w2_t, *w1_t, *wo_t;

@@ -46,6 +46,7 @@ def apply(d):
     ops.COMPOSITE_ENCODER_BWD = bool(d.get("compbwd", 1))
     ops.WGRAD_STORE_FIRST = bool(d.get("storefirst", 1))
     ops.HALF_BATCH_STREAMS = bool(d.get("half", 1))
+    ops.HALF_BATCH_BWD = bool(d.get("halfbwd", 1))
     ops.SPLITK_SLOTS = d.get("skslots", 512)
     ops.SPLITK_MIN_ROWS = d.get("skrows", 800)
 
