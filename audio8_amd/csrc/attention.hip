@@ -406,11 +406,21 @@ __global__ __launch_bounds__(NW * 64, MW) void attn_fwd_kernel(const AttnP P) {
     }
 }
 
+// Occupancy the backward kernels are compiled for.  Left to itself the register allocator aims at 3 waves per SIMD (a 168-VGPR budget),
+// parks the dK / dV (dQ) accumulators in AGPRs and copies them in and out around every VGPR-form MFMA: 129 of the 398 vector
+// instructions of the dK/dV loop were v_accvgpr_read / write -- and 164 + 40 registers run at 2 waves per SIMD anyway.
+#define A8_ATTN_WPE(T, G, MW) ((MW) > 1 ? (MW) : ((G) == 1 && sizeof(T) == 2 ? 2 : 1))
+// Dropout / key-mask presence as template flags (0 = off, 1 = on, 2 = read from the parameters at run time): with run-time tests the
+// 16 scores of a lane are 16 basic blocks -- a wave-uniform branch each -- and nothing of one score's exp / hash chain overlaps the next's.
+#define A8_ATTN_FLAG(F, runtime) ((F) == 2 ? (runtime) : (F) == 1)
+
 // ================================================================== backward A: dK, dV (key block stationary)
 // block = NW waves, each wave owns G groups of 16 keys; streams Q / dO tiles (+ lse, delta of the tile's queries)
-template <typename T, int NW, int G, int MW = 1>
-__global__ __launch_bounds__(NW * 64, MW) void attn_bwd_kv_kernel(const AttnP P) {
+template <typename T, int NW, int G, int MW = 1, int DROP = 2, int MASK = 2>
+__global__ __launch_bounds__(NW * 64, MW) __attribute__((amdgpu_waves_per_eu(A8_ATTN_WPE(T, G, MW), A8_ATTN_WPE(T, G, MW))))
+void attn_bwd_kv_kernel(const AttnP P) {
     constexpr int NT = NW * 64, BK = NW * G * 16, TB = ATile<T>::BYTES, NBUF = attn_nbuf<T>();
+    const bool drop = A8_ATTN_FLAG(DROP, P.thr != 0), masked = A8_ATTN_FLAG(MASK, P.keymask != nullptr);
     __shared__ __attribute__((aligned(16))) char lds[NBUF * 2 * TB];
     __shared__ __attribute__((aligned(16))) float s_stat[NBUF][2][BT];     // [buffer][lse | delta][query in tile]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
@@ -436,7 +446,7 @@ __global__ __launch_bounds__(NW * 64, MW) void attn_bwd_kv_kernel(const AttnP P)
         const bool ok = key[j] < P.T;
         kf[j].load(kb + (long long)key[j] * P.ld_qkv, ok, lane);
         vf[j].load(vb + (long long)key[j] * P.ld_qkv, ok, lane);
-        key_masked[j] = P.keymask && ok && !P.keymask[(long long)b * P.T + key[j]];
+        key_masked[j] = masked && ok && !P.keymask[(long long)b * P.T + key[j]];
         hk[j] = (pair_base(bh + P.bh0, P.T, P.Th, 4 * g) + (uint32_t)(key[j] >> 2) + P.seed) * HC1;
         hc2[j] = HC2 << (8 * (3 - (key[j] & 3)));
 #pragma unroll
@@ -484,10 +494,10 @@ __global__ __launch_bounds__(NW * 64, MW) void attn_bwd_kv_kernel(const AttnP P)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float x = __builtin_fmaf(s[j][i][r], P.scale, -lse4[r]);
-                    if (P.keymask && key_masked[j]) x = MASKED_LOG2 - lse4[r];
+                    if (masked && key_masked[j]) x = MASKED_LOG2 - lse4[r];
                     const float p = fast_exp2(x);      // keys beyond T: harmless garbage in rows that are never stored
                     float pdrop = p, dpv = dp[j][i][r];
-                    if (P.thr) {
+                    if (drop) {
                         uint32_t hh = hk[j] + (uint32_t)(16 * i + r) * ThC;
                         hh = (hh ^ (hh >> 15)) * hc2[j];                  // = hfin() with the key's 8-bit field in bits 31..24
                         const bool keep = hh >= (P.thr << 24);
@@ -531,9 +541,11 @@ __global__ __launch_bounds__(NW * 64, MW) void attn_bwd_kv_kernel(const AttnP P)
 }
 
 // ================================================================== backward B: dQ (query block stationary)
-template <typename T, int NW, int G, int MW = 1>
-__global__ __launch_bounds__(NW * 64, MW) void attn_bwd_q_kernel(const AttnP P) {
+template <typename T, int NW, int G, int MW = 1, int DROP = 2, int MASK = 2>
+__global__ __launch_bounds__(NW * 64, MW) __attribute__((amdgpu_waves_per_eu(A8_ATTN_WPE(T, G, MW), A8_ATTN_WPE(T, G, MW))))
+void attn_bwd_q_kernel(const AttnP P) {
     constexpr int NT = NW * 64, BQ = NW * G * 16, TB = ATile<T>::BYTES, NBUF = attn_nbuf<T>();
+    const bool drop = A8_ATTN_FLAG(DROP, P.thr != 0), masked = A8_ATTN_FLAG(MASK, P.keymask != nullptr);
     __shared__ __attribute__((aligned(16))) char lds[NBUF * 2 * TB];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
     int blk, bh;
@@ -544,7 +556,7 @@ __global__ __launch_bounds__(NW * 64, MW) void attn_bwd_q_kernel(const AttnP P) 
     const T* vb = reinterpret_cast<const T*>(P.v) + (long long)b * P.T * P.ld_qkv + h * DH;
     const T* dob = reinterpret_cast<const T*>(P.dout) + (long long)b * P.T * P.ld_o + h * DH;
     const T* ob = reinterpret_cast<const T*>(P.o) + (long long)b * P.T * P.ld_o + h * DH;
-    const uint8_t* km = P.keymask ? P.keymask + (long long)b * P.T : nullptr;
+    const uint8_t* km = masked ? P.keymask + (long long)b * P.T : nullptr;
     const int ntiles = (P.T + BT - 1) / BT;
 
     RowFrags<T> qf[G], dof[G];
@@ -584,17 +596,17 @@ __global__ __launch_bounds__(NW * 64, MW) void attn_bwd_q_kernel(const AttnP P) 
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 uint32_t h0 = 0;
-                if (P.thr) h0 = hfin(hb[j] + (uint32_t)(4 * i) * HC1);
+                if (drop) h0 = hfin(hb[j] + (uint32_t)(4 * i) * HC1);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float x = __builtin_fmaf(s[j][i][r], P.scale, nlse[j]);
-                    if (km) {                                                  // wave-uniform
+                    if (masked) {                                              // wave-uniform
                         const int key = kt_i * BT + 4 * g + 16 * i + r;
                         if (key < P.T && !km[key]) x = MASKED_LOG2 + nlse[j];
                     }
                     const float p = fast_exp2(x);
                     float dpv = dp[j][i][r];
-                    if (P.thr) dpv = (((h0 >> (8 * r)) & 0xFFu) >= P.thr) ? dpv : 0.f;
+                    if (drop) dpv = (((h0 >> (8 * r)) & 0xFFu) >= P.thr) ? dpv : 0.f;
                     s[j][i][r] = p * __builtin_fmaf(dpv, P.pscale, ndelta[j]);      // dS^T[key][q] / softmax scale
                 }
             }
@@ -901,6 +913,18 @@ int check_common(const char* what, int dtype, int B, int T_, int H, long long ld
         }                                                                                                                      \
     }
 
+// the default 4 x 1 geometry of the 16-bit backward kernels, dropout / key mask resolved at compile time
+#define A8_ATTN_LAUNCH_FLAGS(KERN)                                                                                             \
+    {                                                                                                                          \
+        const dim3 grid(cdiv(T_, 64) * B * H), blk(256);                                                                      \
+        switch (flags) {                                                                                                       \
+            case 0: hipLaunchKernelGGL((KERN<bf16, 4, 1, 1, 0, 0>), grid, blk, 0, s, P); break;                               \
+            case 1: hipLaunchKernelGGL((KERN<bf16, 4, 1, 1, 1, 0>), grid, blk, 0, s, P); break;                               \
+            case 2: hipLaunchKernelGGL((KERN<bf16, 4, 1, 1, 0, 1>), grid, blk, 0, s, P); break;                               \
+            default: hipLaunchKernelGGL((KERN<bf16, 4, 1, 1, 1, 1>), grid, blk, 0, s, P); break;                              \
+        }                                                                                                                      \
+    }
+
 }  // namespace
 
 int a8i_attn_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* keymask,
@@ -944,8 +968,11 @@ int a8i_attn_bwd(int dtype, const void* q, const void* k, const void* v, const v
     P.bh0 = bh0;
     hipStream_t s = (hipStream_t)stream;
     // dQ first: it computes delta = rowsum(dO * O) for its own query rows and publishes it for the dK/dV kernel
-    A8_ATTN_LAUNCH(attn_bwd_q_kernel, 4, "a8_attn_bwd")
-    A8_ATTN_LAUNCH(attn_bwd_kv_kernel, 3, "a8_attn_bwd")
+    const int flags = (P.thr != 0 ? 1 : 0) + (keymask ? 2 : 0);
+    if (dtype == A8_BF16 && g_a8_tuning[4] == 41) A8_ATTN_LAUNCH_FLAGS(attn_bwd_q_kernel)
+    else A8_ATTN_LAUNCH(attn_bwd_q_kernel, 4, "a8_attn_bwd")
+    if (dtype == A8_BF16 && g_a8_tuning[3] == 41) A8_ATTN_LAUNCH_FLAGS(attn_bwd_kv_kernel)
+    else A8_ATTN_LAUNCH(attn_bwd_kv_kernel, 3, "a8_attn_bwd")
     return a8_check_launch("a8_attn_bwd");
 }
 
