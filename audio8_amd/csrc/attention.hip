@@ -196,6 +196,7 @@ struct AttnP {
     int B, T, H;
     long long ld_qkv, ld_o, ld_d;
     float scale, pscale, dscale;   // scale = softmax scale * log2(e) (scores and lse live in the log2 domain); dscale = softmax scale
+    float ipscale;                 // 1 / pscale = the realised keep probability (exact: (256 - thr) / 256)
     float lazy;                    // raise the running max only past this margin (log2 units)
     uint32_t thr, seed;            // thr: 8-bit keep threshold (0 = dropout off)
     int Th;                        // key quads per query row = ceil(T / 4)
@@ -209,6 +210,8 @@ constexpr float MASKED_LOG2 = -1.4426950408889634e9f;      // masked_fill(-1e9) 
 A8_DEV uint32_t hfin(uint32_t h) { h ^= h >> 15; return h * HC2; }
 A8_DEV uint32_t pair_base(int bh, int T, int Th, int q) { return ((uint32_t)bh * (uint32_t)T + (uint32_t)q) * (uint32_t)Th; }
 A8_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// lane (4k + R)'s value in all four lanes of quad k (v_mov_b32_dpp quad_perm:[R,R,R,R]; the compiler folds it into the consumer)
+template <int R> A8_DEV uint32_t quad_bcast(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, R * 0x55, 0xF, 0xF, true); }
 
 // 1-D grid -> (tile block, batch*head).  Workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so
 // when B*H divides by 8 every block of one (batch, head) is placed on the same XCD and its K/V (or Q/dO) panel
@@ -438,8 +441,11 @@ void attn_bwd_kv_kernel(const AttnP P) {
     f32x4 dk[G][4], dv[G][4];
     int key[G];
     bool key_masked[G];
-    uint32_t hk[G], hc2[G];       // dropout word of (query qq, key): fin(hk + (qq - tile base - 4g) * ThC), field (key & 3);
-                                  // the final multiplier is HC2 << 8 (3 - field), which moves the key's byte to the top
+    // Dropout word of (query qq, key): fin(hk + (qq - tile base - 4g) * ThC), 8-bit field (key & 3).  The four lanes of a quad hold
+    // the four keys of one key quad, so they need the SAME 16 words per tile: lane (key & 3) = r hashes the words of the queries
+    // 16 i + 4 g + r only (4 instead of 16 hashes; the 32-bit multiply is a quarter-rate instruction) and the quad exchanges them by DPP.
+    uint32_t hk[G];
+    const uint32_t fmask = 0xFFu << (8 * (li & 3)), fthr = P.thr << (8 * (li & 3));
 #pragma unroll
     for (int j = 0; j < G; ++j) {
         key[j] = blk * BK + (wv * G + j) * 16 + li;
@@ -447,8 +453,7 @@ void attn_bwd_kv_kernel(const AttnP P) {
         kf[j].load(kb + (long long)key[j] * P.ld_qkv, ok, lane);
         vf[j].load(vb + (long long)key[j] * P.ld_qkv, ok, lane);
         key_masked[j] = masked && ok && !P.keymask[(long long)b * P.T + key[j]];
-        hk[j] = (pair_base(bh + P.bh0, P.T, P.Th, 4 * g) + (uint32_t)(key[j] >> 2) + P.seed) * HC1;
-        hc2[j] = HC2 << (8 * (3 - (key[j] & 3)));
+        hk[j] = (pair_base(bh + P.bh0, P.T, P.Th, 4 * g + (li & 3)) + (uint32_t)(key[j] >> 2) + P.seed) * HC1;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { dk[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     }
@@ -490,22 +495,21 @@ void attn_bwd_kv_kernel(const AttnP P) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const f32x4 lse4 = *reinterpret_cast<const f32x4*>(stat + 16 * i + 4 * g);
-                const f32x4 del4 = *reinterpret_cast<const f32x4*>(stat + BT + 16 * i + 4 * g);
+                const f32x4 del4 = *reinterpret_cast<const f32x4*>(stat + BT + 16 * i + 4 * g);      // delta / pscale (see the dQ kernel)
+                uint32_t wr[4] = {0u, 0u, 0u, 0u};
+                if (drop) {
+                    const uint32_t w = hfin(hk[j] + (uint32_t)(16 * i) * ThC);       // this lane's share: query 16 i + 4 g + (key & 3)
+                    wr[0] = quad_bcast<0>(w); wr[1] = quad_bcast<1>(w); wr[2] = quad_bcast<2>(w); wr[3] = quad_bcast<3>(w);
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float x = __builtin_fmaf(s[j][i][r], P.scale, -lse4[r]);
                     if (masked && key_masked[j]) x = MASKED_LOG2 - lse4[r];
                     const float p = fast_exp2(x);      // keys beyond T: harmless garbage in rows that are never stored
-                    float pdrop = p, dpv = dp[j][i][r];
-                    if (drop) {
-                        uint32_t hh = hk[j] + (uint32_t)(16 * i + r) * ThC;
-                        hh = (hh ^ (hh >> 15)) * hc2[j];                  // = hfin() with the key's 8-bit field in bits 31..24
-                        const bool keep = hh >= (P.thr << 24);
-                        pdrop = keep ? p : 0.f;
-                        dpv = keep ? dpv : 0.f;
-                    }
+                    float pdrop = p;
+                    if (drop) pdrop = (wr[r] & fmask) >= fthr ? p : 0.f;
                     s[j][i][r] = pdrop;                                                  // P (dropped, unscaled) for dV
-                    dp[j][i][r] = p * __builtin_fmaf(dpv, P.pscale, -del4[r]);           // dS / softmax scale for dK
+                    dp[j][i][r] = __builtin_fmaf(pdrop, dp[j][i][r], -(p * del4[r]));    // dS / (softmax scale * pscale) for dK
                 }
             }
             hk[j] += (uint32_t)BT * ThC;
@@ -518,6 +522,7 @@ void attn_bwd_kv_kernel(const AttnP P) {
         xt_times_p<T, G>(qt, pd, dk, lane);
         ATTN_STREAM_END()
     }
+    const float kscale = P.dscale * P.pscale;
 #pragma unroll
     for (int j = 0; j < G; ++j)
         if (key[j] < P.T) {
@@ -525,7 +530,7 @@ void attn_bwd_kv_kernel(const AttnP P) {
             T* dvp = reinterpret_cast<T*>(P.dv) + ((long long)b * P.T + key[j]) * P.ld_d + h * DH + 4 * g;
 #pragma unroll
             for (int db = 0; db < 4; ++db) {
-                store4<T>(dkp + 16 * db, dk[j][db][0] * P.dscale, dk[j][db][1] * P.dscale, dk[j][db][2] * P.dscale, dk[j][db][3] * P.dscale);
+                store4<T>(dkp + 16 * db, dk[j][db][0] * kscale, dk[j][db][1] * kscale, dk[j][db][2] * kscale, dk[j][db][3] * kscale);
                 store4<T>(dvp + 16 * db, dv[j][db][0] * P.pscale, dv[j][db][1] * P.pscale, dv[j][db][2] * P.pscale, dv[j][db][3] * P.pscale);
             }
         }
@@ -535,7 +540,7 @@ void attn_bwd_kv_kernel(const AttnP P) {
         for (int j = 0; j < G; ++j) ok[j] = key[j] < P.T;
         float* red = reinterpret_cast<float*>(lds);
         const int d = P.H * DH;
-        block_colsum<G, NW>(dk, ok, P.dscale, P.dbias + d + h * DH, red, wv, lane);
+        block_colsum<G, NW>(dk, ok, kscale, P.dbias + d + h * DH, red, wv, lane);
         block_colsum<G, NW>(dv, ok, P.pscale, P.dbias + 2 * d + h * DH, red, wv, lane);
     }
 }
@@ -577,7 +582,7 @@ void attn_bwd_q_kernel(const AttnP P) {
             of.load(ob + (long long)qi[j] * P.ld_o, ok, lane);
             const float dl = row_dot(of, dof[j]);
             ndelta[j] = -dl;
-            if (ok && g == 0) P.delta[(long long)bh * P.T + qi[j]] = dl;
+            if (ok && g == 0) P.delta[(long long)bh * P.T + qi[j]] = dl * P.ipscale;      // (the dK/dV kernel works in units of pscale)
         }
         hb[j] = (pair_base(bh + P.bh0, P.T, P.Th, qi[j]) + (uint32_t)g + P.seed) * HC1;
 #pragma unroll
@@ -880,6 +885,7 @@ void set_softmax_params(AttnP& P, float scale, float p, uint32_t seed) {
     if (thr > 255u) thr = 255u;
     P.thr = thr;
     P.pscale = thr ? 256.0f / (256.0f - (float)thr) : 1.0f;            // unbiased for the realised keep probability
+    P.ipscale = (256.0f - (float)thr) / 256.0f;
     P.seed = seed;
 }
 
@@ -914,14 +920,14 @@ int check_common(const char* what, int dtype, int B, int T_, int H, long long ld
     }
 
 // the default 4 x 1 geometry of the 16-bit backward kernels, dropout / key mask resolved at compile time
-#define A8_ATTN_LAUNCH_FLAGS(KERN)                                                                                             \
+#define A8_ATTN_LAUNCH_FLAGS(KERN, NW_, G_, W)                                                                                           \
     {                                                                                                                          \
-        const dim3 grid(cdiv(T_, 64) * B * H), blk(256);                                                                      \
+        const dim3 grid(cdiv(T_, NW_ * G_ * 16) * B * H), blk(NW_ * 64);                                                      \
         switch (flags) {                                                                                                       \
-            case 0: hipLaunchKernelGGL((KERN<bf16, 4, 1, 1, 0, 0>), grid, blk, 0, s, P); break;                               \
-            case 1: hipLaunchKernelGGL((KERN<bf16, 4, 1, 1, 1, 0>), grid, blk, 0, s, P); break;                               \
-            case 2: hipLaunchKernelGGL((KERN<bf16, 4, 1, 1, 0, 1>), grid, blk, 0, s, P); break;                               \
-            default: hipLaunchKernelGGL((KERN<bf16, 4, 1, 1, 1, 1>), grid, blk, 0, s, P); break;                              \
+            case 0: hipLaunchKernelGGL((KERN<bf16, NW_, G_, W, 0, 0>), grid, blk, 0, s, P); break;                               \
+            case 1: hipLaunchKernelGGL((KERN<bf16, NW_, G_, W, 1, 0>), grid, blk, 0, s, P); break;                               \
+            case 2: hipLaunchKernelGGL((KERN<bf16, NW_, G_, W, 0, 1>), grid, blk, 0, s, P); break;                               \
+            default: hipLaunchKernelGGL((KERN<bf16, NW_, G_, W, 1, 1>), grid, blk, 0, s, P); break;                              \
         }                                                                                                                      \
     }
 
@@ -969,9 +975,9 @@ int a8i_attn_bwd(int dtype, const void* q, const void* k, const void* v, const v
     hipStream_t s = (hipStream_t)stream;
     // dQ first: it computes delta = rowsum(dO * O) for its own query rows and publishes it for the dK/dV kernel
     const int flags = (P.thr != 0 ? 1 : 0) + (keymask ? 2 : 0);
-    if (dtype == A8_BF16 && g_a8_tuning[4] == 41) A8_ATTN_LAUNCH_FLAGS(attn_bwd_q_kernel)
+    if (dtype == A8_BF16 && g_a8_tuning[4] == 41) A8_ATTN_LAUNCH_FLAGS(attn_bwd_q_kernel, 4, 1, 1)
     else A8_ATTN_LAUNCH(attn_bwd_q_kernel, 4, "a8_attn_bwd")
-    if (dtype == A8_BF16 && g_a8_tuning[3] == 41) A8_ATTN_LAUNCH_FLAGS(attn_bwd_kv_kernel)
+    if (dtype == A8_BF16 && g_a8_tuning[3] == 41) A8_ATTN_LAUNCH_FLAGS(attn_bwd_kv_kernel, 4, 1, 3)
     else A8_ATTN_LAUNCH(attn_bwd_kv_kernel, 3, "a8_attn_bwd")
     return a8_check_launch("a8_attn_bwd");
 }
