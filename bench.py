@@ -171,6 +171,8 @@ def main():
         cfg.update(d_model=1024, num_heads=16, num_layers=24, d_ff=4096)
     model = W.create_model(16, **cfg).to(dev).train()
     loss_fn = W.create_loss(640, 100)
+    if os.environ.get("A8_HALF_BATCH", "1") == "0":                         # developer knob (tools/prof_serial.sh): one stream, whole batch
+        ops.HALF_BATCH_STREAMS = False
     stepper = Stepper(model, lr=2.0e-4, weight_decay=1.0e-2, clip=1.0, bucket_mb=args.bucket_mb,
                       wgrad_side_stream=os.environ.get("A8_SIDE_WGRAD", "1") != "0")
     ops.GROUP_WGRAD = os.environ.get("A8_GROUP_WGRAD", "1") != "0"
