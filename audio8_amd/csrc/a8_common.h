@@ -69,15 +69,24 @@ A8_DEV float rows_sum(float x) {
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+// Whole-wave reductions, all-VALU: four DPP steps inside each row of 16 lanes (quad xor 1, quad xor 2, half-row mirror, row mirror),
+// then the two permlane swaps across the rows -- no ds_bpermute (six dependent LDS-crossbar round trips per value before).
+template <int CTRL> A8_DEV float dpp_f(float v) {
+    return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xF, 0xF, true));
+}
 A8_DEV float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_f<0xB1>(v);          // quad_perm:[1,0,3,2]
+    v += dpp_f<0x4E>(v);          // quad_perm:[2,3,0,1]
+    v += dpp_f<0x141>(v);         // row_half_mirror
+    v += dpp_f<0x140>(v);         // row_mirror
+    return rows_sum(v);
 }
 A8_DEV float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_f<0xB1>(v));
+    v = fmaxf(v, dpp_f<0x4E>(v));
+    v = fmaxf(v, dpp_f<0x141>(v));
+    v = fmaxf(v, dpp_f<0x140>(v));
+    return rows_max(v);
 }
 // block-wide sum for blockDim.x = NW*64 threads; `red` is NW floats of LDS scratch.
 template <int NW> A8_DEV float block_sum(float v, float* red) {
