@@ -851,6 +851,10 @@ class EncoderLayerFn(torch.autograd.Function):
         wo_c, wo_t = eo if eo is not None else (_wcast(wo, dt), None)
         w1_c, w1_t = e1 if e1 is not None else (_wcast(w1, dt), None)
         w2_c, w2_t = e2 if e2 is not None else (_wcast(w2, dt), None)
+        if HALF_STREAM is not None and (eq is None or eo is None or e1 is None or e2 is None):
+            # no prepared weight copies (no Stepper): the casts above were enqueued on this stream just now, and the half-batch stream
+            # only met this one at the top of the stack
+            HALF_STREAM.wait_stream(torch.cuda.current_stream())
         if COMPOSITE_ENCODER_FWD and K.GEMM_PROFILE is None and x.is_contiguous():
             # the whole launch sequence below behind one C call (a8_encoder_layer_fwd); the per-launch path stays for the instrumented
             # roofline steps of bench.py (per-GEMM events) and as the readable statement of the sequence

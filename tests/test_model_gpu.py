@@ -683,7 +683,7 @@ def test_half_batch_two_stream_backward_matches_whole_batch(restore_dtype):
         for B, ld in ((4, 0.0), (3, 0.0), (4, 0.5)):
             l0, g0, p0 = run(False, B, ld)
             l1, g1, p1 = run(True, B, ld)
-            assert l0[0] == l1[0], (B, l0, l1)
+            assert abs(l0[0] - l1[0]) <= 2e-6 * abs(l0[0]), (B, l0, l1)      # same forward; the loss heads sum with f32 atomics
             assert torch.isfinite(g1).all()
             scale = float(g0.abs().max())
             err = float((g0 - g1).abs().max())
