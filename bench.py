@@ -315,7 +315,11 @@ def main():
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_gemm_traffic.json")))
         if cands and default_wl:
             tj = json.load(open(cands[-1]))        # HBM bytes per launch from separate rocprofv3 --pmc passes of this same command (newest round)
-            traffic, traffic_src = round(tj["hbm_bytes_per_launch"]), "profiles/%s (%s)" % (os.path.basename(cands[-1]), tj["method"])
+            # (per launch of THIS line's launch count: the timed step runs the encoder as two half-batches, i.e. more and smaller
+            # launches than the instrumented whole-batch step whose algorithmic bytes stand beside it; the step total is what compares)
+            traffic = round(tj["hbm_bytes_per_step"] / max(1, len(prof))) if "hbm_bytes_per_step" in tj else round(tj["hbm_bytes_per_launch"])
+            traffic_src = "profiles/%s (%s; %.2f GB per step over the GEMM kernels of the step as timed)" % (
+                os.path.basename(cands[-1]), tj["method"], tj.get("hbm_bytes_per_step", 0) / 1e9)
             conv_pmc = tj.get("conv_extractor_fwd_hbm_bytes")
         # ---- north-star components (SURVEY 8d algorithmic work; times from the SERIALISED instrumented step: every kernel of the
         # component back to back on one stream -- its own rate, no credit for overlap)
