@@ -62,6 +62,7 @@ ARGTYPES = {
     "a8_contrastive_fwd": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "a8_contrastive_bwd": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "a8_ctc_pack_targets": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "a8_host_negative_indices": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "a8_ctc_fwd_bwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "a8_log_softmax_fwd": [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "a8_log_softmax_bwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
@@ -170,5 +171,5 @@ EXPORTS = [
     "a8_vq_select", "a8_vq_gather", "a8_vq_ppl", "a8_vq_bwd",
     "a8_contrastive_fwd", "a8_contrastive_bwd", "a8_loss_combine", "a8_loss_combine_bwd", "a8_ctc_greedy_decode",
     "a8_ctc_pack_targets", "a8_ctc_fwd_bwd", "a8_log_softmax_fwd", "a8_log_softmax_bwd",
-    "a8_sumsq", "a8_adamw", "a8_zero", "a8_conv_wgrad_fold",
+    "a8_sumsq", "a8_adamw", "a8_zero", "a8_conv_wgrad_fold", "a8_host_negative_indices",
 ]

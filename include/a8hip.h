@@ -287,6 +287,13 @@ int a8_adamw(float* p, float* g, float* m, float* v, int64_t n, float lr, float 
              float weight_decay, int step, const float* gnorm_sq, float max_norm, float grad_scale, const int64_t* grad_denom,
              int zero_grad, void* stream);
 
+/* ---- host side of the boundary (no GPU work) ----
+ * Negative indices of the contrastive loss exactly as the reference draws them: np.random.randint(0, T - 1, (B, n_neg * T)), the
+ * ">= own frame -> +1" shift and the per-utterance row offset (audio8/wav2vec2.py:955-976), on a copy of numpy's global MT19937 state
+ * (np.random.get_state(): key[624], pos) that is advanced exactly as numpy would advance it.  out: int32 [B, n_neg * T] flat row
+ * indices into [B * T, C].  T is the number of masked frames per utterance. */
+int a8_host_negative_indices(uint32_t* key, int* pos, int B, int T, int n_neg, int32_t* out);
+
 #ifdef __cplusplus
 }
 #endif

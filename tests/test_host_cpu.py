@@ -207,3 +207,37 @@ def test_g9_key_maps_and_convert_keys_equal_the_reference(golden_dir):
         broken.pop(next(iter(cm.flat)))
         with pytest.raises(KeyError):
             W.convert_keys(int(g[f"{tag}_layers"]), broken, cm.nested, cm.flat)
+
+
+def test_native_negative_sampler_is_numpy_bit_for_bit():
+    """a8_host_negative_indices restates numpy's legacy randint (MT19937, masked rejection) on a copy of the global state: same indices
+    as the reference's numpy statement (audio8/wav2vec2.py:962-970) and the SAME generator state afterwards (the next draws of the global
+    RNG agree), for ranges on both sides of a power of two, across several state regenerations, from every starting position."""
+    import numpy as np
+    from audio8_amd import wav2vec2 as W
+    for seed, B, T, N in ((0, 8, 355, 100), (1, 3, 2, 5), (2, 1, 3, 7), (3, 2, 257, 10), (4, 2, 258, 10), (5, 4, 1025, 3), (6, 5, 64, 100)):
+        s = W.Sampler(N)
+        for burn in (0, 1, 623, 624, 1000):
+            np.random.seed(seed)
+            if burn:
+                np.random.randint(0, 2 ** 31 - 1, burn)
+            want = s.indices_numpy(B, T)
+            tail_want = (np.random.random(), np.random.randint(0, 1000, 5).tolist(), np.random.normal())
+            np.random.seed(seed)
+            if burn:
+                np.random.randint(0, 2 ** 31 - 1, burn)
+            got = s.indices(B, T)
+            tail_got = (np.random.random(), np.random.randint(0, 1000, 5).tolist(), np.random.normal())
+            assert got.dtype == (np.int32 if T >= 3 else want.dtype)
+            assert np.array_equal(got, want), (seed, B, T, N, burn)
+            assert tail_got == tail_want, (seed, B, T, N, burn)
+    # a pending cached Gaussian survives the round trip through get_state / set_state
+    np.random.seed(9)
+    np.random.normal()
+    a = W.Sampler(4).indices(2, 50)
+    g1 = np.random.normal()
+    np.random.seed(9)
+    np.random.normal()
+    b = W.Sampler(4).indices_numpy(2, 50)
+    g2 = np.random.normal()
+    assert np.array_equal(a, b) and g1 == g2
