@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liba8hip.so")
+LIB_PATH = os.environ.get("A8HIP_LIB") or os.path.join(_HERE, "liba8hip.so")      # (A8HIP_LIB: developer A/B of two builds)
 
 F32, BF16 = 0, 1
 NT, NN, TN = 0, 1, 2

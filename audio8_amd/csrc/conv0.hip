@@ -175,7 +175,8 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restric
         float v[8], xv[KW];
         conv_frame(xs, tl, w, v, xv);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = gelu_f(fmaf(v[j], sc[j], sh[j]));
+        for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], sc[j], sh[j]);
+        gelu_n(v);
         st8(out + ((long long)b * L0 + t0 + tl) * CC + c0, v);
     }
 }
@@ -252,11 +253,12 @@ __global__ __launch_bounds__(256) void conv0_apply_mfma_kernel(const float* __re
                 for (int j = 0; j < 4; ++j) u[j] = Mma<bf16>::mma(wf[j], xf[ft], (f32x4){0.f, 0.f, 0.f, 0.f});
                 const int t = t0 + 64 * wv + 16 * ft + li;
                 bf16x8 o0, o1;                                     // channels 64 S + 16 g + 4 j + r
+                float ua[8] = {u[0][0], u[0][1], u[0][2], u[0][3], u[1][0], u[1][1], u[1][2], u[1][3]};
+                float ub[8] = {u[2][0], u[2][1], u[2][2], u[2][3], u[3][0], u[3][1], u[3][2], u[3][3]};
+                gelu_n(ua);
+                gelu_n(ub);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    o0[r] = (bf16)gelu_f(u[0][r]); o0[4 + r] = (bf16)gelu_f(u[1][r]);
-                    o1[r] = (bf16)gelu_f(u[2][r]); o1[4 + r] = (bf16)gelu_f(u[3][r]);
-                }
+                for (int r = 0; r < 8; ++r) { o0[r] = (bf16)ua[r]; o1[r] = (bf16)ub[r]; }
                 if (t < te) {
                     bf16* op = out + ((long long)b * L0 + t) * CC + 64 * S + 16 * g;
                     *reinterpret_cast<bf16x8*>(op) = o0;
@@ -339,10 +341,14 @@ __global__ __launch_bounds__(256) void conv0_bwd_main_kernel(const float* __rest
         float v[8], xv[KW], g[8];
         conv_frame(xs, tl, w, v, xv);
         ld8(dout + ((long long)b * L0 + t0 + tl) * CC + c0, g);
+        float zz[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) zz[j] = fmaf((v[j] - mu[j]) * rs[j], gw[j], gb[j]);
+        mul_gelu_grad_n(g, zz);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float xh = (v[j] - mu[j]) * rs[j];
-            const float du = g[j] * gelu_grad_f(fmaf(xh, gw[j], gb[j]));
+            const float du = g[j];
             s1[j] += du;
             s2[j] = fmaf(du, xh, s2[j]);
 #pragma unroll
@@ -484,12 +490,15 @@ __global__ __launch_bounds__(256, 2) void conv0_bwd_mfma_kernel(const float* __r
                 // xh[frame 4 g + r][channel cbase + j]: frames are the MFMA's rows, channels its columns
                 const f32x4 h0 = Mma<bf16>::mma(xf0, wf[j], (f32x4){0.f, 0.f, 0.f, 0.f});
                 bf16x8 du = {0, 0, 0, 0, 0, 0, 0, 0};
+                float dd[4], zz[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { dd[r] = (float)dg[r][j]; zz[r] = fmaf(h0[r], gw[j], gb[j]); }
+                mul_gelu_grad_n(dd, zz);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float d0 = (float)dg[r][j] * gelu_grad_f(fmaf(h0[r], gw[j], gb[j]));
-                    s1[j] += d0;
-                    s2[j] = fmaf(d0, h0[r], s2[j]);
-                    du[r] = (bf16)d0;
+                    s1[j] += dd[r];
+                    s2[j] = fmaf(dd[r], h0[r], s2[j]);
+                    du[r] = (bf16)dd[r];
                 }
                 // A[channel 8 i + j][tap] += sum over the 16 frames (k-slots 4 .. 7 of every lane group are zero on both sides)
                 accA[j] = Mma<bf16>::mma(du, x2, accA[j]);

@@ -192,12 +192,13 @@ A8_DEV void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MI][NJ], char* lds, co
                     *reinterpret_cast<T8*>(reinterpret_cast<T*>(g.zout) + zrow(m) + n) = zv;
                 }
                 if (g.act == A8_ACT_GELU) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+                    gelu_n(v);
                 } else if (g.act == A8_ACT_MUL_GELU_GRAD) {
                     const T8 zz = use_zpre ? zpre[NP == 1 ? it : 0] : *reinterpret_cast<const T8*>(reinterpret_cast<const T*>(g.zin) + zrow(m) + n);
+                    float zf[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(to_f(zz[e]));
+                    for (int e = 0; e < 8; ++e) zf[e] = to_f(zz[e]);
+                    mul_gelu_grad_n(v, zf);
                 } else if (g.act == A8_ACT_ADD) {
                     const T8 zz = use_zpre ? zpre[NP == 1 ? it : 0] : *reinterpret_cast<const T8*>(reinterpret_cast<const T*>(g.zin) + zrow(m) + n);
 #pragma unroll
@@ -683,12 +684,13 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs g) {
                 *reinterpret_cast<T4*>(reinterpret_cast<T*>(g.zout) + zr + n) = zv;
             }
             if (g.act == A8_ACT_GELU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+                gelu_n(v);
             } else if (g.act == A8_ACT_MUL_GELU_GRAD) {
                 const T4 zz = *reinterpret_cast<const T4*>(reinterpret_cast<const T*>(g.zin) + zr + n);
+                float zf[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(to_f(zz[e]));
+                for (int e = 0; e < 4; ++e) zf[e] = to_f(zz[e]);
+                mul_gelu_grad_n(v, zf);
             } else if (g.act == A8_ACT_ADD) {
                 const T4 zz = *reinterpret_cast<const T4*>(reinterpret_cast<const T*>(g.zin) + zr + n);
 #pragma unroll

@@ -255,8 +255,7 @@ __global__ __launch_bounds__(256) void gelu_bwd_bias_kernel(const T* __restrict_
             if (z) {
                 float zz[8];
                 load8(z + off, zz);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) g[i] *= gelu_grad_f(zz[i]);
+                mul_gelu_grad_n(g, zz);
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) ab[i] += g[i];
@@ -413,8 +412,7 @@ __global__ void col2im_kernel(const T* __restrict__ dcol, const T* __restrict__ 
         if (z) {
             float zz[8];
             load8(z + off, zz);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] *= gelu_grad_f(zz[j]);
+            mul_gelu_grad_n(acc, zz);
         }
         store8(dx + off, acc);
     }

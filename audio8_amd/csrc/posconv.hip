@@ -126,10 +126,7 @@ __global__ __launch_bounds__(512) void posconv_fwd_kernel(const PosP P) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) zp[r] = from_f<T>(v[r]);
             }
-            if (P.apply_gelu) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
-            }
+            if (P.apply_gelu) gelu_n(v);
             if (P.add_residual) {
                 const T* rp = reinterpret_cast<const T*>(P.res) + off;
 #pragma unroll
