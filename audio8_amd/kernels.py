@@ -380,6 +380,14 @@ def zeros(shape, dtype, device):
     return t
 
 
+def zero_(t):
+    """t.zero_() as a memset on the current stream (device tensors; contiguous)."""
+    if not t.is_cuda:
+        return t.zero_()
+    L.check(L.lib().a8_zero(L.ptr(t), t.numel() * t.element_size(), L.stream()), "a8_zero")
+    return t
+
+
 def conv_wgrad_fold_(dw2, grad, co, cin, k):
     """grad[co][cin][k] += dw2[co][k][cin]; dw2 is zero again afterwards."""
     L.require_cuda(dw2, grad)

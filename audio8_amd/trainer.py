@@ -605,7 +605,7 @@ class Stepper:
         else:                                            # MEAN over ranks
             scale = 1.0 if self._mean_applied else 1.0 / world
         if self.reducer.norm_sq is None or self._mean_applied:
-            self.gnorm_sq.zero_()
+            K.zero_(self.gnorm_sq)
             K.sumsq_(st.flat_g, self.gnorm_sq)
         for lo, hi, nstep in self._active_runs():
             K.adamw_(st.flat_p[lo:hi], st.flat_g[lo:hi], st.flat_m[lo:hi], st.flat_v[lo:hi], lr, self.betas[0], self.betas[1],
