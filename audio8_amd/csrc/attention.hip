@@ -900,16 +900,15 @@ int check_common(const char* what, int dtype, int B, int T_, int H, long long ld
 }
 
 // launch geometry (a8_set_tuning keys 2 = forward, 3 = dK/dV, 4 = dQ): value = waves_per_block * 10 + row groups per wave
-// (+ 100 * W: the 4 x 1 geometry compiled for at least W = 4 or 5 waves per SIMD, i.e. a 128 / 96 register cap)
+// (any hundreds digit: the same geometry through this generic macro, i.e. with run-time dropout / mask flags -- 141 is the A/B partner
+// of the flag-specialised default 41 of the backward kernels)
 #define A8_ATTN_LAUNCH(KERN, key, what)                                                                                       \
     {                                                                                                                          \
         const int tun = g_a8_tuning[key] >= 10 ? g_a8_tuning[key] : 41;            /* (< 10 selects the 32x32 16-bit forward kernel; f32 data: 4 x 1) */ \
-        const int geo = tun % 100, mw = tun / 100, nw = geo / 10, grp = geo % 10, rows = nw * grp * 16; \
+        const int geo = tun % 100, nw = geo / 10, grp = geo % 10, rows = nw * grp * 16;                                       \
         const dim3 grid(cdiv(T_, rows) * B * H), blk(nw * 64);                                                                 \
         if (dtype == A8_BF16) {                                                                                                \
-            if (geo == 41 && mw == 5) hipLaunchKernelGGL((KERN<bf16, 4, 1, 5>), grid, blk, 0, s, P);                          \
-            else if (geo == 41 && mw == 4) hipLaunchKernelGGL((KERN<bf16, 4, 1, 4>), grid, blk, 0, s, P);                     \
-            else if (geo == 41) hipLaunchKernelGGL((KERN<bf16, 4, 1>), grid, blk, 0, s, P);                                   \
+            if (geo == 41) hipLaunchKernelGGL((KERN<bf16, 4, 1>), grid, blk, 0, s, P);                                        \
             else if (geo == 22) hipLaunchKernelGGL((KERN<bf16, 2, 2>), grid, blk, 0, s, P);                                   \
             else if (geo == 42) hipLaunchKernelGGL((KERN<bf16, 4, 2>), grid, blk, 0, s, P);                                   \
             else return a8_set_error(A8_ERR_ARG, "%s: bad tuning %d", what, geo);                                             \
