@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Attention launch-geometry / register-cap A/B at the cfg2 shape (interleaved rounds, one process).
-a8_set_tuning keys 2 (fwd), 3 (dK/dV), 4 (dQ): value = W*100 + waves*10 + groups."""
+a8_set_tuning keys 2 (fwd), 3 (dK/dV), 4 (dQ): value = waves*10 + groups (141: the default geometry with run-time flags)."""
 import os
 import sys
 
