@@ -201,6 +201,44 @@ def test_composite_encoder_calls_match_the_per_launch_path(restore_dtype, dtype)
             torch.testing.assert_close(g, outs[1][1][n], rtol=1e-5, atol=1e-7)
 
 
+def test_pretrain_step_parity_bf16_full_depth_base(restore_dtype):
+    """The benchmark dtype at the benchmark depth against the ORACLE (not against the product's own f32 mode): wav2vec2-base, 12 layers,
+    2 x 16 000 samples.  Stated tolerance of the bf16 mode (bf16 activations and residual stream, f32 accumulation / statistics / masters):
+    loss within 2e-3, the whole gradient within 20 % (relative L2) and cosine > 0.985 of the oracle's, every parameter's gradient within 20 %
+    of its own norm -- except where the gradient itself vanishes by cancellation: with random weights the upper layers attend almost
+    uniformly, their w_Q / w_K gradients are three orders of magnitude below w_V's (3e-7 against 9e-4 at layer 11) and what bf16 leaves of
+    them is rounding noise of dS = P (dP - delta).  Those (per-element RMS below 5 % of the median parameter's) must have an error below
+    that same 5 % of the median scale; the bias of the target projection, whose gradient is a residual of coefficients that sum to zero
+    per row, is held to the median scale itself."""
+    model, loss, loss_fn, sdg, loss_ref, aux = _pretrain_pair(torch.bfloat16, num_layers=12, seed=3)
+    np.testing.assert_allclose(loss.item(), loss_ref.item(), rtol=2e-3)
+    got = {k: p.grad.detach().float().cpu() for k, p in model.named_parameters()}
+    allg = torch.cat([got[k].flatten() for k in sdg])
+    allr = torch.cat([sdg[k].grad.flatten() for k in sdg])
+    gcos = float(torch.nn.functional.cosine_similarity(allg, allr, dim=0))
+    grel = float((allg - allr).norm() / allr.norm())
+    print("bf16, 12 layers: global cosine %.4f, global relative error %.3f" % (gcos, grel))
+    assert gcos > 0.985 and grel < 0.2, (gcos, grel)
+    # per-element RMS of each parameter's gradient, and the median over parameters as "the scale of a gradient in this model"
+    rms = {k: float(ref.grad.norm()) / ref.grad.numel() ** 0.5 for k, ref in sdg.items()}
+    med = float(np.median(list(rms.values())))
+    vanishing = {}
+    for k, ref in sdg.items():
+        if k.endswith("w_K.layer.bias"):
+            continue
+        err, rn = float((got[k] - ref.grad).norm()), float(ref.grad.norm())
+        if err <= 0.2 * rn:
+            continue
+        erms = err / ref.grad.numel() ** 0.5
+        vanishing[k] = (round(rms[k] / med, 5), round(erms / med, 5))
+        if k == "project_q.layer.bias":          # a shift of positives and negatives alike: the per-row loss coefficients sum to zero and
+            assert erms <= 1.0 * med, (k, erms / med)   # the gradient is their residual -- the error stays on the median gradient's scale
+            continue
+        assert rms[k] <= 0.05 * med and erms <= 0.05 * med, (k, err, rn, rms[k] / med, erms / med)
+    print("vanishing gradients (own RMS, error RMS as fractions of the median parameter's gradient RMS):", vanishing)
+    assert len(vanishing) <= 20
+
+
 def test_prefetched_host_draws_are_bit_identical(restore_dtype):
     """Two training steps with the next step's numpy draws taken ahead of time (prefetch_host_draws, right after
     backward) sample exactly the masks / negatives of two steps that draw inline -- same global-RNG call order --
