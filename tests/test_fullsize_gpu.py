@@ -277,3 +277,25 @@ def test_full_ctc_finetune_step_cfg5():
                 assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().sum() > 0, n
     finally:
         ops.set_compute_dtype(old)
+
+
+def test_cfg2_sequence_length_bf16_against_oracle():
+    """The benchmark dtype at the benchmark depth AND sequence length against the oracle: wav2vec2-base (12 layers), 2 x 250 000 samples
+    (T = 781 frames, 64-key attention tiles with a ragged last tile, conv layer 1 at 25 k rows per utterance); the oracle runs this in a
+    few seconds on the host.  Stated bf16 tolerance: loss within 2e-3, the whole gradient within 25 % (relative L2) of the oracle's and
+    cosine > 0.98; per-parameter detail is test_model_gpu.py::test_pretrain_step_parity_bf16_full_depth_base."""
+    from test_model_gpu import _pretrain_pair
+    from audio8_amd import ops
+    old = ops.compute_dtype()
+    try:
+        model, loss, loss_fn, sdg, loss_ref, aux = _pretrain_pair(torch.bfloat16, num_layers=12, B=2, L=250000, seed=1)
+        np.testing.assert_allclose(loss.item(), loss_ref.item(), rtol=2e-3)
+        got = {k: p.grad.detach().float().cpu() for k, p in model.named_parameters()}
+        allg = torch.cat([got[k].flatten() for k in sdg])
+        allr = torch.cat([sdg[k].grad.flatten() for k in sdg])
+        gcos = float(torch.nn.functional.cosine_similarity(allg, allr, dim=0))
+        grel = float((allg - allr).norm() / allr.norm())
+        print("bf16, 12 layers, T = 781: loss %.5f vs %.5f, global cosine %.4f, global relative error %.3f" % (loss.item(), loss_ref.item(), gcos, grel))
+        assert gcos > 0.98 and grel < 0.25, (gcos, grel)
+    finally:
+        ops.set_compute_dtype(old)
