@@ -163,7 +163,7 @@ def test_gemm_grouped_asymmetric_ring_matches_default():
         L.check(L.lib().a8_set_tuning(14, 1), "tune")
         got = run()
     finally:
-        L.check(L.lib().a8_set_tuning(14, 10000), "tune")
+        L.check(L.lib().a8_set_tuning(14, 1000), "tune")
     for r, g_ in zip(ref, got):
         assert torch.equal(r, g_)
 
@@ -197,7 +197,7 @@ def test_gemm_pipelined_256_kernel_matches_default(key):
             L.check(L.lib().a8_set_tuning(key, 1), "tune")
             got = fn()
         finally:
-            for k_, v_ in {**saved, 14: 10000}.items():                 # back to the library defaults
+            for k_, v_ in {**saved, 14: 1000}.items():                 # back to the library defaults
                 L.check(L.lib().a8_set_tuning(k_, v_), "tune")
         return ref, got
 
