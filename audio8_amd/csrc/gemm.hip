@@ -267,7 +267,7 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
     constexpr int PPA = TA / 1024 / NW, PPB = TB / 1024 / NW;              // 1 KB LDS-DMA pieces per operand per stage per wave
     static_assert(PPA * NW * 1024 == TA && PPB * NW * 1024 == TB && PPA == PPB, "the waves share the DMA pieces evenly");
     constexpr int PPW = PPA;
-    static_assert(!A3 || (!AKS && !BKS && NST == 2), "the 3-deep A ring is built for NT with a 2-deep B ring");
+    static_assert(!A3 || NST == 2, "the 3-deep A ring goes with a 2-deep B ring");
     constexpr int RING = A3 ? 3 * TA + 2 * TB : NST * STAGE;
     constexpr int NP = (KB == 1 && NST == 2) ? 2 : 1;                      // small-LDS variant: epilogue in two passes
     constexpr int EPI = NW * 16 * MI * 64 * 4 / NP;                        // epilogue staging: a 64-column f32 slab per wave
@@ -428,16 +428,34 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
             const int k0 = kbeg + kb * BK;
 #pragma unroll
             for (int j = 0; j < PPA; ++j) {
-                const int k = k0 + a_k[j];
-                glds16((a_ok[j] && k + EPC <= kend) ? a_ptr[j] + (long long)k * SZ : zero, ta + (w + NW * j) * 1024);
+                const char* sa;
+                if constexpr (!AKS) {
+                    const int k = k0 + a_k[j];
+                    sa = (a_ok[j] && k + EPC <= kend) ? a_ptr[j] + (long long)k * SZ : zero;
+                } else {                                  // K-strided: the lane's running source pointer (see `issue` below)
+                    sa = (a_ok[j] && a_k[j] < kend) ? a_cur[j] : zero;
+                    a_k[j] += BK;
+                    a_cur[j] += a_step;
+                    if (g.A.rpb) { a_r[j] += BK; while (a_r[j] >= (int)g.A.rpb) { a_r[j] -= (int)g.A.rpb; a_cur[j] += a_wrap; } }
+                }
+                glds16(sa, ta + (w + NW * j) * 1024);
             }
         };
         auto issue_b = [&](int kb, char* tb) {
             const int k0 = kbeg + kb * BK;
 #pragma unroll
             for (int j = 0; j < PPB; ++j) {
-                const int k = k0 + b_k[j];
-                glds16((b_ok[j] && k + EPC <= kend) ? b_ptr[j] + (long long)k * SZ : zero, tb + (w + NW * j) * 1024);
+                const char* sb;
+                if constexpr (!BKS) {
+                    const int k = k0 + b_k[j];
+                    sb = (b_ok[j] && k + EPC <= kend) ? b_ptr[j] + (long long)k * SZ : zero;
+                } else {
+                    sb = (b_ok[j] && b_k[j] < kend) ? b_cur[j] : zero;
+                    b_k[j] += BK;
+                    b_cur[j] += b_step;
+                    if (g.B.rpb) { b_r[j] += BK; while (b_r[j] >= (int)g.B.rpb) { b_r[j] -= (int)g.B.rpb; b_cur[j] += b_wrap; } }
+                }
+                glds16(sb, tb + (w + NW * j) * 1024);
             }
         };
         char* const bbase = lds + 3 * TA;
@@ -452,19 +470,28 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
             __builtin_amdgcn_s_barrier();
             if (kb == 0) stamp(g, 2);
             const int sa2 = sa == 0 ? 2 : sa - 1;     // (sa + 2) % 3: the slot read in the previous iteration
-            issue_b(kb + 1, bbase + (sb ^ 1) * TB);   // (beyond kend: 16 zero bytes per lane -- keeps the counts uniform)
-            issue_a(kb + 2, lds + sa2 * TA);
+            if constexpr (!(AKS || BKS)) {
+                issue_b(kb + 1, bbase + (sb ^ 1) * TB);   // (beyond kend: 16 zero bytes per lane -- keeps the counts uniform)
+                issue_a(kb + 2, lds + sa2 * TA);
+            }
             const char* ta = lds + sa * TA;
             const char* tb = bbase + sb * TB;
             typename MM::Frag fa[ST::KSTEPS][MI], fb[ST::KSTEPS][NJ];
 #pragma unroll
             for (int ks = 0; ks < ST::KSTEPS; ++ks) {
 #pragma unroll
-                for (int i = 0; i < MI; ++i) fa[ks][i] = ST::kc_frag(ta, wm * (16 * MI) + 16 * i, ks, lane);
+                for (int i = 0; i < MI; ++i)
+                    fa[ks][i] = AKS ? ST::ks_frag(ta, wm * (16 * MI) + 16 * i, ks, lane) : ST::kc_frag(ta, wm * (16 * MI) + 16 * i, ks, lane);
 #pragma unroll
-                for (int i = 0; i < NJ; ++i) fb[ks][i] = ST::kc_frag(tb, wn * (16 * NJ) + 16 * i, ks, lane);
+                for (int i = 0; i < NJ; ++i)
+                    fb[ks][i] = BKS ? ST::ks_frag(tb, wn * (16 * NJ) + 16 * i, ks, lane) : ST::kc_frag(tb, wn * (16 * NJ) + 16 * i, ks, lane);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (AKS || BKS) {               // (transposed reads: the refill goes behind them, as in the symmetric loop)
+                issue_b(kb + 1, bbase + (sb ^ 1) * TB);
+                issue_a(kb + 2, lds + sa2 * TA);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int ks = 0; ks < ST::KSTEPS; ++ks)
 #pragma unroll
@@ -537,6 +564,13 @@ A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
 template <typename T>
 __global__ __launch_bounds__(512, 4) void gemm_a3_kernel(const GemmArgs g) {
     gemm_body<T, false, false, 2, 2, 4, true>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n * g.nsplit));
+}
+
+// the asymmetric ring for the weight-gradient layout (both operands K-strided; a8_set_tuning key 15 = 0 restores the symmetric ring):
+// bit-identical, the encoder layer's grouped weight gradients 123 -> 111 us
+template <typename T>
+__global__ __launch_bounds__(512, 4) void gemm_a3_tn_kernel(const GemmArgs g) {
+    gemm_body<T, true, true, 2, 2, 4, true>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n * g.nsplit));
 }
 
 // ---- pipelined 256 x 256 main loop for large NT problems with N % 256 == 0 and K % 64 == 0 (the conv layers: N = 512):
@@ -721,6 +755,15 @@ __global__ __launch_bounds__(128 * NWM, (NST * 2 * 8192 * KB <= 65536) ? NWM : N
     gemm_body<T, AKS, BKS, KB, NST, NWM>(g, bid - grp.start[i]);
 }
 
+template <typename T>
+__global__ __launch_bounds__(512, 4) void gemm_grouped_a3_tn_kernel(const GemmGroup grp) {
+    const int bid = xcd_remap(blockIdx.x, grp.start[grp.n]);
+    int i = 0;
+    while (i + 1 < grp.n && bid >= grp.start[i + 1]) ++i;
+    const GemmArgs g = grp.g[i];
+    gemm_body<T, true, true, 2, 2, 4, true>(g, bid - grp.start[i]);
+}
+
 // the grouped launch with the asymmetric ring of gemm_a3_kernel (bf16 NT; the conv data-gradient halves)
 template <typename T>
 __global__ __launch_bounds__(512, 4) void gemm_grouped_a3_kernel(const GemmGroup grp) {
@@ -839,6 +882,10 @@ extern "C" int a8_gemm(const a8_gemm_desc* d, void* stream) {
         hipLaunchKernelGGL(gemm_a3_kernel<bf16>, dim3((int)grid), dim3(512), 0, s, g);
         return a8_check_launch("a8_gemm");
     }
+    if (d->dtype == A8_BF16 && d->layout == A8_GEMM_TN && g_a8_tuning[15] > 0) {
+        hipLaunchKernelGGL(gemm_a3_tn_kernel<bf16>, dim3((int)grid), dim3(512), 0, s, g);
+        return a8_check_launch("a8_gemm");
+    }
     return d->dtype == A8_BF16 ? launch<bf16>(d, g, (int)grid, s) : launch<float>(d, g, (int)grid, s);
 }
 
@@ -864,6 +911,10 @@ extern "C" int a8_gemm_grouped(const a8_gemm_desc* descs, int n, void* stream) {
         for (int i = 0; i < n && a3; ++i) a3 = descs[i].M == 0 || descs[i].M >= g_a8_tuning[14];
         if (a3) {
             hipLaunchKernelGGL(gemm_grouped_a3_kernel<bf16>, dim3((int)total), dim3(512), 0, s, grp);
+            return a8_check_launch("a8_gemm_grouped");
+        }
+        if (descs[0].layout == A8_GEMM_TN && g_a8_tuning[15] > 0) {
+            hipLaunchKernelGGL(gemm_grouped_a3_tn_kernel<bf16>, dim3((int)total), dim3(512), 0, s, grp);
             return a8_check_launch("a8_gemm_grouped");
         }
         return launch_grouped<bf16>(descs[0].layout, grp, (int)total, s);

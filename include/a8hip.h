@@ -60,7 +60,8 @@ int a8_gemm_grouped(const a8_gemm_desc* descs, int n, void* stream);
  * pipelined bf16 NT GEMM (N % 256 == 0, K % 64 == 0, no bias; 0 = off); 6 positional-conv weight-gradient loop splits;
  * 9 = 1: conv layer 0 on the VALU in bf16 mode too; 14 asymmetric LDS ring for bf16 NT GEMMs (A requested two k-tiles ahead, B one):
  * 0 = off, otherwise the minimum M (default 1000: the conv layers and the encoder's products -- issued as half-batches on two streams,
- * most of their blocks sit alone on a CU, where the deeper A ring hides what a co-resident block otherwise would). */
+ * most of their blocks sit alone on a CU, where the deeper A ring hides what a co-resident block otherwise would); 15 the same ring for
+ * bf16 TN products (the weight gradients; default 1 = on). */
 int a8_set_tuning(int key, int value);
 
 /* ---- per-step weight preparation (the f32 -> compute-dtype casts the reference's autocast-free f32 path never needs;

@@ -168,6 +168,62 @@ def test_gemm_grouped_asymmetric_ring_matches_default():
         assert torch.equal(r, g_)
 
 
+def test_gemm_tn_asymmetric_ring_matches_symmetric():
+    """The asymmetric ring in the weight-gradient layout (a8_set_tuning key 15, default on; both operands K-strided, running source
+    pointers): bit-identical to the symmetric ring on integer operands -- plain, split-K with accumulation, ragged M / N / K tails, the
+    conv weight gradient's row remaps on both operands (stride-2 input rows, padded gradient rows) and the grouped launch."""
+    from audio8_amd import kernels as Kn, _lib as L
+    dev, bf = "cuda", torch.bfloat16
+
+    def both(fn):
+        try:
+            L.check(L.lib().a8_set_tuning(15, 0), "tune")
+            ref = fn()
+            L.check(L.lib().a8_set_tuning(15, 1), "tune")
+            got = fn()
+        finally:
+            L.check(L.lib().a8_set_tuning(15, 1), "tune")
+        return ref, got
+
+    for i, (n_out, n_in, m, sk) in enumerate(((768, 3072, 6248, 1), (3072, 768, 6248, 3), (200, 136, 1000, 1), (128, 128, 64, 1), (512, 1536, 4000, 7))):
+        dy, x = _mk((m, n_out), bf, 100 + i, integer=True).to(dev), _mk((m, n_in), bf, 120 + i, integer=True).to(dev)
+
+        def run():
+            C = torch.ones(n_out, n_in, device=dev)
+            Kn.gemm(L.TN, dy, x, n_out, n_in, m, out=C, accumulate=True, splitk=sk)
+            return C
+        ref, got = both(run)
+        assert torch.equal(ref, got), (n_out, n_in, m, sk)
+        np.testing.assert_array_equal(ref.cpu().numpy(), 1.0 + (dy.float().T @ x.float()).cpu().numpy())
+    # the conv layers' weight gradient: dW[co][k*cin] = sum over (utterance, frame) of dz[b, pad + t][co] * x[b, s*t + kk][cin]
+    Bn, Lin, cin, co, k, s_, pad = 3, 301, 64, 128, 3, 2, 1
+    Lout = (Lin - k) // s_ + 1
+    xin = _mk((Bn, Lin, cin), bf, 140, integer=True).to(dev)
+    dz = _mk((Bn, Lout + 2 * pad, co), bf, 141, integer=True).to(dev)
+
+    def run_conv():
+        dw = torch.zeros(co, k * cin, device=dev)
+        Kn.gemm(L.TN, dz, xin, co, k * cin, Bn * Lout, out=dw, splitk=3, ldb=s_ * cin, b_rpb=Lout, b_bs=Lin * cin, lda=co,
+                a_off=pad * co, a_rpb=Lout, a_bs=(Lout + 2 * pad) * co)
+        return dw
+    ref, got = both(run_conv)
+    assert torch.equal(ref, got)
+    cols = torch.stack([xin[:, kk:kk + s_ * (Lout - 1) + 1:s_, :] for kk in range(k)], 2).reshape(Bn * Lout, k * cin).float()
+    want = dz[:, pad:pad + Lout, :].reshape(Bn * Lout, co).float().T @ cols
+    np.testing.assert_array_equal(ref.cpu().numpy(), want.cpu().numpy())
+    # grouped (the encoder layer's four weight gradients)
+    M = 1000
+    shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768)]
+    ops_ = [(_mk((M, a), bf, 150 + j, integer=True).to(dev), _mk((M, b), bf, 160 + j, integer=True).to(dev)) for j, (a, b) in enumerate(shapes)]
+
+    def run_grouped():
+        tg = [torch.zeros(a, b, device=dev) for a, b in shapes]
+        Kn.gemm_grouped(L.TN, [(dy, x, a, b, M, dict(out=t, accumulate=True)) for (a, b), (dy, x), t in zip(shapes, ops_, tg)])
+        return tg
+    ref, got = both(run_grouped)
+    assert all(torch.equal(a, b) for a, b in zip(ref, got))
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_add_epilogue(dtype):
     from audio8_amd import kernels as Kn, _lib as L
