@@ -3,9 +3,12 @@
 #include "../../include/a8hip.h"
 
 // a8_set_tuning table (runtime.hip): [1] ln_bwd geometry NW*100 + rows per wave, [2..4] attention fwd / dK,dV / dQ launch geometry,
-// [5] min 256 x 256 tiles for the pipelined NT GEMM (0 = off), [6] posconv wgrad loop splits, [9] conv layer 0 on the VALU,
+// [5] min M for the stream NT GEMM of gemm_stream.hip (0 = off), [7] its forced tile height (0 = per launch), [6] posconv wgrad loop splits, [9] conv layer 0 on the VALU,
 // [14] min M for the asymmetric-ring NT GEMM; the rest spare
 extern int g_a8_tuning[32];
+
+// gemm_stream.hip: launches the problem on BM x 256 tiles if it qualifies (1), 0 = not taken, < 0 = -(error code)
+int a8i_gemm_stream_try(const a8_gemm_desc* d, void* stream);
 
 // forward entry points with a dropout-counter origin (used by composite.hip for calls on a slice of the batch)
 int a8i_layernorm_fwd(int dtype, const void* x, const void* res, const float* gamma, const float* beta, void* y, float* mean, float* rstd,

@@ -573,171 +573,6 @@ __global__ __launch_bounds__(512, 4) void gemm_a3_tn_kernel(const GemmArgs g) {
     gemm_body<T, true, true, 2, 2, 4, true>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n * g.nsplit));
 }
 
-// ---- pipelined 256 x 256 main loop for large NT problems with N % 256 == 0 and K % 64 == 0 (the conv layers: N = 512):
-// 8 waves of 128 x 64 (0.375 KB of fragment reads per MFMA instead of 0.75, half the staged bytes per FLOP), one block per CU.
-// Per k-tile t (LDS buffer b = t & 1), per wave, entering with the first A / B quarters of tile t in registers:
-//     read B1(t)                 | MFMA C00 += A0 B0
-//     read A1(t)                 | MFMA C01 += A0 B1
-//     wait: A1 in registers, this wave's DMA pieces of tile t+1 landed;   s_barrier
-//        -> nobody reads buffer b any more (all four operand quarters are in registers); tile t+1 is visible in buffer b^1
-//     DMA tile t+2 -> buffer b   | MFMA C11 += A1 B1
-//     read A0(t+1), B0(t+1) from b^1 (B0 into the registers B1 just vacated: the two B register sets swap roles every tile)
-//                                | MFMA C10 += A1 B0
-// so a tile's DMA has a whole k-tile to land, no wave waits on an LDS read it has just issued, and the k-tile boundary
-// has no barrier (validated standalone in tools/ubench/gemm_pipe.hip).  Rows beyond M are clamped to row M-1 on the way in
-// (their results are never stored).  Epilogue: NONE / GELU + zout / x gelu'(zin) / + zin, 16-bit outputs, 8-byte stores.
-template <typename T>
-__global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs g) {
-    static_assert(sizeof(T) == 2, "16-bit operands");
-    typedef Mma<T> MM;
-    constexpr int KROW = 128, TA = 256 * KROW, TB = 256 * KROW, STAGE = TA + TB, SZ = 2;
-    __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
-    const int t = threadIdx.x, lane = t & 63;
-    const int w = __builtin_amdgcn_readfirstlane(t >> 6), wr = w >> 2, wc = w & 3;
-    const int tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
-    constexpr int GROUP_M = 8;
-    const int tpg = GROUP_M * g.tiles_n, grp = tile / tpg, first_m = grp * GROUP_M;
-    const int gsz = min(GROUP_M, g.tiles_m - first_m), tin = tile - grp * tpg;
-    const int m0 = (first_m + tin % gsz) * 256, n0 = (tin / gsz) * 256;
-    const int nk = g.K / 64;
-
-    // LDS-DMA: 32 one-KB pieces (8 rows) per operand per stage, 4 per wave (rows 64 apart); XOR swizzle on the source address.
-    // A rows go through the row remap (conv windows, utterance boundaries): one 32-bit byte offset per piece and lane.
-    const int srow = 8 * w + (lane >> 3), sch = (lane & 7) ^ (srow & 7);
-    unsigned a_off[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = min(m0 + srow + 64 * j, g.M - 1);
-        a_off[j] = (unsigned)(outer_off(g.A, row) * SZ + sch * 16);
-    }
-    const unsigned b_off = (unsigned)((long long)(n0 + srow) * g.B.ld * SZ + sch * 16);
-    const unsigned bjstep = (unsigned)(64 * g.B.ld * SZ);
-    unsigned koff = 0;
-    auto issue = [&](int kt) {
-        char* ta = lds + (kt & 1) * STAGE;
-        char* tb = ta + TA;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            glds16(g.A.p + (a_off[j] + koff), ta + (w + 8 * j) * 1024);
-            glds16(g.B.p + (b_off + j * bjstep + koff), tb + (w + 8 * j) * 1024);
-        }
-        koff += KROW;
-    };
-    auto frag = [&](const char* tl, int rb, int ks) {          // 16 rows x 32 k: lane & 15 = row, lane >> 4 = 16-byte chunk of the k-step
-        const int row = rb + (lane & 15);
-        return *reinterpret_cast<const typename MM::Frag*>(tl + row * KROW + (((ks * 4 + (lane >> 4)) ^ (row & 7)) << 4));
-    };
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    typename MM::Frag a0[2][4], a1[2][4], b0[2][2], b1[2][2];
-    const int ra = wr * 128, cb = wc * 64;
-    auto rd_a = [&](typename MM::Frag (&f)[2][4], const char* ta, int half) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) f[ks][i] = frag(ta, ra + 64 * half + 16 * i, ks);
-    };
-    auto rd_b = [&](typename MM::Frag (&f)[2][2], const char* tb, int half) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) f[ks][i] = frag(tb, cb + 32 * half + 16 * i, ks);
-    };
-    // swapped operands: accumulator register r <-> 4 consecutive n, lane & 15 <-> m
-    auto mma = [&](const typename MM::Frag (&fa)[2][4], const typename MM::Frag (&fb)[2][2], int ah, int bh) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[4 * ah + i][2 * bh + j] = MM::mma(fb[ks][j], fa[ks][i], acc[4 * ah + i][2 * bh + j]);
-    };
-    auto step = [&](int kt, typename MM::Frag (&bx)[2][2], typename MM::Frag (&by)[2][2]) {
-        const char* ta = lds + (kt & 1) * STAGE;
-        const char* tb = ta + TA;
-        const char* na = lds + ((kt + 1) & 1) * STAGE;
-        const char* nb = na + TA;
-        rd_b(by, tb, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(a0, bx, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        rd_a(a1, ta, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(a0, by, 0, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nk) issue(kt + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(a1, by, 1, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < nk) {
-            rd_a(a0, na, 0);
-            rd_b(by, nb, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        mma(a1, bx, 1, 0);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    issue(0);
-    if (nk > 1) issue(1);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8) : "memory");       // k-tile 0 (the 8 older of this wave's 16 DMAs)
-    if (nk <= 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    rd_a(a0, lds, 0);
-    rd_b(b0, lds + TA, 0);
-    for (int kt = 0; kt < nk; kt += 2) {
-        step(kt, b0, b1);
-        if (kt + 1 < nk) step(kt + 1, b1, b0);
-    }
-
-    // ---- epilogue: register r of acc[i][j] is column 16 j + 4 (lane >> 4) + r of row 16 i + (lane & 15)
-    typedef T T4 __attribute__((ext_vector_type(4)));
-    auto zrow = [&](int m) -> long long { return remap_off(m, g.z_rpb, g.z_bs, g.ldz); };
-    const int li = lane & 15, c4 = 4 * (lane >> 4);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int m = m0 + ra + 16 * i + li;
-        if (m >= g.M) continue;
-        const long long crow = remap_off(m, g.c_rpb, g.c_bs, g.ldc);
-        const long long zr = (g.zout || g.zin) ? zrow(m) : 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + cb + 16 * j + c4;
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * g.alpha;
-            if (g.zout) {
-                T4 zv;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) zv[e] = from_f<T>(v[e]);
-                *reinterpret_cast<T4*>(reinterpret_cast<T*>(g.zout) + zr + n) = zv;
-            }
-            if (g.act == A8_ACT_GELU) {
-                gelu_n(v);
-            } else if (g.act == A8_ACT_MUL_GELU_GRAD) {
-                const T4 zz = *reinterpret_cast<const T4*>(reinterpret_cast<const T*>(g.zin) + zr + n);
-                float zf[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) zf[e] = to_f(zz[e]);
-                mul_gelu_grad_n(v, zf);
-            } else if (g.act == A8_ACT_ADD) {
-                const T4 zz = *reinterpret_cast<const T4*>(reinterpret_cast<const T*>(g.zin) + zr + n);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += to_f(zz[e]);
-            }
-            T4 ov;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) ov[e] = from_f<T>(v[e]);
-            *reinterpret_cast<T4*>(reinterpret_cast<T*>(g.C) + crow + n) = ov;
-        }
-    }
-}
-
 template <typename T, bool AKS, bool BKS, int KB, int NST, int NWM>
 __global__ __launch_bounds__(128 * NWM, (NST * 2 * 8192 * KB <= 65536) ? NWM : NWM / 2) void gemm_kernel(const GemmArgs g) {
     gemm_body<T, AKS, BKS, KB, NST, NWM>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n * g.nsplit));
@@ -853,30 +688,14 @@ static int build_args(const a8_gemm_desc* d, GemmArgs& g, long long* grid) {
     return A8_OK;
 }
 
-// the pipelined 256 x 256 kernel takes large bf16 NT problems with N % 256 == 0 and K % 64 == 0, 16-bit output, no bias / column sums
-// (a8_set_tuning key 5 = minimum number of 256 x 256 tiles; 0 = never)
-static bool p256_eligible(const a8_gemm_desc* d, const GemmArgs& g) {
-    if (!(d->dtype == A8_BF16 && d->layout == A8_GEMM_NT && g_a8_tuning[5] > 0 && d->N % 256 == 0 && d->K % 64 == 0 && d->K >= 64 &&
-          !d->out_f32 && !d->bias && !d->colsum && g.nsplit == 1 && !g.atomic && d->ldc % 4 == 0 && d->ldz % 4 == 0 && ((uintptr_t)d->C % 8) == 0))
-        return false;
-    // 32-bit byte offsets into A and B
-    const long long a_span = ((d->a_rpb ? (long long)((d->M - 1) / d->a_rpb) * d->a_bs + (long long)((d->M - 1) % d->a_rpb) * d->lda
-                                        : (long long)(d->M - 1) * d->lda) + d->K) * 2;
-    const long long b_span = ((long long)(d->N - 1) * d->ldb + d->K) * 2;
-    return (long long)cdiv(d->M, 256) * (d->N / 256) >= g_a8_tuning[5] && a_span < (1ll << 32) && b_span < (1ll << 32);
-}
-
 extern "C" int a8_gemm(const a8_gemm_desc* d, void* stream) {
     GemmArgs g;
     long long grid = 0;
     if (int e = build_args(d, g, &grid)) return e;
     if (d->M == 0) return A8_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (p256_eligible(d, g)) {
-        g.tiles_m = cdiv(d->M, 256); g.tiles_n = d->N / 256;
-        hipLaunchKernelGGL(gemm_p256_kernel<bf16>, dim3(g.tiles_m * g.tiles_n), dim3(512), 0, s, g);
-        return a8_check_launch("a8_gemm");
-    }
+    // many rows, N % 256 == 0: BM x 256 tiles on persistent blocks (gemm_stream.hip; a8_set_tuning key 5 = minimum M, 0 = never)
+    if (const int r = a8i_gemm_stream_try(d, stream)) return r > 0 ? A8_OK : -r;
     // Asymmetric ring (a8_set_tuning key 14: 0 = never, otherwise the minimum M; 1 = every bf16 NT problem)
     if (d->dtype == A8_BF16 && d->layout == A8_GEMM_NT && g_a8_tuning[14] > 0 && d->M >= g_a8_tuning[14]) {
         hipLaunchKernelGGL(gemm_a3_kernel<bf16>, dim3((int)grid), dim3(512), 0, s, g);

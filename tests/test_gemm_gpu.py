@@ -235,15 +235,17 @@ def test_gemm_add_epilogue(dtype):
     np.testing.assert_allclose(out.double().cpu().numpy(), ref.numpy(), rtol=tol, atol=tol)
 
 
-@pytest.mark.parametrize("key", [5, 14])
-def test_gemm_pipelined_256_kernel_matches_default(key):
-    """The two alternative NT kernels that ship -- pipelined 256 x 256 (a8_set_tuning key 5; N % 256 == 0, K % 64 == 0; no bias / column
-    sums) and the asymmetric ring (key 14 = 1: A three k-tiles deep) -- walk K in the same order as the default kernel: outputs must be
-    bit-identical across M tails, single and odd k-tile counts, the conv row remaps on A, C and z, and each epilogue; ineligible
-    problems must fall through.  (The round-2 experiments that did not ship live in tools/ubench/gemm_variants.hip.)"""
+@pytest.mark.parametrize("key,height", [(5, 0), (5, 160), (5, 192), (5, 224), (5, 256), (14, 0)])
+def test_gemm_alternative_nt_kernels_match_default(key, height):
+    """The two alternative NT kernels that ship -- the stream kernel of csrc/gemm_stream.hip (a8_set_tuning key 5 = minimum M; N % 256 == 0,
+    K % 128 == 0, K >= 256, plain / bias / GELU + pre-activation copy epilogues; BM x 256 tiles on persistent blocks, key 7 forces the tile
+    height) and the asymmetric ring (key 14 = 1: A three k-tiles deep) -- walk K in the same order as the default kernel: outputs must be
+    bit-identical across M tails, both A-ring depths of the stream kernel (K % 384 == 0 or not), several tiles per persistent block, the
+    conv row remaps on A, C and z (batch items that are no multiple of the tile height: their last tile is shifted up), and each
+    epilogue; ineligible problems must fall through.  (The round-2 experiments that did not ship live in tools/ubench/gemm_variants.hip.)"""
     from audio8_amd import kernels as Kn, _lib as L
     dev, bf = "cuda", torch.bfloat16
-    saved = {5: 0, 14: 0}
+    saved = {5: 0, 14: 0, 7: 0}
 
     def both(fn):
         try:
@@ -251,9 +253,10 @@ def test_gemm_pipelined_256_kernel_matches_default(key):
                 L.check(L.lib().a8_set_tuning(k_, v_), "tune")          # the reference: every alternative kernel off
             ref = fn()
             L.check(L.lib().a8_set_tuning(key, 1), "tune")
+            L.check(L.lib().a8_set_tuning(7, height), "tune")
             got = fn()
         finally:
-            for k_, v_ in {**saved, 14: 1000}.items():                 # back to the library defaults
+            for k_, v_ in {**saved, 14: 1000, 5: 20000}.items():       # back to the library defaults
                 L.check(L.lib().a8_set_tuning(k_, v_), "tune")
         return ref, got
 
@@ -263,6 +266,7 @@ def test_gemm_pipelined_256_kernel_matches_default(key):
 
     for (M, N, K) in [(781, 768, 512), (256, 256, 64), (300, 512, 2048), (6248, 768, 768), (1000, 256, 192), (33, 512, 320),
                       (40000, 512, 1536), (129, 1024, 96), (4133, 512, 1024),      # several tiles per persistent block, 2 column tiles
+                      (70000, 256, 256), (257, 256, 384), (160, 512, 768),         # 4 k-tiles, more tiles than blocks; one row over a tile; one tile
                       (1000, 264, 72), (300, 136, 2056)]:                  # the last two are not eligible
         A, B = _mk((M, K), bf, 1).to(dev), _mk((N, K), bf, 2).to(dev)
         same(*both(lambda: (Kn.gemm(L.NT, A, B, M, N, K),)), ("plain", M, N, K))
@@ -277,7 +281,12 @@ def test_gemm_pipelined_256_kernel_matches_default(key):
     same(*both(lambda: (Kn.gemm(L.NT, A, B, M, N, K, act=L.ACT_MUL_GELU_GRAD, zin=z),)), "x gelu'(z)")
     same(*both(lambda: (Kn.gemm(L.NT, A, B, M, N, K, act=L.ACT_ADD, zin=z),)), "add")
     bias = torch.randn(N, device=dev)
-    same(*both(lambda: (Kn.gemm(L.NT, A, B, M, N, K, bias=bias),)), "bias (falls through)")
+    same(*both(lambda: (Kn.gemm(L.NT, A, B, M, N, K, bias=bias),)), "bias")
+
+    def bias_gelu_zout():
+        zo = torch.empty(M, N, device=dev, dtype=bf)
+        return Kn.gemm(L.NT, A, B, M, N, K, bias=bias, act=L.ACT_GELU, zout=zo), zo
+    same(*both(bias_gelu_zout), "bias + gelu + zout")
     same(*both(lambda: (Kn.gemm(L.NT, A, B, M, N, K, out_dtype=torch.float32),)), "f32 out (falls through)")
 
     def with_colsum():
