@@ -9,6 +9,7 @@ extern int g_a8_tuning[32];
 
 // gemm_stream.hip: launches the problem on BM x 256 tiles if it qualifies (1), 0 = not taken, < 0 = -(error code)
 int a8i_gemm_stream_try(const a8_gemm_desc* d, void* stream);
+bool a8i_gemm_stream_eligible(const a8_gemm_desc* d);
 
 // forward entry points with a dropout-counter origin (used by composite.hip for calls on a slice of the batch)
 int a8i_layernorm_fwd(int dtype, const void* x, const void* res, const float* gamma, const float* beta, void* y, float* mean, float* rstd,

@@ -724,6 +724,21 @@ extern "C" int a8_gemm_grouped(const a8_gemm_desc* descs, int n, void* stream) {
         grp.start[++grp.n] = (int)total;
     }
     if (grp.n == 0) return A8_OK;
+    // every problem fit for the stream kernel (the conv data gradients' even / odd halves: each fills the chip for several rounds
+    // by itself): one persistent launch each instead of the shared grid
+    if (descs[0].dtype == A8_BF16 && descs[0].layout == A8_GEMM_NT && a8i_gemm_stream_eligible(&descs[0])) {
+        bool all = true;
+        for (int i = 1; i < n && all; ++i) all = descs[i].M == 0 || a8i_gemm_stream_eligible(&descs[i]);
+        if (all) {
+            for (int i = 0; i < n; ++i) {
+                if (descs[i].M == 0) continue;
+                const int r = a8i_gemm_stream_try(&descs[i], stream);
+                if (r < 0) return -r;
+                A8_REQUIRE(r == 1, "a8_gemm_grouped: stream kernel refused an eligible problem");
+            }
+            return A8_OK;
+        }
+    }
     hipStream_t s = (hipStream_t)stream;
     if (descs[0].dtype == A8_BF16) {
         bool a3 = descs[0].layout == A8_GEMM_NT && g_a8_tuning[14] > 0;

@@ -31,12 +31,12 @@ constexpr int BN = 256, BK = 64, KROW = 128;
 constexpr int TA = 256 * KROW, TB = BN * KROW;                  // 32 KB per ring slot
 
 struct StreamArgs {
-    const char* A; const char* B; char* C; char* Z; const float* bias;
+    const char* A; const char* B; char* C; char* Z; const char* Zin; const float* bias;
     int lda, a_bs;                 // elements: row stride of A, distance between batch items
     int ldb;
     int ldc, c_bs, ldz, z_bs;
     int K, rpb, tpb, tiles_m, tiles_n;      // rows per batch item, tiles per batch item
-    int act;                       // A8_ACT_NONE / A8_ACT_GELU
+    int act;                       // A8_ACT_NONE / A8_ACT_GELU (Z = pre-activation copy out) / A8_ACT_MUL_GELU_GRAD, A8_ACT_ADD (Zin; rows as Z's)
 };
 
 struct TileAt { unsigned a, b; int bi, r0, n0; };       // byte offsets of the tile's first A row / B row; batch item, first row in it, first column
@@ -53,7 +53,9 @@ A8_DEV unsigned pack2(float a, float b) {
 
 // MI = 16-row fragments per wave (5..8): tile height BM = 32 MI, wave row wr owns rows [16 MI wr, 16 MI (wr + 1)), wave column wc
 // 64 of the 256 columns.  NA = slots of the A ring (3: K % 384 == 0; 2: K % 128 == 0).
-template <int MI, int NA>
+// ZIN: the epilogues with a second input (x gelu'(zin), + zin) are their own instantiations: their zin registers and code stay out of
+// the forward kernels' allocation.
+template <int MI, int NA, bool ZIN>
 __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const StreamArgs g) {
     static_assert(NA == 2 || NA == 3, "A ring depth");
     constexpr int BM = 32 * MI, WR = 16 * MI;
@@ -242,7 +244,15 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const StreamArgs g)
         const int li = lane & 15, gq = lane >> 4;
         bf16* const crow0 = reinterpret_cast<bf16*>(g.C) + ((long long)done.bi * g.c_bs + (long long)done.r0 * g.ldc);
         bf16* const zrow0 = reinterpret_cast<bf16*>(g.Z) + ((long long)done.bi * g.z_bs + (long long)done.r0 * g.ldz);
-        const bool gelu = g.act == A8_ACT_GELU, zout = g.Z != nullptr;
+        const bool gelu = !ZIN && g.act == A8_ACT_GELU, zout = !ZIN && g.Z != nullptr;
+        const bool zmul = ZIN && g.act == A8_ACT_MUL_GELU_GRAD;
+        // lanes of 16-lane row gq: even gq keeps fragment 2jj (its own 4 columns + the next row's), odd gq fragment 2jj+1
+        const int col0 = done.n0 + cb + 16 * (gq & 1) + 8 * (gq >> 1);
+        // epilogues with a second input (x gelu'(zin): conv data gradients; + zin): the lane's 16 bytes of every row fragment of a
+        // column pair are requested ahead of that pair's arithmetic, in the layout of the stores; the same two swaps that build a
+        // store turn a load back into the accumulator layout (the swap is an involution)
+        u32x4 zv[ZIN ? MI : 1];
+        const bf16* const zin0 = ZIN ? reinterpret_cast<const bf16*>(g.Zin) + ((long long)done.bi * g.z_bs + (long long)done.r0 * g.ldz) : nullptr;
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             float bz[2][4];
@@ -253,18 +263,35 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const StreamArgs g)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) bz[q][e] = bv[e];
             }
-            // lanes of 16-lane row gq: even gq keeps fragment 2jj (its own 4 columns + the next row's), odd gq fragment 2jj+1
-            const int col = done.n0 + cb + 32 * jj + 16 * (gq & 1) + 8 * (gq >> 1);
+            const int col = col0 + 32 * jj;
+            if constexpr (ZIN) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    zv[i] = *reinterpret_cast<const u32x4*>(zin0 + ((unsigned)(ra + 16 * i + li) * (unsigned)g.ldz + (unsigned)col));
+            }
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 const int rr = ra + 16 * i + li;
                 unsigned zl[2], zh[2], yl[2], yh[2];
+                if constexpr (ZIN) {
+                    auto t0 = __builtin_amdgcn_permlane16_swap(zv[i][0], zv[i][2], false, false);
+                    auto t1 = __builtin_amdgcn_permlane16_swap(zv[i][1], zv[i][3], false, false);
+                    zl[0] = t0[0]; zl[1] = t0[1]; zh[0] = t1[0]; zh[1] = t1[1];
+                }
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     float x[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) x[e] = acc[i][2 * jj + q][e] + bz[q][e];
-                    if (zout) { zl[q] = pack2(x[0], x[1]); zh[q] = pack2(x[2], x[3]); }
+                    if constexpr (ZIN) {
+                        const float zf[4] = {__uint_as_float(zl[q] << 16), __uint_as_float(zl[q] & 0xFFFF0000u),
+                                             __uint_as_float(zh[q] << 16), __uint_as_float(zh[q] & 0xFFFF0000u)};
+                        if (zmul) mul_gelu_grad_n(x, zf);
+                        else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) x[e] += zf[e];
+                        }
+                    } else if (zout) { zl[q] = pack2(x[0], x[1]); zh[q] = pack2(x[2], x[3]); }
                     if (gelu) gelu_n(x);
                     yl[q] = pack2(x[0], x[1]); yh[q] = pack2(x[2], x[3]);
                 }
@@ -302,47 +329,67 @@ int pick_bm(int batches, int rpb, int tiles_n, int cus) {
 
 }  // namespace
 
-// Takes the problem if it fits the stream kernel (returns 1 and launches, 0 = not taken, < 0 = launch error code negated).
-// a8_set_tuning key 5 = minimum M (0 = never); key 7 = forced tile height (0 = chosen per launch).
-int a8i_gemm_stream_try(const a8_gemm_desc* d, void* stream) {
+// Fills the kernel arguments if the problem fits the stream kernel.  a8_set_tuning key 5 = minimum M (0 = never); key 7 = forced
+// tile height (0 = chosen per launch).
+static bool stream_plan(const a8_gemm_desc* d, StreamArgs& g, int& bm, int& grid, bool& deep) {
     const int min_m = g_a8_tuning[5];
-    if (min_m <= 0 || d->dtype != A8_BF16 || d->layout != A8_GEMM_NT || d->M < min_m) return 0;
-    if (d->N % 256 || d->K % 128 || d->K < 256 || d->out_f32 || d->accumulate || d->splitk > 1 || d->colsum || d->bias_rows || d->alpha != 1.0f) return 0;
-    if (!(d->act == A8_ACT_NONE || d->act == A8_ACT_GELU) || d->zin || d->b_rpb) return 0;
+    if (min_m <= 0 || d->dtype != A8_BF16 || d->layout != A8_GEMM_NT || d->M < min_m) return false;
+    if (d->N % 256 || d->K % 128 || d->K < 256 || d->out_f32 || d->accumulate || d->splitk > 1 || d->colsum || d->bias_rows || d->alpha != 1.0f) return false;
+    const bool zin = d->act == A8_ACT_MUL_GELU_GRAD || d->act == A8_ACT_ADD;
+    if (!(d->act == A8_ACT_NONE || d->act == A8_ACT_GELU || zin) || (zin && (!d->zin || d->zout)) || (!zin && d->zin) || d->b_rpb) return false;
     const int rpb = d->a_rpb ? (int)d->a_rpb : d->M;
-    if (d->M % rpb) return 0;
+    if (d->M % rpb) return false;
     const int batches = d->M / rpb;
-    if ((d->c_rpb && d->c_rpb != rpb) || (d->zout && d->z_rpb && d->z_rpb != rpb)) return 0;
-    if (d->ldc % 8 || (d->zout && d->ldz % 8) || ((uintptr_t)d->C % 16) || (d->zout && ((uintptr_t)d->zout % 16)) || (d->bias && ((uintptr_t)d->bias % 16))) return 0;
+    const bool hasz = d->zout || zin;
+    if ((d->c_rpb && d->c_rpb != rpb) || (hasz && d->z_rpb && d->z_rpb != rpb)) return false;
+    if (d->ldc % 8 || (hasz && d->ldz % 8) || ((uintptr_t)d->C % 16) || (d->zout && ((uintptr_t)d->zout % 16)) || (zin && ((uintptr_t)d->zin % 16)) ||
+        (d->bias && ((uintptr_t)d->bias % 16)))
+        return false;
     const long long a_bs = d->a_rpb ? d->a_bs : (long long)rpb * d->lda;
     const long long c_bs = d->c_rpb ? d->c_bs : (long long)rpb * d->ldc;
-    const long long z_bs = d->zout ? (d->z_rpb ? d->z_bs : (long long)rpb * d->ldz) : 0;
+    const long long z_bs = hasz ? (d->z_rpb ? d->z_bs : (long long)rpb * d->ldz) : 0;
     // 32-bit byte offsets into A and B, 31-bit element offsets into C / Z
     const long long a_span = ((long long)(batches - 1) * a_bs + (long long)(rpb - 1) * d->lda + d->K) * 2;
     const long long b_span = ((long long)(d->N - 1) * d->ldb + d->K) * 2;
     const long long c_span = (long long)(batches - 1) * c_bs + (long long)(rpb - 1) * d->ldc + d->N;
-    const long long z_span = d->zout ? (long long)(batches - 1) * z_bs + (long long)(rpb - 1) * d->ldz + d->N : 0;
-    if (a_span >= (1ll << 32) || b_span >= (1ll << 32) || c_span >= (1ll << 31) || z_span >= (1ll << 31) || a_bs >= (1ll << 31)) return 0;
+    const long long z_span = hasz ? (long long)(batches - 1) * z_bs + (long long)(rpb - 1) * d->ldz + d->N : 0;
+    if (a_span >= (1ll << 32) || b_span >= (1ll << 32) || c_span >= (1ll << 31) || z_span >= (1ll << 31) || a_bs >= (1ll << 31)) return false;
     static int cus = 0;
     if (!cus) {
         int dev = 0; hipDeviceProp_t p;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return false;
         cus = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
     }
-    int bm = g_a8_tuning[7];
+    bm = g_a8_tuning[7];
     if (!(bm == 160 || bm == 192 || bm == 224 || bm == 256) || rpb < bm) bm = pick_bm(batches, rpb, d->N / 256, cus);
-    if (!bm) return 0;
-    StreamArgs g;
-    g.A = (const char*)d->A; g.B = (const char*)d->B; g.C = (char*)d->C; g.Z = (char*)d->zout; g.bias = d->bias;
+    if (!bm) return false;
+    g.A = (const char*)d->A; g.B = (const char*)d->B; g.C = (char*)d->C; g.Z = (char*)d->zout; g.Zin = (const char*)d->zin; g.bias = d->bias;
     g.lda = (int)d->lda; g.a_bs = (int)a_bs; g.ldb = (int)d->ldb;
     g.ldc = (int)d->ldc; g.c_bs = (int)c_bs; g.ldz = (int)d->ldz; g.z_bs = (int)z_bs;
     g.K = d->K; g.rpb = rpb; g.tpb = cdiv(rpb, bm); g.tiles_m = batches * g.tpb; g.tiles_n = d->N / 256;
     g.act = d->act;
-    const int total = g.tiles_m * g.tiles_n, grid = total < cus ? total : cus;
-    const bool deep = (d->K / 64) % 6 == 0;
+    const int total = g.tiles_m * g.tiles_n;
+    grid = total < cus ? total : cus;
+    deep = (d->K / 64) % 6 == 0;
+    return true;
+}
+
+bool a8i_gemm_stream_eligible(const a8_gemm_desc* d) {
+    StreamArgs g; int bm, grid; bool deep;
+    return stream_plan(d, g, bm, grid, deep);
+}
+
+// Takes the problem if it fits the stream kernel (returns 1 and launches, 0 = not taken, < 0 = launch error code negated).
+int a8i_gemm_stream_try(const a8_gemm_desc* d, void* stream) {
+    StreamArgs g; int bm, grid; bool deep;
+    if (!stream_plan(d, g, bm, grid, deep)) return 0;
     hipStream_t s = (hipStream_t)stream;
-#define A8_STREAM_LAUNCH(MI_) do { if (deep) hipLaunchKernelGGL((gemm_stream_kernel<MI_, 3>), dim3(grid), dim3(512), 0, s, g); \
-                                   else hipLaunchKernelGGL((gemm_stream_kernel<MI_, 2>), dim3(grid), dim3(512), 0, s, g); } while (0)
+    const bool zin = g.Zin != nullptr;
+#define A8_STREAM_LAUNCH(MI_) do { \
+        if (deep && !zin) hipLaunchKernelGGL((gemm_stream_kernel<MI_, 3, false>), dim3(grid), dim3(512), 0, s, g); \
+        else if (!zin) hipLaunchKernelGGL((gemm_stream_kernel<MI_, 2, false>), dim3(grid), dim3(512), 0, s, g); \
+        else if (deep) hipLaunchKernelGGL((gemm_stream_kernel<MI_, 3, true>), dim3(grid), dim3(512), 0, s, g); \
+        else hipLaunchKernelGGL((gemm_stream_kernel<MI_, 2, true>), dim3(grid), dim3(512), 0, s, g); } while (0)
     switch (bm) {
         case 160: A8_STREAM_LAUNCH(5); break;
         case 192: A8_STREAM_LAUNCH(6); break;

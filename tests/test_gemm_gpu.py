@@ -320,5 +320,20 @@ def test_gemm_alternative_nt_kernels_match_default(key, height):
                 zin=zprev, ldz=2 * cin, z_rpb=Lout + 1, z_bs=(2 * Lout + 1) * cin)
         return (dx,)
     same(*both(conv_dgrad_even), "conv dgrad remap")
+    # both halves of the data gradient in one grouped call (odd positions: K = co, output / z rows offset by one frame)
+    b_odd = _mk((cin, co), bf, 11).to(dev)
+
+    def conv_dgrad_grouped():
+        dx = torch.zeros(Bn * prow, cin, device=dev, dtype=bf)
+        zk = dict(zin=zprev, ldz=2 * cin, z_bs=(2 * Lout + 1) * cin)
+        even = (dz, b_even, Bn * (Lout + 1), cin, 2 * co,
+                dict(out=dx, lda=co, a_rpb=Lout + 1, a_bs=dzrows * co, ldc=2 * cin, c_off=npad * cin, c_rpb=Lout + 1, c_bs=prow * cin,
+                     act=L.ACT_MUL_GELU_GRAD, **dict(zk, z_rpb=Lout + 1)))
+        odd = (dz, b_odd, Bn * Lout, cin, co,
+               dict(out=dx, lda=co, a_off=co, a_rpb=Lout, a_bs=dzrows * co, ldc=2 * cin, c_off=(npad + 1) * cin, c_rpb=Lout, c_bs=prow * cin,
+                    act=L.ACT_MUL_GELU_GRAD, **dict(zk, z_rpb=Lout, z_off=cin)))
+        Kn.gemm_grouped(L.NT, [even, odd])
+        return (dx,)
+    same(*both(conv_dgrad_grouped), "conv dgrad, grouped even + odd")
 
 
