@@ -345,7 +345,7 @@ def main():
                            "frac_hbm_bwd": frac(comp["conv0_out_elems"] * esz, c0_b, PEAK_HBM_TBS * 1e12)},
                 "note": "7-layer strided conv stack; bytes = SURVEY 8d minimum (input + each layer output written once and read once + weights), "
                         "backward counted as 2 x forward; layers 1-6 are MFMA-bound GEMMs (frac_mfma), only layer 0 is HBM-bound (layer0)"}
-        roofline = {"bound": "mfma", "kernel": "gemm_kernel<%s> (a8_gemm: all Linear/conv-as-GEMM fwd, dgrad, wgrad)" % args.dtype,
+        roofline = {"bound": "mfma", "kernel": "a8_gemm kernel family <%s> (128 x 128-tile gemm_a3 / grouped / TN kernels + the BM x 256-tile gemm_stream kernel: all Linear/conv-as-GEMM fwd, dgrad, wgrad)" % args.dtype,
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                     "achieved_serial": round(ser_fl / (ser_ms * 1e-3) / 1e12, 2), "frac_serial": round(ser_fl / (ser_ms * 1e-3) / 1e12 / peak, 4),
                     "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": traffic_src,

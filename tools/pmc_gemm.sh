@@ -16,7 +16,7 @@ for f in glob.glob("gpurun_out/pmc_gemm/p*/**/*counter_collection.csv", recursiv
         k = r["Kernel_Name"]
         if "gemm_" not in k or "<float" in k or "IfL" in k:
             continue
-        name = "gemm_grouped(TN,bf16)" if "grouped" in k else ("gemm(TN,bf16)" if ("Lb1ELb1" in k or "true, true" in k or "E, true" in k) else "gemm(NT,bf16)")
+        name = "gemm_stream(NT,bf16,BMx256)" if "gemm_stream" in k else "gemm_grouped(TN,bf16)" if "grouped" in k else ("gemm(TN,bf16)" if ("Lb1ELb1" in k or "true, true" in k or "E, true" in k) else "gemm(NT,bf16)")
         agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 print("SQ counters of the GEMM kernels during `bench.py --steps 2 --warmup 1` (rocprofv3 --pmc, 4 separate passes); averages per launch")
 for k, d in agg.items():
