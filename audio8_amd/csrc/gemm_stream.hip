@@ -264,10 +264,12 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const StreamArgs g)
                 for (int e = 0; e < 4; ++e) bz[q][e] = bv[e];
             }
             const int col = col0 + 32 * jj;
-            if constexpr (ZIN) {
+            if constexpr (ZIN) {                         // the first column pair's zin; the second pair's is requested row fragment by row
+                if (jj == 0) {                           // fragment as the first pair's registers free up (below): its latency is hidden
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
-                    zv[i] = *reinterpret_cast<const u32x4*>(zin0 + ((unsigned)(ra + 16 * i + li) * (unsigned)g.ldz + (unsigned)col));
+                    for (int i = 0; i < MI; ++i)
+                        zv[i] = *reinterpret_cast<const u32x4*>(zin0 + ((unsigned)(ra + 16 * i + li) * (unsigned)g.ldz + (unsigned)col));
+                }
             }
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
@@ -277,6 +279,7 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const StreamArgs g)
                     auto t0 = __builtin_amdgcn_permlane16_swap(zv[i][0], zv[i][2], false, false);
                     auto t1 = __builtin_amdgcn_permlane16_swap(zv[i][1], zv[i][3], false, false);
                     zl[0] = t0[0]; zl[1] = t0[1]; zh[0] = t1[0]; zh[1] = t1[1];
+                    if (jj == 0) zv[i] = *reinterpret_cast<const u32x4*>(zin0 + ((unsigned)(ra + 16 * i + li) * (unsigned)g.ldz + (unsigned)(col + 32)));
                 }
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
