@@ -3,7 +3,7 @@
 #include "../../include/a8hip.h"
 
 // a8_set_tuning table (runtime.hip): [1] ln_bwd geometry NW*100 + rows per wave, [2..4] attention fwd / dK,dV / dQ launch geometry,
-// [5] min M for the stream NT GEMM of gemm_stream.hip (0 = off), [7] its forced tile height (0 = per launch), [6] posconv wgrad loop splits, [9] conv layer 0 on the VALU,
+// [5] min M for the stream NT GEMM of gemm_stream.hip (0 = off), [7] its forced tile height (0 = per launch), [8] its grid oversubscription, [6] posconv wgrad loop splits, [9] conv layer 0 on the VALU,
 // [14] min M for the asymmetric-ring NT GEMM; the rest spare
 extern int g_a8_tuning[32];
 

@@ -372,7 +372,11 @@ static bool stream_plan(const a8_gemm_desc* d, StreamArgs& g, int& bm, int& grid
     g.K = d->K; g.rpb = rpb; g.tpb = cdiv(rpb, bm); g.tiles_m = batches * g.tpb; g.tiles_n = d->N / 256;
     g.act = d->act;
     const int total = g.tiles_m * g.tiles_n;
-    grid = total < cus ? total : cus;
+    // blocks per CU's worth of grid (a8_set_tuning key 8; default 1: every block resident from the start, one static share each).
+    // > 1: shorter static shares, the surplus blocks are dispatched as CUs free up -- the hardware balances the load when another
+    // kernel (RCCL, the side stream's weight gradients) holds some CUs at launch, for one more ring prologue per block.
+    const int over = g_a8_tuning[8] > 1 ? g_a8_tuning[8] : 1;
+    grid = total < cus * over ? total : cus * over;
     deep = (d->K / 64) % 6 == 0;
     return true;
 }

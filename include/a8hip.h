@@ -58,7 +58,9 @@ int a8_gemm_grouped(const a8_gemm_desc* descs, int n, void* stream);
 /* developer tuning knobs, never needed for correctness (defaults are the measured best): key 1 LayerNorm-backward geometry
  * (waves*100 + rows per wave); 2..4 attention fwd / dK,dV / dQ launch geometry; 5 minimum M for the
  * stream bf16 NT GEMM (N % 256 == 0, K % 128 == 0: BM x 256 tiles on persistent blocks, the conv layers' forward; default 20000, 0 = off),
- * 7 its forced tile height (160 / 192 / 224 / 256; 0 = chosen per launch); 6 positional-conv weight-gradient loop splits;
+ * 7 its forced tile height (160 / 192 / 224 / 256; 0 = chosen per launch), 8 its grid in CUs' worths of persistent blocks (default 1: all
+ * resident from the start; 2..4: shorter static shares, surplus blocks dispatched as CUs free up -- +0.09 ms alone on the GPU, for runs where
+ * another kernel holds CUs at launch); 6 positional-conv weight-gradient loop splits;
  * 9 = 1: conv layer 0 on the VALU in bf16 mode too; 14 asymmetric LDS ring for bf16 NT GEMMs (A requested two k-tiles ahead, B one):
  * 0 = off, otherwise the minimum M (default 1000: the conv layers and the encoder's products -- issued as half-batches on two streams,
  * most of their blocks sit alone on a CU, where the deeper A ring hides what a co-resident block otherwise would); 15 the same ring for
