@@ -34,6 +34,8 @@ ARGTYPES = {
     "a8_col2im_gelu_grad": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "a8_layernorm_fwd": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_void_p],
     "a8_layernorm_bwd": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_uint32, C.c_uint32, C.c_void_p],
+    "a8_layernorm_bwd_partial_rows": [C.c_int],
+    "a8_colsum_partials_reduce": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "a8_cast": [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
     "a8_ctc_greedy_decode": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_void_p],
     "a8_dropout": [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_uint32, C.c_uint32, C.c_void_p],
@@ -99,7 +101,7 @@ class EncoderLayerBwdDesc(C.Structure):
                [(n, C.c_uint32) for n in ("seed_attn", "seed1", "seed2")] + [("b0", C.c_int)] + \
                [(n, C.c_void_p) for n in ("dx2", "x", "qkv", "o", "ao", "x1", "z1", "f", "keymask", "lse", "mean2", "rstd2", "mean1", "rstd1", "g1", "g2",
                                           "w2_t", "w1_t", "wo_t", "dg1", "dbe1", "dg2", "dbe2", "db2", "db1", "dbo",
-                                          "df", "dx1_res", "dz1", "dx1_ffn", "dao", "dx_res", "dout_o", "dqkv", "delta")]
+                                          "df", "dx1_res", "dz1", "dx1_ffn", "dao", "dx_res", "dout_o", "dqkv", "delta", "ln1_partials", "ln2_partials")]
 
 
 class WPrepDesc(C.Structure):
@@ -163,7 +165,7 @@ def require_cuda(*ts):
 EXPORTS = [
     "a8_version", "a8_last_error", "a8_gemm", "a8_gemm_grouped", "a8_set_tuning", "a8_encoder_layer_fwd", "a8_encoder_layer_bwd", "a8_prepare_weights", "a8_prepare_weights_device",
     "a8_conv0_gn_gelu_fwd", "a8_conv0_gn_gelu_bwd", "a8_col2im_gelu_grad",
-    "a8_layernorm_fwd", "a8_layernorm_bwd",
+    "a8_layernorm_fwd", "a8_layernorm_bwd", "a8_layernorm_bwd_partial_rows", "a8_colsum_partials_reduce",
     "a8_cast", "a8_dropout", "a8_mask_fill_rows", "a8_mask_fill_rows_bwd", "a8_mask_zero_cols", "a8_zero_rows",
     "a8_gather_rows", "a8_scatter_add_rows", "a8_add",
     "a8_posconv_fwd", "a8_posconv_wgrad", "a8_weightnorm_pack", "a8_weightnorm_bwd", "a8_gelu_bwd_bias",

@@ -4,7 +4,7 @@
 
 // a8_set_tuning table (runtime.hip): [1] ln_bwd geometry NW*100 + rows per wave, [2..4] attention fwd / dK,dV / dQ launch geometry,
 // [5] min M for the stream NT GEMM of gemm_stream.hip (0 = off), [7] its forced tile height (0 = per launch), [8] its grid oversubscription, [6] posconv wgrad loop splits, [9] conv layer 0 on the VALU,
-// [14] min M for the asymmetric-ring NT GEMM; the rest spare
+// [14] min M for the asymmetric-ring NT GEMM, [17] ln_bwd geometry of the partial-row form; the rest spare
 extern int g_a8_tuning[32];
 
 // gemm_stream.hip: launches the problem on BM x 256 tiles if it qualifies (1), 0 = not taken, < 0 = -(error code)
@@ -18,7 +18,8 @@ int a8i_attn_fwd(int dtype, const void* q, const void* k, const void* v, void* o
                  int64_t ld_qkv, int64_t ld_o, float scale, float p, uint32_t seed, int bh0, void* stream);
 int a8i_layernorm_bwd(int dtype, const void* dy, const void* dy2, const void* x, const void* res, const float* gamma, const float* mean,
                       const float* rstd, void* dx, void* dres, float* dgamma, float* dbeta, float* dbias, int rows, int cols, float p,
-                      uint32_t seed, uint32_t rng_stream, int64_t rng_elem0, void* stream);
+                      uint32_t seed, uint32_t rng_stream, int64_t rng_elem0, void* stream, float* partials = nullptr);
+int a8i_layernorm_bwd_partial_rows(int rows);
 int a8i_attn_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                  const uint8_t* keymask, void* dq, void* dk, void* dv, float* delta, float* dbias, int B, int T, int H, int64_t ld_qkv,
                  int64_t ld_o, int64_t ld_dqkv, float scale, float p, uint32_t seed, int bh0, void* stream);

@@ -66,11 +66,14 @@ extern "C" int a8_encoder_layer_bwd(const a8_encoder_layer_bwd_desc* e, void* st
     A8_REQUIRE(e->B > 0 && e->T > 0 && e->H > 0 && e->d == e->H * 64 && e->dff > 0, "a8_encoder_layer_bwd: bad sizes B=%d T=%d H=%d d=%d dff=%d",
                e->B, e->T, e->H, e->d, e->dff);
     A8_REQUIRE(e->p > 0.f || (e->dx1_res == e->df && e->dx_res == e->dao), "a8_encoder_layer_bwd: with p = 0, dx1_res / dx_res must alias df / dao");
+    A8_REQUIRE((e->ln1_partials == nullptr) == (e->ln2_partials == nullptr), "a8_encoder_layer_bwd: ln1_partials and ln2_partials go together");
     const int M = e->B * e->T, d = e->d, esz = e->dtype == A8_BF16 ? 2 : 4;
     const bool drop = e->p > 0.f;
     const int64_t rng0 = (int64_t)e->b0 * e->T * d;          // dropout counters of utterances [b0, b0 + B) of the logical batch (see the forward)
+    // e->ln1_partials / ln2_partials (both or neither): the LayerNorm parameter gradients and the w_2 / w_O bias gradients leave the
+    // kernels as per-block partial rows (a8_colsum_partials_reduce, issued by the caller off this stream, adds them into dg / dbe / db)
     if (int rc = a8i_layernorm_bwd(e->dtype, e->dx2, nullptr, e->f, e->x1, e->g1, e->mean1, e->rstd1, e->df, drop ? e->dx1_res : nullptr,
-                                   e->dg1, e->dbe1, e->db2, M, d, e->p, e->seed2, 4, rng0, stream))
+                                   e->dg1, e->dbe1, e->db2, M, d, e->p, e->seed2, 4, rng0, stream, e->ln1_partials))
         return rc;
     a8_gemm_desc g = nt_desc(e->dtype, e->df, e->w2_t, e->dz1, M, e->dff, d, nullptr);
     g.act = A8_ACT_MUL_GELU_GRAD; g.zin = e->z1; g.ldz = e->dff; g.colsum = e->db1;
@@ -78,7 +81,7 @@ extern "C" int a8_encoder_layer_bwd(const a8_encoder_layer_bwd_desc* e, void* st
     g = nt_desc(e->dtype, e->dz1, e->w1_t, e->dx1_ffn, M, d, e->dff, nullptr);
     if (int rc = a8_gemm(&g, stream)) return rc;
     if (int rc = a8i_layernorm_bwd(e->dtype, e->dx1_res, e->dx1_ffn, e->ao, e->x, e->g2, e->mean2, e->rstd2, e->dao, drop ? e->dx_res : nullptr,
-                                   e->dg2, e->dbe2, e->dbo, M, d, e->p, e->seed1, 3, rng0, stream))
+                                   e->dg2, e->dbe2, e->dbo, M, d, e->p, e->seed1, 3, rng0, stream, e->ln2_partials))
         return rc;
     g = nt_desc(e->dtype, e->dao, e->wo_t, e->dout_o, M, d, d, nullptr);
     if (int rc = a8_gemm(&g, stream)) return rc;

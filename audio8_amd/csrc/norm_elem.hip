@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 // waves add into the lower waves' slabs in a second pass) -> one atomic per column per block.
 // acc[c][i] belongs to column (lane + 64c)*8 + i.  lds: float[NS * cols], NS = min(NW, 8).
 template <int NW, int MC>
-A8_DEV void flush_colsum(float (&acc)[MC][8], float* lds, float* __restrict__ out, int cols) {
+A8_DEV void flush_colsum(float (&acc)[MC][8], float* lds, float* __restrict__ out, int cols, const bool store = false) {
     constexpr int NS = NW < 8 ? NW : 8;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nch = cols >> 3;
     __syncthreads();
@@ -144,7 +144,8 @@ A8_DEV void flush_colsum(float (&acc)[MC][8], float* lds, float* __restrict__ ou
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < NS; ++k) t += lds[k * cols + i];
-        atomicAdd(out + i, t);
+        if (store) out[i] = t;                       // a per-block partial row (summed later, off the critical stream): no same-address atomics
+        else atomicAdd(out + i, t);
     }
 }
 
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(NW * 64, MC <= 2 ? 4 : 2) void ln_bwd_kernel(const 
                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, T* __restrict__ dx, T* __restrict__ dres,
                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dbias,
-                                                         int rows, int cols, Drop dr, long long rng0) {
+                                                         float* __restrict__ partials, int rows, int cols, Drop dr, long long rng0) {
     __shared__ __attribute__((aligned(16))) float lds[(NW < 8 ? NW : 8) * MC * 512];
     const int lane = threadIdx.x & 63, nch = cols >> 3;
     const float inv = 1.0f / (float)cols;
@@ -224,18 +225,37 @@ __global__ __launch_bounds__(NW * 64, MC <= 2 ? 4 : 2) void ln_bwd_kernel(const 
                     for (int i = 0; i < 8; ++i) o[i] = a8_kept(keep[c], i) ? o[i] * dr.scale : 0.f;
                 }
                 if (dx) store8(dx + off, o);
-                if (dbias) {
+                if (dbias || partials) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) ad[c][i] += o[i];
                 }
             }
         }
     }
+    if (partials) {                                  // [block][dgamma | dbeta | dbias][cols]: plain coalesced stores (a8_colsum_partials_reduce adds them up)
+        float* pr = partials + (long long)blockIdx.x * 3 * cols;
+        flush_colsum<NW, MC>(ag, lds, pr, cols, true);
+        flush_colsum<NW, MC>(ab, lds, pr + cols, cols, true);
+        flush_colsum<NW, MC>(ad, lds, pr + 2 * cols, cols, true);
+        return;
+    }
     if (dgamma) {
         flush_colsum<NW, MC>(ag, lds, dgamma, cols);
         flush_colsum<NW, MC>(ab, lds, dbeta, cols);
     }
     if (dbias) flush_colsum<NW, MC>(ad, lds, dbias, cols);
+}
+
+// out_k[c] += sum over the partial rows b of ws[b][k][c]  (k = 0..2; a null out_k is skipped).  grid = (column chunks of 256, row stripes)
+__global__ __launch_bounds__(256) void colsum_partials_reduce_kernel(const float* __restrict__ ws, int nrows, int cols, float* __restrict__ o0,
+                                                                      float* __restrict__ o1, float* __restrict__ o2) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= 3 * cols) return;
+    float* const out = c < cols ? o0 : (c < 2 * cols ? o1 : o2);
+    if (!out) return;
+    float t = 0.f;
+    for (int b = blockIdx.y; b < nrows; b += gridDim.y) t += ws[(long long)b * 3 * cols + c];
+    atomicAdd(out + (c % cols), t);
 }
 
 // ------------------------------------------------------------------ dz = dy * gelu'(z); dbias += colsum(dz)
@@ -550,9 +570,21 @@ extern "C" int a8_layernorm_fwd(int dtype, const void* x, const void* res, const
     return a8i_layernorm_fwd(dtype, x, res, gamma, beta, y, mean, rstd, rows, cols, eps, p, seed, rng_stream, 0, stream);
 }
 
+// geometry of a launch: waves per block and rows per wave (a8_set_tuning key 1 = NW*100 + R for the atomic column sums: fewer, fatter
+// blocks mean fewer same-address atomics; key 17 for the partial-row form, where nothing is contended and more, smaller blocks
+// hide the row latency: 8 x 1 / 4 x 2 measured best, -0.06 ms per step against 8 x 2 with atomics)
+static void ln_bwd_geometry(bool partials, int& nw, int& rpw) {
+    const int t = partials ? g_a8_tuning[17] : g_a8_tuning[1];
+    nw = t / 100; rpw = t % 100;
+}
+int a8i_layernorm_bwd_partial_rows(int rows) {
+    int nw, rpw;
+    ln_bwd_geometry(true, nw, rpw);
+    return (nw == 4 || nw == 8 || nw == 16) && rpw > 0 ? cdiv(rows, nw * rpw) : 0;
+}
 int a8i_layernorm_bwd(int dtype, const void* dy, const void* dy2, const void* x, const void* res, const float* gamma,
                       const float* mean, const float* rstd, void* dx, void* dres, float* dgamma, float* dbeta, float* dbias,
-                      int rows, int cols, float p, uint32_t seed, uint32_t rng_stream, int64_t rng_elem0, void* stream) {
+                      int rows, int cols, float p, uint32_t seed, uint32_t rng_stream, int64_t rng_elem0, void* stream, float* partials) {
     A8_REQUIRE(rng_elem0 % 8 == 0, "a8_layernorm_bwd: the counter offset must be a multiple of 8");
     A8_REQUIRE(cols % 8 == 0 && cols <= MAXC * 512, "a8_layernorm_bwd: cols=%d must be a multiple of 8 and <= %d", cols, MAXC * 512);
     A8_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "a8_layernorm_bwd: dgamma and dbeta go together");
@@ -560,11 +592,13 @@ int a8i_layernorm_bwd(int dtype, const void* dy, const void* dy2, const void* x,
     const Drop dr = make_drop(p, seed, rng_stream);
     // rows per wave R and waves per block NW (a8_set_tuning key 1 = NW*100 + R): fewer, fatter blocks mean fewer
     // same-address atomics on the column sums
-    const int nw = g_a8_tuning[1] / 100, rpw = g_a8_tuning[1] % 100;
+    int nw, rpw;
+    ln_bwd_geometry(partials != nullptr, nw, rpw);
+    A8_REQUIRE(rpw > 0, "a8_layernorm_bwd: bad tuning");
     const int grid = cdiv(rows, nw * rpw);
 #define LN_BWD2(NW, MC) DISPATCH_T(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T, NW, MC>), dim3(grid), dim3(NW * 64), 0, (hipStream_t)stream, \
                                          (const T*)dy, (const T*)dy2, (const T*)x, (const T*)res, gamma, mean, rstd, (T*)dx, (T*)dres, \
-                                         dgamma, dbeta, dbias, rows, cols, dr, (long long)rng_elem0))
+                                         dgamma, dbeta, dbias, partials, rows, cols, dr, (long long)rng_elem0))
 #define LN_BWD(NW) do { if (cols <= 1024) LN_BWD2(NW, 2); else LN_BWD2(NW, MAXC); } while (0)
     if (nw == 4) LN_BWD(4); else if (nw == 8) LN_BWD(8); else if (nw == 16) LN_BWD(16);
     else return a8_set_error(A8_ERR_ARG, "a8_layernorm_bwd: bad tuning %d", g_a8_tuning[1]);
@@ -576,7 +610,16 @@ int a8i_layernorm_bwd(int dtype, const void* dy, const void* dy2, const void* x,
 extern "C" int a8_layernorm_bwd(int dtype, const void* dy, const void* dy2, const void* x, const void* res, const float* gamma,
                                 const float* mean, const float* rstd, void* dx, void* dres, float* dgamma, float* dbeta, float* dbias,
                                 int rows, int cols, float p, uint32_t seed, uint32_t rng_stream, void* stream) {
-    return a8i_layernorm_bwd(dtype, dy, dy2, x, res, gamma, mean, rstd, dx, dres, dgamma, dbeta, dbias, rows, cols, p, seed, rng_stream, 0, stream);
+    return a8i_layernorm_bwd(dtype, dy, dy2, x, res, gamma, mean, rstd, dx, dres, dgamma, dbeta, dbias, rows, cols, p, seed, rng_stream, 0, stream, nullptr);
+}
+
+extern "C" int a8_layernorm_bwd_partial_rows(int rows) { return a8i_layernorm_bwd_partial_rows(rows); }
+extern "C" int a8_colsum_partials_reduce(const float* ws, int nrows, int cols, float* out0, float* out1, float* out2, void* stream) {
+    A8_REQUIRE(ws != nullptr && nrows >= 0 && cols > 0, "a8_colsum_partials_reduce: bad arguments");
+    if (nrows == 0) return A8_OK;
+    int gy = nrows < 16 ? nrows : 16;
+    hipLaunchKernelGGL(colsum_partials_reduce_kernel, dim3(cdiv(3 * cols, 256), gy), dim3(256), 0, (hipStream_t)stream, ws, nrows, cols, out0, out1, out2);
+    return a8_check_launch("a8_colsum_partials_reduce");
 }
 
 extern "C" int a8_gelu_bwd_bias(int dtype, const void* dy, const void* z, void* dz, float* dbias, int rows, int cols, void* stream) {

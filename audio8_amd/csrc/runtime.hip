@@ -23,7 +23,7 @@ int a8_check_launch(const char* what) {
 extern "C" int a8_version(void) { return A8HIP_VERSION; }
 extern "C" const char* a8_last_error(void) { return g_err; }
 
-int g_a8_tuning[32] = {0, 802, 0, 41, 41, 20000, 3, 0, 0, 0, 0, 0, 0, 0, 1000, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+int g_a8_tuning[32] = {0, 802, 0, 41, 41, 20000, 3, 0, 0, 0, 0, 0, 0, 0, 1000, 1, 0, 801, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 extern "C" int a8_set_tuning(int key, int value) {
     if (key < 0 || key >= 32) return a8_set_error(A8_ERR_ARG, "a8_set_tuning: unknown key %d", key);

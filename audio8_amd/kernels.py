@@ -112,11 +112,13 @@ def encoder_layer_fwd(x, keymask, B, T, H, p, eps, seeds, wqkv, bqkv, wo, bo, w1
 
 
 def encoder_layer_bwd(dx2, x, keymask, qkv, o, lse, ao, x1, mean2, rstd2, z1, f, mean1, rstd1, g1, g2, w2_t, w1_t, wo_t,
-                      dg1, dbe1, dg2, dbe2, db2, db1, dbo, B, T, H, p, seeds, aux_stream=None):
+                      dg1, dbe1, dg2, dbe2, db2, db1, dbo, B, T, H, p, seeds, aux_stream=None, ln_partials=False):
     """a8_encoder_layer_bwd: LN1 bwd, FFN data gradients, LN2 bwd, output-projection data gradient and attention backward in one C call
     (two calls, utterances [0, B/2) on the current stream and [B/2, B) on aux_stream, when one is given: the parameter gradients the
     chain produces are atomic column sums, the rest is row-local).
-    Returns (df, dz1, dao, dqkv, dx_res): the weight-gradient operands and the residual-branch gradient of the layer input."""
+    ln_partials: the two LayerNorm backward launches write per-block partial column sums instead of adding atomically into dg / dbe /
+    db2 / dbo; the sixth return value is then the workspace f32 [2 LayerNorms][partial rows][3][d] for colsum_partials_reduce (else None).
+    Returns (df, dz1, dao, dqkv, dx_res, partials): the weight-gradient operands and the residual-branch gradient of the layer input."""
     M, d = x.shape
     dff = z1.shape[1]
     dev, dt = x.device, x.dtype
@@ -130,10 +132,19 @@ def encoder_layer_bwd(dx2, x, keymask, qkv, o, lse, ao, x1, mean2, rstd2, z1, f,
     dqkv = torch.empty((M, 3 * d), device=dev, dtype=dt)
     delta = torch.empty((B, H, T), device=dev, dtype=torch.float32)
     es = x.element_size()
+    split = aux_stream is not None and B >= 2
+    halves = [(0, B // 2), (B // 2, B - B // 2)] if split else [(0, B)]
+    ws, prow0 = None, [0] * len(halves)
+    if ln_partials:
+        nrows = [L.lib().a8_layernorm_bwd_partial_rows(nb * T) for _, nb in halves]
+        prow0 = [sum(nrows[:i]) for i in range(len(halves))]
+        ws = torch.empty((2, sum(nrows), 3, d), device=dev, dtype=torch.float32)
 
-    def desc(b0, nb):
+    def desc(i):
+        b0, nb = halves[i]
         r0 = b0 * T
         rd, rf = r0 * d * es, r0 * dff * es
+        wp = [ws[k].data_ptr() + prow0[i] * 3 * d * 4 for k in (0, 1)] if ws is not None else [None, None]
         return L.EncoderLayerBwdDesc(L.dt(x), nb, T, H, d, dff, p, _u32(seeds[0]), _u32(seeds[1]), _u32(seeds[2]), b0,
                                      dx2.data_ptr() + rd, x.data_ptr() + rd, qkv.data_ptr() + 3 * rd, o.data_ptr() + rd, ao.data_ptr() + rd,
                                      x1.data_ptr() + rd, z1.data_ptr() + rf, f.data_ptr() + rd,
@@ -143,18 +154,25 @@ def encoder_layer_bwd(dx2, x, keymask, qkv, o, lse, ao, x1, mean2, rstd2, z1, f,
                                      w2_t.data_ptr(), w1_t.data_ptr(), wo_t.data_ptr(),
                                      dg1.data_ptr(), dbe1.data_ptr(), dg2.data_ptr(), dbe2.data_ptr(), db2.data_ptr(), db1.data_ptr(), dbo.data_ptr(),
                                      df.data_ptr() + rd, dx1_res.data_ptr() + rd, dz1.data_ptr() + rf, dx1_ffn.data_ptr() + rd, dao.data_ptr() + rd,
-                                     dx_res.data_ptr() + rd, dout_o.data_ptr() + rd, dqkv.data_ptr() + 3 * rd, delta.data_ptr() + 4 * b0 * H * T)
-    if aux_stream is not None and B >= 2:
-        nb = B // 2
-        ea, eb = desc(0, nb), desc(nb, B - nb)
-        for t_ in (dx2, slab, dz1, dqkv, delta):
+                                     dx_res.data_ptr() + rd, dout_o.data_ptr() + rd, dqkv.data_ptr() + 3 * rd, delta.data_ptr() + 4 * b0 * H * T,
+                                     wp[0], wp[1])
+    if split:
+        ea, eb = desc(0), desc(1)
+        for t_ in (dx2, slab, dz1, dqkv, delta) + ((ws,) if ws is not None else ()):
             t_.record_stream(aux_stream)          # (the saved forward tensors carry aux in their stream set since the forward)
         L.check(L.lib().a8_encoder_layer_bwd(C.byref(ea), L.stream()), "a8_encoder_layer_bwd")
         L.check(L.lib().a8_encoder_layer_bwd(C.byref(eb), aux_stream.cuda_stream), "a8_encoder_layer_bwd")
     else:
-        e = desc(0, B)
+        e = desc(0)
         L.check(L.lib().a8_encoder_layer_bwd(C.byref(e), L.stream()), "a8_encoder_layer_bwd")
-    return df, dz1, dao, dqkv, dx_res
+    return df, dz1, dao, dqkv, dx_res, ws
+
+
+def colsum_partials_reduce(ws, out0, out1, out2):
+    """out_k += column sums of ws[:, k, :] (ws f32 [rows, 3, cols]: the partial rows of a LayerNorm backward launch); on the current stream."""
+    rows, three, cols = ws.shape
+    assert three == 3 and ws.is_contiguous() and ws.dtype == torch.float32
+    L.check(L.lib().a8_colsum_partials_reduce(ws.data_ptr(), rows, cols, L.ptr(out0), L.ptr(out1), L.ptr(out2), L.stream()), "a8_colsum_partials_reduce")
 
 
 def gemm_grouped(layout, problems):

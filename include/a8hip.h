@@ -60,7 +60,7 @@ int a8_gemm_grouped(const a8_gemm_desc* descs, int n, void* stream);
  * stream bf16 NT GEMM (N % 256 == 0, K % 128 == 0: BM x 256 tiles on persistent blocks, the conv layers' forward; default 20000, 0 = off),
  * 7 its forced tile height (160 / 192 / 224 / 256; 0 = chosen per launch), 8 its grid in CUs' worths of persistent blocks (default 1: all
  * resident from the start; 2..4: shorter static shares, surplus blocks dispatched as CUs free up -- +0.09 ms alone on the GPU, for runs where
- * another kernel holds CUs at launch); 6 positional-conv weight-gradient loop splits;
+ * another kernel holds CUs at launch); 6 positional-conv weight-gradient loop splits; 17 LayerNorm-backward geometry of the partial-row form (default 801);
  * 9 = 1: conv layer 0 on the VALU in bf16 mode too; 14 asymmetric LDS ring for bf16 NT GEMMs (A requested two k-tiles ahead, B one):
  * 0 = off, otherwise the minimum M (default 1000: the conv layers and the encoder's products -- issued as half-batches on two streams,
  * most of their blocks sit alone on a CU, where the deeper A ring hides what a co-resident block otherwise would); 15 the same ring for
@@ -205,8 +205,18 @@ typedef struct a8_encoder_layer_bwd_desc {
     float *dg1, *dbe1, *dg2, *dbe2, *db2, *db1, *dbo;
     void *df, *dx1_res, *dz1, *dx1_ffn, *dao, *dx_res, *dout_o, *dqkv;
     float* delta;
+    float *ln1_partials, *ln2_partials;   /* NULL: dg / dbe / db2 / dbo are accumulated by the kernels (f32 atomics).  Otherwise f32
+                                             [a8_layernorm_bwd_partial_rows(B*T)][3][d] each: per-block partial column sums (dgamma | dbeta |
+                                             bias gradient), to be added into dg1, dbe1, db2 (ln1) / dg2, dbe2, dbo (ln2) by
+                                             a8_colsum_partials_reduce on any stream ordered behind this call */
 } a8_encoder_layer_bwd_desc;
 int a8_encoder_layer_bwd(const a8_encoder_layer_bwd_desc* e, void* stream);
+/* LayerNorm backward without same-address atomics (audio8/wav2vec2.py:613-623 LayerNorms' weight / bias gradients): the number of
+ * partial rows one backward launch over `rows` rows writes, and the reduction out_k[c] += sum_b ws[b][k][c] (ws f32 [nrows][3][cols]; a NULL
+ * out_k is skipped).  391 x 2304 same-address atomics per launch forced few, fat, latency-exposed blocks: -0.06 ms per step, and the sums are
+ * deterministic up to the 16 row stripes of the reduction. */
+int a8_layernorm_bwd_partial_rows(int rows);
+int a8_colsum_partials_reduce(const float* ws, int nrows, int cols, float* out0, float* out1, float* out2, void* stream);
 
 /* ---- small runtime helpers of the step (no ATen kernels between the first conv launch and the optimizer) ------------------
  * a8_zero: bytes of device memory := 0 on the stream (hipMemsetAsync).

@@ -735,3 +735,49 @@ def test_half_batch_two_stream_backward_matches_whole_batch(restore_dtype):
             assert float((p0 - p1).abs().max()) <= 1e-3 * float(p0.abs().max())
     finally:
         ops.HALF_BATCH_BWD = old
+
+
+def test_layernorm_partial_row_column_sums_match_the_atomic_form(restore_dtype):
+    """ops.LN_PARTIALS: under a Stepper the two LayerNorm backward launches of an encoder layer write per-block partial column sums
+    (dgamma | dbeta | the w_2 / w_O bias gradient) instead of f32 atomics on 3 x 768 addresses, and a8_colsum_partials_reduce adds them
+    into the flat gradient on the weight-gradient stream.  Same dropout masks, same row arithmetic: every gradient must equal the
+    atomic form's to the order of f32 sums -- whole batch and half-batch streams, an odd batch (1 + 2: unequal partial-row counts), and
+    with layer drop (a dropped layer's parameters untouched)."""
+    from audio8_amd import ops, wav2vec2 as W
+    from audio8_amd.trainer import Stepper
+    ops.set_compute_dtype(torch.bfloat16)
+    old = (ops.LN_PARTIALS, ops.HALF_BATCH_BWD)
+
+    def run(partials, B, half, layer_drop=0.0):
+        ops.LN_PARTIALS, ops.HALF_BATCH_BWD = partials, half
+        torch.manual_seed(0)
+        ops.reset_seed_stream()
+        model = W.create_model(num_layers=3, dropout=0.1, layer_drop=layer_drop).cuda().train()
+        st = Stepper(model, lr=1e-4, weight_decay=1e-2, clip=1.0)
+        try:
+            loss_fn = W.create_loss(640, 100)
+            x = synth(B, 24000, 5).cuda()
+            st.zero_grad()
+            np.random.seed(3)
+            loss = loss_fn(model, x)
+            loss.backward()
+            st.sync_grads()
+            torch.cuda.synchronize()
+            g = st.state.flat_g.clone()
+            st.step()
+            torch.cuda.synchronize()
+            return loss.item(), g, st.state.flat_p.clone()
+        finally:
+            st.close()
+    try:
+        for B, half, ld in ((4, True, 0.0), (3, True, 0.0), (4, False, 0.0), (4, True, 0.5)):
+            l0, g0, p0 = run(False, B, half, ld)
+            l1, g1, p1 = run(True, B, half, ld)
+            assert abs(l0 - l1) <= 2e-6 * abs(l0), (B, half, l0, l1)
+            assert torch.isfinite(g1).all()
+            scale = float(g0.abs().max())
+            assert float((g0 - g1).abs().max()) <= 2e-5 * scale, (B, half, ld)
+            assert float((p0 - p1).abs().max()) <= 1e-3 * float(p0.abs().max())
+    finally:
+        ops.LN_PARTIALS, ops.HALF_BATCH_BWD = old
+

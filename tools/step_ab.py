@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from audio8_amd import _lib as L, ops, wav2vec2 as W  # noqa: E402
 from audio8_amd.trainer import Stepper  # noqa: E402
 
-DEFAULTS = {1: 802, 2: 0, 3: 41, 4: 41, 5: 20000, 6: 3, 7: 0, 8: 0, 14: 1000, 15: 1}
+DEFAULTS = {1: 802, 2: 0, 3: 41, 4: 41, 5: 20000, 6: 3, 7: 0, 8: 0, 14: 1000, 15: 1, 17: 801}
 cfgs = []
 for part in (sys.argv[1] if len(sys.argv) > 1 else "base:").split(";"):
     name, _, kv = part.partition(":")
@@ -47,6 +47,7 @@ def apply(d):
     ops.WGRAD_STORE_FIRST = bool(d.get("storefirst", 1))
     ops.HALF_BATCH_STREAMS = bool(d.get("half", 1))
     ops.HALF_BATCH_BWD = bool(d.get("halfbwd", 1))
+    ops.LN_PARTIALS = bool(d.get("lnp", 1))
     ops.SPLITK_SLOTS = d.get("skslots", 512)
     ops.SPLITK_MIN_ROWS = d.get("skrows", 800)
 
