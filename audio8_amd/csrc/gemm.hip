@@ -73,13 +73,18 @@ template <int KB> struct StageTile<bf16, KB> {
         const int row = rb + (lane & 15);
         return *reinterpret_cast<const bf16x8*>(t + row * G::KROW + (((ks * 4 + (lane >> 4)) ^ G::swz(row)) << 4));
     }
+    // The two transposed reads of a fragment as inline assembly: in front of the ds_read_tr builtin (no alias information) hipcc puts
+    // s_waitcnt vmcnt(0), which drained the LDS-DMA ring at the top of EVERY k-tile of the K-strided layouts (weight gradients): the
+    // tile requested last had to land at once and the refill could only be issued behind the reads.  The callers wait for these reads
+    // themselves (s_waitcnt lgkmcnt in front of the MFMAs: the compiler does not track an asm statement's LDS result).
     static A8_DEV bf16x8 ks_frag(const char* t, int rb, int ks, int lane) {
         const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3, nb = rb >> 4;
-        const int k0 = ks * 32 + 8 * g + q, k1 = k0 + 4;
-        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, t + k0 * 256 + ((nb ^ ks_key(k0)) << 5) + 8 * p));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, t + k1 * 256 + ((nb ^ ks_key(k1)) << 5) + 8 * p));
-        typedef short s16x8 __attribute__((ext_vector_type(8)));
-        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const int k0 = ks * 32 + 8 * g + q;            // the second read is k0 + 4: same swizzle key, 1024 bytes on
+        const unsigned a = (unsigned)(size_t)LDS_PTR(char, t + k0 * 256 + ((nb ^ ks_key(k0)) << 5) + 8 * p);
+        u32x2 lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(hi) : "v"(a));
+        const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
         return __builtin_bit_cast(bf16x8, v);
     }
     static A8_DEV void ks_src(int p, int lane, int& k, int& col) {
@@ -470,10 +475,9 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
             __builtin_amdgcn_s_barrier();
             if (kb == 0) stamp(g, 2);
             const int sa2 = sa == 0 ? 2 : sa - 1;     // (sa + 2) % 3: the slot read in the previous iteration
-            if constexpr (!(AKS || BKS)) {
-                issue_b(kb + 1, bbase + (sb ^ 1) * TB);   // (beyond kend: 16 zero bytes per lane -- keeps the counts uniform)
-                issue_a(kb + 2, lds + sa2 * TA);
-            }
+            issue_b(kb + 1, bbase + (sb ^ 1) * TB);   // (beyond kend: 16 zero bytes per lane -- keeps the counts uniform)
+            issue_a(kb + 2, lds + sa2 * TA);
+            __builtin_amdgcn_sched_barrier(0);
             const char* ta = lds + sa * TA;
             const char* tb = bbase + sb * TB;
             typename MM::Frag fa[ST::KSTEPS][MI], fb[ST::KSTEPS][NJ];
@@ -486,12 +490,8 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
                 for (int i = 0; i < NJ; ++i)
                     fb[ks][i] = BKS ? ST::ks_frag(tb, wn * (16 * NJ) + 16 * i, ks, lane) : ST::kc_frag(tb, wn * (16 * NJ) + 16 * i, ks, lane);
             }
+            if constexpr ((AKS || BKS) && sizeof(T) == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (inline-asm transposed reads)
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (AKS || BKS) {               // (transposed reads: the refill goes behind them, as in the symmetric loop)
-                issue_b(kb + 1, bbase + (sb ^ 1) * TB);
-                issue_a(kb + 2, lds + sa2 * TA);
-                __builtin_amdgcn_sched_barrier(0);
-            }
 #pragma unroll
             for (int ks = 0; ks < ST::KSTEPS; ++ks)
 #pragma unroll
@@ -511,9 +511,10 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NST - 2) * (PPA + PPB)) : "memory");
             __builtin_amdgcn_s_barrier();
             if (kb == 0) stamp(g, 2);
-            // DMA issue order, measured: with plain b128 fragment reads (NT) issuing the refill first is best; with
-            // transposed reads (twice the LDS instructions) issuing it after the reads hides its issue slots in their latency
-            if constexpr (!(AKS || BKS)) issue(kb + NST - 1);
+            // DMA issue order: the refill first, then the fragment reads (with the transposed reads as inline assembly -- StageTile::ks_frag --
+            // that holds for the K-strided layouts too: no compiler-inserted vmcnt(0) in front of them any more)
+            issue(kb + NST - 1);                  // refills the buffer every wave finished reading last iteration
+            __builtin_amdgcn_sched_barrier(0);
             const char* ta = lds + (kb % NST) * STAGE;
             const char* tb = ta + TA;
             // all fragment reads of the k-tile are issued up front (one exposed LDS latency per tile, counted lgkmcnt waits
@@ -528,11 +529,8 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
                 for (int i = 0; i < NJ; ++i)
                     fb[ks][i] = BKS ? ST::ks_frag(tb, wn * (16 * NJ) + 16 * i, ks, lane) : ST::kc_frag(tb, wn * (16 * NJ) + 16 * i, ks, lane);
             }
+            if constexpr ((AKS || BKS) && sizeof(T) == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (inline-asm transposed reads)
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (AKS || BKS) {
-                issue(kb + NST - 1);              // refills the buffer every wave finished reading last iteration
-                __builtin_amdgcn_sched_barrier(0);
-            }
             // swapped operands: accumulator reg r <-> 4 consecutive n, lane&15 <-> m  (row-contiguous C stores)
 #pragma unroll
             for (int ks = 0; ks < ST::KSTEPS; ++ks)
