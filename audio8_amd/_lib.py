@@ -109,6 +109,9 @@ class WPrepDesc(C.Structure):
                 ("tap", C.c_int), ("ld_dst", C.c_int), ("ld_dstT", C.c_int)]
 
 
+ABI_VERSION = 110            # include/a8hip.h: A8HIP_VERSION
+
+
 def lib():
     """Load (once) and return the HIP library; raise if it is not built."""
     global _lib
@@ -120,6 +123,9 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         _lib.a8_last_error.restype = C.c_char_p
         _lib.a8_version.restype = C.c_int
+        if _lib.a8_version() != ABI_VERSION:          # descriptor layouts are positional: never talk to a library of another layout
+            got, _lib = _lib.a8_version(), None
+            raise RuntimeError(f"a8hip: {LIB_PATH} has ABI version {got}, this binding was written for {ABI_VERSION} -- rebuild the library")
         for name, argtypes in ARGTYPES.items():
             fn = getattr(_lib, name)
             fn.argtypes = argtypes

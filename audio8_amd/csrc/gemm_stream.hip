@@ -317,10 +317,13 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const StreamArgs g)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// the tile height that minimises rounds x (time per tile): MFMA time grows with BM, the operand feed with BM + 256
+// the tile height that minimises rounds x (time per tile): MFMA time grows with BM, the operand feed with BM + 256.
+// 256 rows (MI = 8) is not offered: at the 256-register cap those instantiations spill (2..16 registers, tests/test_codeobj_cpu.py),
+// the reloads count in vmcnt and drain the DMA ring, and 224 rows measured faster on every layer anyway (conv layer 1 forward alone:
+// 340 vs 350 us); a8_set_tuning key 7 = 256 still forces it (bit-identity tests).
 int pick_bm(int batches, int rpb, int tiles_n, int cus) {
     int best = 0; double bc = 1e30;
-    for (int bm = 160; bm <= 256; bm += 32) {
+    for (int bm = 160; bm <= 224; bm += 32) {
         if (rpb < bm) continue;
         const long long tiles = (long long)batches * cdiv(rpb, bm) * tiles_n;
         const long long rounds = (tiles + cus - 1) / cus;
@@ -333,10 +336,15 @@ int pick_bm(int batches, int rpb, int tiles_n, int cus) {
 }  // namespace
 
 // Fills the kernel arguments if the problem fits the stream kernel.  a8_set_tuning key 5 = minimum M (0 = never); key 7 = forced
-// tile height (0 = chosen per launch).
+// tile height (0 = chosen per launch); key 19 = 1: plain (not row-remapped) problems too.
 static bool stream_plan(const a8_gemm_desc* d, StreamArgs& g, int& bm, int& grid, bool& deep) {
     const int min_m = g_a8_tuning[5];
     if (min_m <= 0 || d->dtype != A8_BF16 || d->layout != A8_GEMM_NT || d->M < min_m) return false;
+    // Opt-in by problem kind, not by size alone: only row-remapped A operands (the conv layers as GEMMs) take this kernel.  A plain Dense
+    // product with M >= min_m (the encoder's projections at a large batch) stays on the 128 x 128 tiles: a persistent block owns its CU,
+    // so nothing of the half-batch or weight-gradient streams runs beside it (+0.36 .. +0.47 ms per step measured).
+    // a8_set_tuning key 19 = 1 lifts the restriction (tests, A/B runs).
+    if (!d->a_rpb && g_a8_tuning[19] == 0) return false;
     if (d->N % 256 || d->K % 128 || d->K < 256 || d->out_f32 || d->accumulate || d->splitk > 1 || d->colsum || d->bias_rows || d->alpha != 1.0f) return false;
     const bool zin = d->act == A8_ACT_MUL_GELU_GRAD || d->act == A8_ACT_ADD;
     if (!(d->act == A8_ACT_NONE || d->act == A8_ACT_GELU || zin) || (zin && (!d->zin || d->zout)) || (!zin && d->zin) || d->b_rpb) return false;
@@ -366,6 +374,25 @@ static bool stream_plan(const a8_gemm_desc* d, StreamArgs& g, int& bm, int& grid
     bm = g_a8_tuning[7];
     if (!(bm == 160 || bm == 192 || bm == 224 || bm == 256) || rpb < bm) bm = pick_bm(batches, rpb, d->N / 256, cus);
     if (!bm) return false;
+    // Aliasing rule (include/a8hip.h): the last tile of a batch item is shifted up to end with it, so when rpb % bm != 0 its top rows
+    // are computed and stored by TWO tiles.  That is only sound while nothing a tile reads (A, B, zin) overlaps what another tile
+    // writes (C, zout): an in-place "+ zin" / "x gelu'(zin)" (C == zin) would apply the second input twice on those rows.  Such a
+    // problem goes to the 128 x 128 kernels, where every element is read and written once by the same lane.
+    if (rpb % bm) {
+        auto overlaps = [](const void* p, long long pbytes, const void* q, long long qbytes) {
+            const uintptr_t a = (uintptr_t)p, b = (uintptr_t)q;
+            return p && q && a < b + (uintptr_t)qbytes && b < a + (uintptr_t)pbytes;
+        };
+        const long long cb = c_span * 2, zb = z_span * 2;
+        const void* outs[2] = {d->C, d->zout};
+        const long long outb[2] = {cb, zb};
+        for (int o = 0; o < 2; ++o) {
+            if (!outs[o]) continue;
+            if (overlaps(outs[o], outb[o], d->A, a_span) || overlaps(outs[o], outb[o], d->B, b_span) ||
+                (zin && overlaps(outs[o], outb[o], d->zin, zb)))
+                return false;
+        }
+    }
     g.A = (const char*)d->A; g.B = (const char*)d->B; g.C = (char*)d->C; g.Z = (char*)d->zout; g.Zin = (const char*)d->zin; g.bias = d->bias;
     g.lda = (int)d->lda; g.a_bs = (int)a_bs; g.ldb = (int)d->ldb;
     g.ldc = (int)d->ldc; g.c_bs = (int)c_bs; g.ldz = (int)d->ldz; g.z_bs = (int)z_bs;

@@ -196,14 +196,14 @@ class GradReducer:
         self.enabled = self.world > 1 or (dist.is_initialized() and os.environ.get("A8_FORCE_REDUCER", "0") == "1")
         self.on_gpu = state.flat_g.is_cuda
         self.side = torch.cuda.Stream() if self.on_gpu else None     # exchange + per-bucket gradient-norm stream
-        if self.enabled and self.on_gpu and self.world > 1 and os.environ.get("A8_STREAM_GRID", "") == "":
-            # RCCL kernels hold some CUs while the conv layers' persistent stream GEMMs launch: two CUs' worths of blocks (half-size static
-            # shares, the surplus dispatched as CUs free up) keep that work-conserving; alone on the GPU it costs 0.09 ms per step, which is
-            # why the single-GPU default stays 1 (a8_set_tuning key 8; A8_STREAM_GRID=<n> overrides)
+        # a8_set_tuning key 8 (the conv layers' persistent stream GEMMs launched as n CUs' worths of blocks: shorter static shares, the
+        # surplus dispatched as CUs free up -- work-conserving when RCCL kernels hold CUs at launch) costs 0.09 ms per step alone on the
+        # GPU and has never been measured under real RCCL traffic: it stays at the library default (1) unless A8_STREAM_GRID=<n> asks;
+        # close() restores the value found here
+        self._stream_grid_saved = None
+        if self.on_gpu and os.environ.get("A8_STREAM_GRID", "") != "":
             from . import _lib as L
-            L.check(L.lib().a8_set_tuning(8, 2), "a8_set_tuning")
-        elif self.on_gpu and os.environ.get("A8_STREAM_GRID", "") != "":
-            from . import _lib as L
+            self._stream_grid_saved = 1
             L.check(L.lib().a8_set_tuning(8, int(os.environ["A8_STREAM_GRID"])), "a8_set_tuning")
         # RCCL enqueues a collective on the stream it is issued from, so kernels behind it on that stream see the reduced data;
         # gloo (CPU rehearsals of the GPU path) completes on its own threads: only wait() orders it
@@ -520,6 +520,11 @@ class Stepper:
         ops.CONV_DGRAD_CACHE = None
         ops.wait_weight_prep()
         ops.WPREP_EARLY = frozenset()
+        red = getattr(self, "reducer", None)
+        if red is not None and getattr(red, "_stream_grid_saved", None) is not None:      # A8_STREAM_GRID override: back to the default
+            from . import _lib as L
+            L.check(L.lib().a8_set_tuning(8, red._stream_grid_saved), "a8_set_tuning")
+            red._stream_grid_saved = None
         global ACTIVE_STEPPER
         if ACTIVE_STEPPER is self:
             ACTIVE_STEPPER = None

@@ -19,7 +19,10 @@
 extern "C" {
 #endif
 
-#define A8HIP_VERSION 100
+/* Bumped whenever a descriptor struct's layout or an entry point's meaning changes (round 4 appended ln1_partials / ln2_partials to
+ * a8_encoder_layer_bwd_desc without doing so).  A binding built against another value must refuse to load: the descriptors carry no
+ * size field, a shorter struct would be read past its end.  audio8_amd/_lib.py checks a8_version() == the value it was written for. */
+#define A8HIP_VERSION 110
 
 enum { A8_DT_F32 = 0, A8_DT_BF16 = 1 };
 enum { A8_GEMM_NT = 0, A8_GEMM_NN = 1, A8_GEMM_TN = 2 };
@@ -33,7 +36,10 @@ const char* a8_last_error(void);      /* thread-local text of the last non-zero 
  * FFN projections of TransformerEncoderStack (:613-622) and, through the row remap, nn.Conv1d layers
  * 1..6 of ConvFeatureExtractionModel (:425-429).
  * C[M,N] = epi(alpha * A . B^T + bias);  layout NT: A[M][K],B[N][K]; NN: A[M][K],B[K][N]; TN: A[K][M],B[K][N].
- * Outer index o of an operand addresses (o / rpb) * bs + (o % rpb) * ld elements (rpb = 0: o * ld). */
+ * Outer index o of an operand addresses (o / rpb) * bs + (o % rpb) * ld elements (rpb = 0: o * ld).
+ * Aliasing rule: C (and zout) may alias zin element for element (in-place "+ zin" / "x gelu'(zin)": every element is then read and
+ * written once, by the same lane); they must not otherwise overlap A, B or zin.  The library sends an aliased problem to the
+ * 128 x 128 kernels (the stream kernel's shifted last tile stores some rows twice). */
 typedef struct a8_gemm_desc {
     int dtype, layout;
     int M, N, K;
@@ -64,7 +70,9 @@ int a8_gemm_grouped(const a8_gemm_desc* descs, int n, void* stream);
  * 9 = 1: conv layer 0 on the VALU in bf16 mode too; 14 asymmetric LDS ring for bf16 NT GEMMs (A requested two k-tiles ahead, B one):
  * 0 = off, otherwise the minimum M (default 1000: the conv layers and the encoder's products -- issued as half-batches on two streams,
  * most of their blocks sit alone on a CU, where the deeper A ring hides what a co-resident block otherwise would); 15 the same ring for
- * bf16 TN products (the weight gradients; default 1 = on). */
+ * bf16 TN products (the weight gradients; default 1 = on); 19 = 1: the stream kernel also takes plain (not row-remapped) problems
+ * (default 0: only the conv layers' remapped products -- a persistent block owns its CU, which costs the encoder's projections their
+ * co-running streams). */
 int a8_set_tuning(int key, int value);
 
 /* ---- per-step weight preparation (the f32 -> compute-dtype casts the reference's autocast-free f32 path never needs;

@@ -299,3 +299,18 @@ def test_cfg2_sequence_length_bf16_against_oracle():
         assert gcos > 0.98 and grel < 0.25, (gcos, grel)
     finally:
         ops.set_compute_dtype(old)
+
+
+def test_cfg2_sequence_length_f32_against_oracle():
+    """north_star's tolerance mode (f32) at the benchmark depth AND sequence length, with every gradient: wav2vec2-base (12 layers),
+    2 x 250 000 samples -> T = 781 frames (the 64-key ragged last attention tile, conv layer 1 at 25 k rows per utterance, the
+    Tm = 368 loss geometry).  Loss and contrastive logits within 1e-4 rtol (audio8/wav2vec2.py:927-952, 371-392), every parameter
+    gradient within 3e-4 relative L2 of the oracle's (the 12-layer bound of test_model_gpu.py)."""
+    from test_model_gpu import _pretrain_pair, _check_f32_parity
+    from audio8_amd import ops
+    old = ops.compute_dtype()
+    try:
+        worst = _check_f32_parity(*_pretrain_pair(torch.float32, num_layers=12, B=2, L=250000, seed=1), grad_tol=3e-4)
+        print("f32, 12 layers, T = 781: worst per-parameter relative gradient error %.3e" % worst)
+    finally:
+        ops.set_compute_dtype(old)

@@ -245,7 +245,7 @@ def test_gemm_alternative_nt_kernels_match_default(key, height):
     epilogue; ineligible problems must fall through.  (The round-2 experiments that did not ship live in tools/ubench/gemm_variants.hip.)"""
     from audio8_amd import kernels as Kn, _lib as L
     dev, bf = "cuda", torch.bfloat16
-    saved = {5: 0, 14: 0, 7: 0}
+    saved = {5: 0, 14: 0, 7: 0, 19: 0}
 
     def both(fn):
         try:
@@ -254,6 +254,7 @@ def test_gemm_alternative_nt_kernels_match_default(key, height):
             ref = fn()
             L.check(L.lib().a8_set_tuning(key, 1), "tune")
             L.check(L.lib().a8_set_tuning(7, height), "tune")
+            L.check(L.lib().a8_set_tuning(19, 1), "tune")               # plain (not row-remapped) problems through the stream kernel too
             got = fn()
         finally:
             for k_, v_ in {**saved, 14: 1000, 5: 20000}.items():       # back to the library defaults
@@ -280,6 +281,20 @@ def test_gemm_alternative_nt_kernels_match_default(key, height):
     same(*both(gelu_zout), "gelu+zout")
     same(*both(lambda: (Kn.gemm(L.NT, A, B, M, N, K, act=L.ACT_MUL_GELU_GRAD, zin=z),)), "x gelu'(z)")
     same(*both(lambda: (Kn.gemm(L.NT, A, B, M, N, K, act=L.ACT_ADD, zin=z),)), "add")
+
+    # in place (C == zin; M is no multiple of any tile height): the stream kernel's shifted last tile would add zin twice on the rows two
+    # tiles store -- stream_plan must hand such a problem to the 128 x 128 kernels (a8hip.h, aliasing rule)
+    def add_in_place():
+        zc = z.clone()
+        return (Kn.gemm(L.NT, A, B, M, N, K, act=L.ACT_ADD, zin=zc, out=zc),)
+    ref_ip, got_ip = both(add_in_place)
+    same(ref_ip, got_ip, "add, in place")
+    assert torch.equal(ref_ip[0], Kn.gemm(L.NT, A, B, M, N, K, act=L.ACT_ADD, zin=z)), "in-place add differs from the out-of-place one"
+
+    def mul_in_place():
+        zc = z.clone()
+        return (Kn.gemm(L.NT, A, B, M, N, K, act=L.ACT_MUL_GELU_GRAD, zin=zc, out=zc),)
+    same(*both(mul_in_place), "x gelu'(z), in place")
     bias = torch.randn(N, device=dev)
     same(*both(lambda: (Kn.gemm(L.NT, A, B, M, N, K, bias=bias),)), "bias")
 

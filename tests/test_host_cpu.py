@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/a8hip.h but not exported"
     assert sorted(L.EXPORTS) == declared
-    assert lib.a8_version() == 100
+    assert lib.a8_version() == L.ABI_VERSION == int(re.search(r"#define A8HIP_VERSION (\d+)", hdr).group(1))
 
 
 def test_state_dict_keys_match_reference_names():
