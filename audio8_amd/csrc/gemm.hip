@@ -29,7 +29,7 @@ struct GemmArgs {
     const float* bias;
     float* colsum;
     int M, N, K, kchunk, nsplit, tiles_m, tiles_n;
-    int act, out_f32, atomic, bias_rows, group_m;
+    int act, out_f32, atomic, bias_rows, group_m, direct_off;
 #ifdef A8_STAMPS
     unsigned long long* stamps;                   // developer build only (make STAMPS=1, a8_debug_set_stamps): 8 timestamps per block, nullptr = off
 #endif
@@ -243,6 +243,87 @@ A8_DEV void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MI][NJ], char* lds, co
         }
     }
 }
+// ---- epilogue without LDS (16-bit outputs of the NT kernels; the arithmetic, in the order of gemm_epilogue: bit-identical results).
+// Accumulator register r of fragment (i, j) is column 16 j + 4 (lane >> 4) + r of row 16 i + (lane & 15): two v_permlane16_swap per
+// fragment PAIR give every lane 8 consecutive columns, so a wave-instruction stores 16 rows x 64 contiguous bytes (gemm_stream.hip's
+// epilogue).  No barrier, no wait for the other waves, nothing parked in the ring: a wave stores as soon as its own MFMAs are done.
+// epre: the lane's prefetched second input -- zin in the layout of the stores (epre[2 i + jj]; the same two swaps, an involution, turn
+// it into the accumulator layout) or the bias in the accumulator layout (epre[2 jj + q] = 4 floats); never both (the caller checks).
+A8_DEV unsigned pack_bf16x2(float a, float b) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const bf16x2 v = {(bf16)a, (bf16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+template <int MI>
+A8_DEV void gemm_epilogue_direct(const GemmArgs& g, f32x4 (&acc)[MI][NJ], const int w, const int m0, const int n0, const int lane,
+                                 const u32x4 (&epre)[2 * MI]) {
+#pragma clang fp contract(off)
+    static_assert(MI == 2 && NJ == 4, "a wave owns 32 x 64");
+    const int wm = w >> 1, wn = w & 1, li = lane & 15, gq = lane >> 4;
+    const bool zmul = g.act == A8_ACT_MUL_GELU_GRAD, zadd = g.act == A8_ACT_ADD, gelu = g.act == A8_ACT_GELU;
+    const bool has_z = zmul || zadd;
+    bf16* const C = reinterpret_cast<bf16*>(g.C);
+    bf16* const Z = reinterpret_cast<bf16*>(g.zout);
+    long long crow[MI], zrow[MI];
+    bool rok[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * (16 * MI) + 16 * i + li;
+        rok[i] = m < g.M;
+        crow[i] = remap_off(rok[i] ? m : 0, g.c_rpb, g.c_bs, g.ldc);
+        zrow[i] = Z ? remap_off(rok[i] ? m : 0, g.z_rpb, g.z_bs, g.ldz) : 0;
+    }
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int col = n0 + wn * 64 + 32 * jj + 16 * (gq & 1) + 8 * (gq >> 1);       // first of the lane's 8 stored columns
+        const bool cok = col < g.N;
+        float bz[2][4];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bz[q][e] = (g.bias && !has_z) ? __uint_as_float(epre[2 * jj + q][e]) : 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            unsigned zl[2] = {0u, 0u}, zh[2] = {0u, 0u}, yl[2], yh[2];
+            if (has_z) {
+                const u32x4 zv = epre[2 * i + jj];
+                auto t0 = __builtin_amdgcn_permlane16_swap(zv[0], zv[2], false, false);
+                auto t1 = __builtin_amdgcn_permlane16_swap(zv[1], zv[3], false, false);
+                zl[0] = t0[0]; zl[1] = t0[1]; zh[0] = t1[0]; zh[1] = t1[1];
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float x[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { x[e] = acc[i][2 * jj + q][e] * g.alpha; x[e] += bz[q][e] + 0.f; }
+                if (has_z) {
+                    const float zf[4] = {__uint_as_float(zl[q] << 16), __uint_as_float(zl[q] & 0xFFFF0000u),
+                                         __uint_as_float(zh[q] << 16), __uint_as_float(zh[q] & 0xFFFF0000u)};
+                    if (zmul) mul_gelu_grad_n(x, zf);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) x[e] += zf[e];
+                    }
+                } else if (Z) { zl[q] = pack_bf16x2(x[0], x[1]); zh[q] = pack_bf16x2(x[2], x[3]); }
+                if (gelu) gelu_n(x);
+                yl[q] = pack_bf16x2(x[0], x[1]); yh[q] = pack_bf16x2(x[2], x[3]);
+            }
+            {
+                auto s0 = __builtin_amdgcn_permlane16_swap(yl[0], yl[1], false, false);
+                auto s1 = __builtin_amdgcn_permlane16_swap(yh[0], yh[1], false, false);
+                const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+                if (rok[i] && cok) *reinterpret_cast<u32x4*>(C + crow[i] + col) = o;
+            }
+            if (Z && !has_z) {
+                auto s0 = __builtin_amdgcn_permlane16_swap(zl[0], zl[1], false, false);
+                auto s1 = __builtin_amdgcn_permlane16_swap(zh[0], zh[1], false, false);
+                const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+                if (rok[i] && cok) *reinterpret_cast<u32x4*>(Z + zrow[i] + col) = o;
+            }
+        }
+    }
+}
+
 // Main loop: NST-deep ring of LDS stages filled by LDS-DMA (global_load_lds, 16 B per lane), NST-1 k-tiles in
 // flight per block; one raw s_barrier and one counted s_waitcnt vmcnt per k-tile; no register staging.
 #ifdef A8_STAMPS
@@ -258,7 +339,9 @@ A8_DEV void stamp(const GemmArgs&, int) {}
 #endif
 
 // A3: the asymmetric ring (A three k-tiles deep, B two) of gemm_a3_kernel below
-template <typename T, bool AKS, bool BKS, int KB, int NST, int NWM, bool A3 = false>
+// DIRECT: 16-bit NT outputs leave through gemm_epilogue_direct (no LDS, no barrier) whenever the problem allows (no f32 / atomic / column-sum
+// / per-row-bias output, not bias AND second input together); a8_set_tuning key 22 = 1 restores the LDS-staged epilogue (A/B runs)
+template <typename T, bool AKS, bool BKS, int KB, int NST, int NWM, bool A3 = false, bool DIRECT = false>
 A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const int kend) {
     typedef StageTile<T, KB> ST;
     typedef KcGeom<KB> G;
@@ -395,7 +478,42 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
     bool use_zpre = false;
     float bpre[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // the lane's 8 bias columns, for the same reason
     bool use_bpre = false;
+    constexpr bool DIRECT_OK = DIRECT && ZPRE && !AKS && !BKS && MI == 2;
+    bool direct = false;                                             // block-uniform (kernel arguments only)
+    if constexpr (DIRECT_OK) {
+        const bool zact = g.act == A8_ACT_MUL_GELU_GRAD || g.act == A8_ACT_ADD;
+        direct = !g.direct_off && !g.out_f32 && !g.atomic && !g.colsum && !g.bias_rows && !(g.bias && zact) && !(zact && g.zout);
+    }
     auto prefetch_epilogue_inputs = [&]() {
+        if constexpr (DIRECT_OK) {
+            if (direct) {               // the direct epilogue's inputs, in ITS layouts, in the registers of zpre (never both kinds)
+                const int li = lane & 15, gq = lane >> 4;
+                if (g.act == A8_ACT_MUL_GELU_GRAD || g.act == A8_ACT_ADD) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) {
+                            const int m = m0 + wm * (16 * MI) + 16 * i + li, n = n0 + wn * 64 + 32 * jj + 16 * (gq & 1) + 8 * (gq >> 1);
+                            zpre[2 * i + jj] = T8z{};
+                            if (m < g.M && n < g.N) {
+                                const long long zr = remap_off(m, g.z_rpb, g.z_bs, g.ldz);
+                                zpre[2 * i + jj] = *reinterpret_cast<const T8z*>(reinterpret_cast<const T*>(g.zin) + zr + n);
+                            }
+                        }
+                } else if (g.bias) {
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int n = n0 + wn * 64 + 32 * jj + 16 * q + 4 * gq;
+                            f32x4 b = {0.f, 0.f, 0.f, 0.f};
+                            if (n < g.N) b = *reinterpret_cast<const f32x4*>(g.bias + n);
+                            zpre[2 * jj + q] = __builtin_bit_cast(T8z, b);
+                        }
+                }
+                return;
+            }
+        }
         if constexpr (ZPRE) {
             use_zpre = g.zin != nullptr && !g.out_f32 && (g.act == A8_ACT_MUL_GELU_GRAD || g.act == A8_ACT_ADD);
             if (use_zpre) {
@@ -540,8 +658,22 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
                     for (int j = 0; j < NJ; ++j) acc[i][j] = MM::mma(fb[ks][j], fa[ks][i], acc[i][j]);
         }
     }
-    // no DMA may still be in flight, and every wave must be done reading the ring, before LDS is reused
     stamp(g, 3);
+    if constexpr (DIRECT_OK) {
+        if (direct) {                   // registers -> global: nothing to wait for but this wave's own MFMAs
+            u32x4 epre[2 * MI];
+#pragma unroll
+            for (int i = 0; i < 2 * MI; ++i) epre[i] = __builtin_bit_cast(u32x4, zpre[i]);
+            gemm_epilogue_direct<MI>(g, acc, w, m0, n0, lane, epre);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the ring's look-ahead pieces past kend: 16 zero bytes per lane)
+#ifdef A8_STAMPS
+            __syncthreads();
+            stamp(g, 4);
+#endif
+            return;
+        }
+    }
+    // no DMA may still be in flight, and every wave must be done reading the ring, before LDS is reused
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     gemm_epilogue<T, MI, NWM, NP>(g, acc, lds, w, m0, n0, lane, zpre, use_zpre, bpre, use_bpre);
@@ -551,17 +683,17 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
 #endif
 }
 
-template <typename T, bool AKS, bool BKS, int KB, int NST, int NWM, bool A3 = false>
+template <typename T, bool AKS, bool BKS, int KB, int NST, int NWM, bool A3 = false, bool DIRECT = false>
 A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
     const int split = bid / (g.tiles_m * g.tiles_n);
     const int kbeg = split * g.kchunk;
-    gemm_core<T, AKS, BKS, KB, NST, NWM, A3>(g, bid - split * (g.tiles_m * g.tiles_n), kbeg, min(g.K, kbeg + g.kchunk));
+    gemm_core<T, AKS, BKS, KB, NST, NWM, A3, DIRECT>(g, bid - split * (g.tiles_m * g.tiles_n), kbeg, min(g.K, kbeg + g.kchunk));
 }
 
 // ---- the default 128 x 128 NT tile with the asymmetric ring (A three deep, B two deep: gemm_body, A3)
 template <typename T>
 __global__ __launch_bounds__(512, 4) void gemm_a3_kernel(const GemmArgs g) {
-    gemm_body<T, false, false, 2, 2, 4, true>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n * g.nsplit));
+    gemm_body<T, false, false, 2, 2, 4, true, true>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n * g.nsplit));
 }
 
 // the asymmetric ring for the weight-gradient layout (both operands K-strided; a8_set_tuning key 15 = 0 restores the symmetric ring):
@@ -604,7 +736,7 @@ __global__ __launch_bounds__(512, 4) void gemm_grouped_a3_kernel(const GemmGroup
     int i = 0;
     while (i + 1 < grp.n && bid >= grp.start[i + 1]) ++i;
     const GemmArgs g = grp.g[i];
-    gemm_body<T, false, false, 2, 2, 4, true>(g, bid - grp.start[i]);
+    gemm_body<T, false, false, 2, 2, 4, true, true>(g, bid - grp.start[i]);
 }
 
 // bf16: 128 B of K per row, 2-deep ring, 8 waves (4 waves/SIMD at 2 blocks/CU);  f32: 64-byte rows, 4-deep ring, 4 waves
@@ -674,6 +806,7 @@ static int build_args(const a8_gemm_desc* d, GemmArgs& g, long long* grid) {
     g.kchunk = kchunk; g.nsplit = nsplit;
     g.act = d->act; g.out_f32 = d->out_f32; g.alpha = d->alpha;
     g.group_m = 8;                                                   // m-tiles per tile-order group (1..16 measured: 8)
+    g.direct_off = g_a8_tuning[22] == 1;                             // (A/B: LDS-staged epilogue in the NT kernels too)
 #ifdef A8_STAMPS
     g.stamps = g_stamps;
 #endif

@@ -352,3 +352,95 @@ def test_gemm_alternative_nt_kernels_match_default(key, height):
     same(*both(conv_dgrad_grouped), "conv dgrad, grouped even + odd")
 
 
+
+
+def test_gemm_direct_epilogue_matches_lds_staged():
+    """The bf16 NT kernels' LDS-free epilogue (gemm_epilogue_direct: accumulators -> two permlane swaps -> 16-byte stores; no barrier)
+    against the LDS-staged one (a8_set_tuning key 22 = 1) on the same main loop: bit-identical outputs over M / N tails, every
+    16-bit epilogue (bias, GELU + pre-activation copy, x gelu'(z), + z, in place), alpha != 1, the conv row remaps and the grouped
+    launch; problems it does not take (f32 output, column sums) must still run."""
+    from audio8_amd import kernels as Kn, _lib as L
+    dev, bf = "cuda", torch.bfloat16
+
+    def both(fn):
+        try:
+            L.check(L.lib().a8_set_tuning(14, 1), "tune")           # every bf16 NT problem on the asymmetric-ring kernel (the one with DIRECT)
+            L.check(L.lib().a8_set_tuning(5, 0), "tune")            # stream kernel off
+            L.check(L.lib().a8_set_tuning(22, 1), "tune")
+            ref = fn()
+            L.check(L.lib().a8_set_tuning(22, 0), "tune")
+            got = fn()
+        finally:
+            for k_, v_ in {14: 1000, 5: 20000, 22: 0}.items():
+                L.check(L.lib().a8_set_tuning(k_, v_), "tune")
+        return ref, got
+
+    def same(pair, what):
+        for r, g_ in zip(*pair):
+            assert torch.equal(r, g_), what
+
+    for (M, N, K) in [(128, 128, 64), (200, 136, 104), (781, 768, 512), (3124, 768, 768), (130, 264, 72), (33, 8, 64), (1000, 2304, 768)]:
+        A, B = _mk((M, K), bf, 1).to(dev), _mk((N, K), bf, 2).to(dev)
+        z = _mk((M, N), bf, 3).to(dev)
+        bias = torch.randn(N, device=dev)
+        same(both(lambda: (Kn.gemm(L.NT, A, B, M, N, K),)), ("plain", M, N, K))
+        same(both(lambda: (Kn.gemm(L.NT, A, B, M, N, K, bias=bias, alpha=0.37),)), ("bias, alpha", M, N, K))
+
+        def gelu_zout():
+            zo = torch.zeros(M, N, device=dev, dtype=bf)
+            return Kn.gemm(L.NT, A, B, M, N, K, bias=bias, act=L.ACT_GELU, zout=zo), zo
+        same(both(gelu_zout), ("bias + gelu + zout", M, N, K))
+        same(both(lambda: (Kn.gemm(L.NT, A, B, M, N, K, act=L.ACT_MUL_GELU_GRAD, zin=z, alpha=0.5),)), ("x gelu'(z)", M, N, K))
+        same(both(lambda: (Kn.gemm(L.NT, A, B, M, N, K, act=L.ACT_ADD, zin=z),)), ("+ z", M, N, K))
+
+        def add_in_place():
+            zc = z.clone()
+            return (Kn.gemm(L.NT, A, B, M, N, K, act=L.ACT_ADD, zin=zc, out=zc),)
+        same(both(add_in_place), ("+ z in place", M, N, K))
+        same(both(lambda: (Kn.gemm(L.NT, A, B, M, N, K, out_dtype=torch.float32),)), ("f32 out (LDS path both times)", M, N, K))
+
+        def with_colsum():
+            cs = torch.zeros(N, device=dev)
+            return Kn.gemm(L.NT, A, B, M, N, K, act=L.ACT_MUL_GELU_GRAD, zin=z, colsum=cs), cs
+        (r_out, r_cs), (g_out, g_cs) = both(with_colsum)
+        assert torch.equal(r_out, g_out), ("column sums (LDS path both times)", M, N, K)
+        torch.testing.assert_close(r_cs, g_cs, rtol=1e-4, atol=1e-2)          # (f32 atomics across blocks: arrival order)
+    # reference values, not only self-consistency: exact on small integers
+    M, N, K = 300, 136, 96
+    A, B, R = _mk((M, K), bf, 31, integer=True), _mk((N, K), bf, 32, integer=True), _mk((M, N), bf, 33, integer=True)
+    out = Kn.gemm(L.NT, A.to(dev), B.to(dev), M, N, K, act=L.ACT_ADD, zin=R.to(dev))
+    want = (A.double() @ B.double().T + R.double()).to(bf)
+    L.check(L.lib().a8_set_tuning(14, 1), "tune")
+    try:
+        out1 = Kn.gemm(L.NT, A.to(dev), B.to(dev), M, N, K, act=L.ACT_ADD, zin=R.to(dev))
+    finally:
+        L.check(L.lib().a8_set_tuning(14, 1000), "tune")
+    assert torch.equal(out.cpu(), want) and torch.equal(out1.cpu(), want)
+    # conv layers as GEMMs: row remaps on A (forward) and on C / z (data gradient, even positions), utterance boundaries inside tiles
+    Bn, Lin, Cc = 3, 1001, 512
+    Lout = (Lin - 3) // 2 + 1
+    x = _mk((Bn * Lin * Cc,), bf, 6).to(dev)
+    Wc = _mk((512, 3 * Cc), bf, 7).to(dev)
+
+    def conv_fwd():
+        zo = torch.empty(Bn * Lout, 512, device=dev, dtype=bf)
+        return Kn.gemm(L.NT, x, Wc, Bn * Lout, 512, 3 * Cc, lda=2 * Cc, a_rpb=Lout, a_bs=Lin * Cc, act=L.ACT_GELU, zout=zo), zo
+    same(both(conv_fwd), "conv forward remap")
+    co, cin, npad = 512, 512, 1
+    dzrows, prow = Lout + 2, 2 * Lout + 1 + 2 * npad
+    dz = _mk((Bn * dzrows, co), bf, 8).to(dev)
+    b_even, b_odd = _mk((cin, 2 * co), bf, 9).to(dev), _mk((cin, co), bf, 11).to(dev)
+    zprev = _mk((Bn * (2 * Lout + 1), cin), bf, 10).to(dev)
+
+    def conv_dgrad_grouped():
+        dx = torch.zeros(Bn * prow, cin, device=dev, dtype=bf)
+        zk = dict(zin=zprev, ldz=2 * cin, z_bs=(2 * Lout + 1) * cin)
+        even = (dz, b_even, Bn * (Lout + 1), cin, 2 * co,
+                dict(out=dx, lda=co, a_rpb=Lout + 1, a_bs=dzrows * co, ldc=2 * cin, c_off=npad * cin, c_rpb=Lout + 1, c_bs=prow * cin,
+                     act=L.ACT_MUL_GELU_GRAD, **dict(zk, z_rpb=Lout + 1)))
+        odd = (dz, b_odd, Bn * Lout, cin, co,
+               dict(out=dx, lda=co, a_off=co, a_rpb=Lout, a_bs=dzrows * co, ldc=2 * cin, c_off=(npad + 1) * cin, c_rpb=Lout, c_bs=prow * cin,
+                    act=L.ACT_MUL_GELU_GRAD, **dict(zk, z_rpb=Lout, z_off=cin)))
+        Kn.gemm_grouped(L.NT, [even, odd])
+        return (dx,)
+    same(both(conv_dgrad_grouped), "conv dgrad, grouped even + odd")
