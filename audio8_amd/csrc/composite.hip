@@ -78,9 +78,14 @@ extern "C" int a8_encoder_layer_bwd(const a8_encoder_layer_bwd_desc* e, void* st
     a8_gemm_desc g = nt_desc(e->dtype, e->df, e->w2_t, e->dz1, M, e->dff, d, nullptr);
     g.act = A8_ACT_MUL_GELU_GRAD; g.zin = e->z1; g.ldz = e->dff; g.colsum = e->db1;
     if (int rc = a8_gemm(&g, stream)) return rc;
+    // a8_set_tuning key 23 = 1 (round-5 experiment, off): dx1 = dz1 W1 + dx1_res in the product's epilogue, so that the LayerNorm backward
+    // below reads ONE gradient tensor instead of two -- one 9.6 MB stream less in a latency-bound kernel, and no gain in the step
+    // (11.713 vs 11.677 ms, profiles/r05_step_ab.txt): the epilogue's second input costs the product what the LayerNorm saves
     g = nt_desc(e->dtype, e->dz1, e->w1_t, e->dx1_ffn, M, d, e->dff, nullptr);
+    const bool fuse_res = g_a8_tuning[23] == 1;
+    if (fuse_res) { g.act = A8_ACT_ADD; g.zin = e->dx1_res; g.ldz = d; }
     if (int rc = a8_gemm(&g, stream)) return rc;
-    if (int rc = a8i_layernorm_bwd(e->dtype, e->dx1_res, e->dx1_ffn, e->ao, e->x, e->g2, e->mean2, e->rstd2, e->dao, drop ? e->dx_res : nullptr,
+    if (int rc = a8i_layernorm_bwd(e->dtype, fuse_res ? e->dx1_ffn : e->dx1_res, fuse_res ? nullptr : e->dx1_ffn, e->ao, e->x, e->g2, e->mean2, e->rstd2, e->dao, drop ? e->dx_res : nullptr,
                                    e->dg2, e->dbe2, e->dbo, M, d, e->p, e->seed1, 3, rng0, stream, e->ln2_partials))
         return rc;
     g = nt_desc(e->dtype, e->dao, e->wo_t, e->dout_o, M, d, d, nullptr);

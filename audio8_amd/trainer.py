@@ -187,9 +187,20 @@ class WeightCache:
 class GradReducer:
     """Bucketed all-reduce of the flat gradient buffer, overlapped with backward."""
 
-    def __init__(self, state: FlatState, bucket_mb: float = 32.0, process_group=None, tail_elems: int = 65536):
+    def __init__(self, state: FlatState, bucket_mb: float = 32.0, process_group=None, tail_elems: int = 65536, payload=None):
         self.state = state
         self.pg = process_group
+        # Payload of the exchange (SURVEY section 5: 380 MB of f32 per step is ~4.3 ms on one xGMI link against an ~11 ms step).
+        # "f32" (default): the flat f32 gradient buffer is all-reduced in place.  "bf16": each bucket is cast into a bf16 staging buffer,
+        # all-reduced there (half the bytes on the links) and cast back over the bucket's f32 slot -- every rank ends with the same SUM,
+        # exact to bf16 rounding of the addends and of the ring's partial sums (relative 2^-8 per element; the optimizer's moments and
+        # the masters stay f32).  Off by default: the reference exchanges f32 (DDP over f32 parameters, audio8/pretrain.py:158).
+        payload = payload or os.environ.get("A8_GRAD_PAYLOAD", "f32")
+        if payload not in ("f32", "bf16"):
+            raise ValueError(f"a8hip GradReducer: payload must be 'f32' or 'bf16', got {payload!r}")
+        self.payload = payload
+        self.stage = None                    # bf16 staging buffer, one element per gradient element (allocated on first use)
+        self.deferred = []                   # (handle, f32 view, bf16 view): cast-backs of a backend that is not stream ordered (gloo)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # A8_FORCE_REDUCER=1: run the whole exchange path (hooks, buckets, side stream, RCCL calls) on a single rank too --
         # a rehearsal of the N > 1 code on a one-GPU box (an all-reduce over one rank leaves the data unchanged)
@@ -341,15 +352,35 @@ class GradReducer:
                 ev.record(st)
                 self.side.wait_event(ev)
             with torch.cuda.stream(self.side):
-                if self.enabled:
+                if self.enabled and self.payload == "bf16":
+                    sv = self._stage_view(bk)
+                    sv.copy_(view)                                            # f32 -> bf16 (round to nearest even)
+                    h = dist.all_reduce(sv, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                    if self.stream_ordered:
+                        h.wait()                                              # the exchange stream (not the host) waits for the collective
+                        view.copy_(sv)                                        # bf16 SUM over ranks back into the f32 slot
+                        h = None
+                    else:
+                        self.deferred.append((h, view, sv))
+                        h = None
+                elif self.enabled:
                     h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
                 if self.norm_sq is not None and self.stream_ordered:      # stream order: behind this bucket's collective
                     K.sumsq_(view, self.norm_sq)
+        elif self.enabled and self.payload == "bf16":    # gloo on CPU (tests)
+            sv = self._stage_view(bk)
+            sv.copy_(view)
+            self.deferred.append((dist.all_reduce(sv, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), view, sv))
         elif self.enabled:                               # gloo on CPU (tests): same bucket schedule, no streams
             h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         if h is not None:
             self.handles.append(h)
         bk["launched"] = True
+
+    def _stage_view(self, bk):
+        if self.stage is None:
+            self.stage = torch.empty(self.state.total, device=self.state.flat_g.device, dtype=torch.bfloat16)
+        return self.stage[bk["lo"]:bk["hi"]]
 
     def begin_pass(self):
         """Before a backward pass whose gradients will be exchanged: every bucket waits for all of its members again."""
@@ -360,6 +391,7 @@ class GradReducer:
             bk["launched"] = False
         self.marked = [False] * len(self.state.params)
         self.handles = []
+        self.deferred = []
         self.next_bucket = 0
 
     def begin_step(self):
@@ -404,6 +436,14 @@ class GradReducer:
         for h in self.handles:
             h.wait()
         self.handles = []
+        for h, view, sv in self.deferred:                 # bf16 payload over a backend that completes on its own threads
+            h.wait()
+            if self.on_gpu:
+                with torch.cuda.stream(self.side):
+                    view.copy_(sv)
+            else:
+                view.copy_(sv)
+        self.deferred = []
         if self.on_gpu:
             torch.cuda.current_stream().wait_stream(self.side)
             if self.norm_sq is not None and not self.stream_ordered:
@@ -431,9 +471,9 @@ class Stepper:
     left untouched and keep their own step count, as torch's AdamW does for `p.grad is None`."""
 
     def __init__(self, model, lr=2.0e-4, weight_decay=1.0e-2, betas=(0.9, 0.999), eps=1e-8, clip=1.0, bucket_mb=32.0, lr_function=None,
-                 wgrad_side_stream=True, process_group=None, global_step=0, sync_touched=None):
+                 wgrad_side_stream=True, process_group=None, global_step=0, sync_touched=None, grad_payload=None):
         self.state = FlatState(model)
-        self.reducer = GradReducer(self.state, bucket_mb, process_group)
+        self.reducer = GradReducer(self.state, bucket_mb, process_group, payload=grad_payload)     # grad_payload: "f32" (default) / "bf16"
         if self.reducer.enabled:                         # C1 of SURVEY 2.2: rank 0's parameters everywhere -- BEFORE anything
             dist.broadcast(self.state.flat_p, src=0, group=process_group)      # is derived from them (the bf16 working copies below)
         self.lr, self.wd, self.betas, self.eps, self.clip = lr, weight_decay, betas, eps, clip
@@ -629,6 +669,21 @@ class Stepper:
             self.wcache.refresh()
         self.reducer.prune_hooks()
         return counts
+
+
+def pin_host_cores(n=4, rank=None, world=None):
+    """Confine this process's launching thread (and every thread it starts from now on) to `n` cores of its own slice of the host and
+    give torch as many intra-op threads.  One process per GPU issues ~330 launches per 11 ms step from ONE Python thread; left unpinned
+    with an OpenMP thread per visible core, that thread is measurably slower (host 9.5 vs 7.0 ms per step, step 11.9 vs 11.75 ms on a
+    16-core share; bench.py does the same before importing torch).  Call before the first GPU work; returns the cores taken."""
+    world = max(1, int(os.environ.get("WORLD_SIZE", "1")) if world is None else world)
+    rank = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0"))) if rank is None else rank
+    cpus = sorted(os.sched_getaffinity(0))
+    per = max(1, len(cpus) // world)
+    mine = cpus[(rank % world) * per:(rank % world) * per + per][:n] or cpus[:n]
+    os.sched_setaffinity(0, mine)
+    torch.set_num_threads(len(mine))
+    return mine
 
 
 def init_distributed_from_env():

@@ -19,6 +19,26 @@ import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this driver (set before HIP starts)
 
+# Host placement, decided BEFORE torch is imported and before any GPU call (every thread the process starts later inherits it):
+# each rank launches from its own small slice of the host's cores -- rank r of W takes --host-cores N (default 4) cores from the r-th
+# of W equal slices of the allowed CPU list -- with as many OpenMP threads.  Unpinned, with one OpenMP thread per visible core, the
+# launching thread of the SAME code is slower (host 9.5 vs 7.0 ms per step) and the step with it (11.86-11.92 vs 11.73-11.75 ms;
+# 16 cores / 16 threads: 12.3 ms) -- profiles/r05_host_affinity.txt.  --host-cores 0 leaves the process unpinned; --host-cores 1 / 2 is
+# the host-side stress of VERDICT r4 item 8b (the step must stay GPU-bound: host_ms_per_step < ms_per_step).
+ALL_CPUS = sorted(os.sched_getaffinity(0))
+HOST_CORES = 4
+if "--host-cores" in sys.argv:
+    HOST_CORES = int(sys.argv[sys.argv.index("--host-cores") + 1])
+if "--dry-run" in sys.argv:
+    HOST_CORES = 0
+if HOST_CORES > 0:
+    _w, _r = max(1, int(os.environ.get("WORLD_SIZE", "1"))), int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
+    _per = max(1, len(ALL_CPUS) // _w)
+    _mine = ALL_CPUS[(_r % _w) * _per:(_r % _w) * _per + _per][:HOST_CORES] or ALL_CPUS[:HOST_CORES]
+    os.sched_setaffinity(0, _mine)
+    os.environ["OMP_NUM_THREADS"] = str(len(_mine))
+    os.environ["MKL_NUM_THREADS"] = str(len(_mine))
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -40,7 +60,12 @@ def cpu_baseline(args):
     sequence on this host's cores, on a bounded sample of the workload."""
     from oracle import ref_cpu as R
     B, L = args.cpu_batch, args.samples
-    torch.set_num_threads(min(args.cpu_threads, os.cpu_count() or 1))       # the GPU box's CPU share for one GPU is 16
+    for tid in os.listdir("/proc/self/task"):                                # the CPU leg may use the whole CPU share again: the GPU legs were pinned,
+        try:                                                                 # and worker threads started meanwhile inherited the pinned mask
+            os.sched_setaffinity(int(tid), ALL_CPUS)
+        except OSError:
+            pass
+    torch.set_num_threads(min(args.cpu_threads, len(ALL_CPUS)))              # the GPU box's CPU share for one GPU is 16
     torch.manual_seed(0)
     np.random.seed(0)
     sd = {k: v.clone().requires_grad_(True) for k, v in R.init_state_dict(seed=0).items()}
@@ -143,6 +168,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--bucket-mb", type=float, default=32.0)
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous rehearsal on CPU ranks (gloo): no GPU work, no metric")
+    ap.add_argument("--host-cores", type=int, default=4, help="cores (and OpenMP threads) this rank launches from, taken from its slice of the host; 0 = unpinned")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
@@ -370,6 +396,7 @@ def main():
                           "global_batch": world * args.batch, "samples_per_clip": args.samples, "parallelism": "dp%d" % world,
                           "last_loss": round(float(lv), 5),
                           "host_ms_per_step": {k_: round(v_, 3) for k_, v_ in host_ms.items()},     # max over ranks: enqueue time per phase ("wait" = loss.item())
+                          "host_cores": HOST_CORES if HOST_CORES > 0 else len(ALL_CPUS),      # cores the GPU legs' launching process was confined to
                           "ms_per_step_with_h2d": round(ms_h2d, 3) if ms_h2d is not None else None,
                           "h2d_note": "same step with the batch handed over as host arrays every step (audio8/pretrain.py:172-177 times "
                                       "next(train_itr) + batch.to(device) too): pinned double-buffered on-ramp, %d steps" % args.h2d_steps},

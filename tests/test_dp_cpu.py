@@ -65,6 +65,59 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _bf16_payload_worker(rank, world, port, q):
+    """payload="bf16": every bucket travels as bf16 (half the bytes on the links) and lands back in the f32 flat buffer.  Every rank must
+    end with the SAME values (bit for bit: they all cast back the same reduced bf16 numbers), equal to the bf16-rounded sum of the
+    bf16-rounded per-rank gradients, hence within 2^-6 of the f32 exchange relative to the larger addend (three roundings of relative
+    2^-8 each, the sum at most twice the larger addend); untouched buckets stay zero."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from audio8_amd.trainer import FlatState, GradReducer
+        torch.manual_seed(0)
+        model = torch.nn.Sequential(torch.nn.Linear(40, 300), torch.nn.GELU(), torch.nn.Linear(300, 300), torch.nn.GELU(), torch.nn.Linear(300, 7))
+        model.register_parameter("unused", torch.nn.Parameter(torch.zeros(1000)))
+        st = FlatState(model)
+        red = GradReducer(st, bucket_mb=0.2, tail_elems=2000, payload="bf16")
+        assert red.payload == "bf16" and len(red.buckets) >= 3
+        ok = True
+        for step in range(2):
+            st.zero_grad()
+            red.begin_step()
+            x = torch.randn(16, 40, generator=torch.Generator().manual_seed(100 * step + rank))
+            model(x).square().sum().backward()
+            local = st.flat_g.clone()
+            red.finish()
+            both = [torch.empty_like(local) for _ in range(world)]
+            dist.all_gather(both, local)                                   # the per-rank f32 gradients, for the reference
+            exact = both[0] + both[1]
+            want = (both[0].bfloat16() + both[1].bfloat16()).float()       # bf16 addends, one bf16-rounded sum (world 2: a single add)
+            ok = ok and torch.equal(st.flat_g, want)
+            scale = torch.maximum(both[0].abs(), both[1].abs())
+            ok = ok and bool(((st.flat_g - exact).abs() <= 2.0 ** -6 * scale + 1e-30).all())
+            same = [torch.empty_like(local) for _ in range(world)]
+            dist.all_gather(same, st.flat_g)
+            ok = ok and torch.equal(same[0], same[1])                      # replicas cannot drift: identical bits on every rank
+            unused = [i for i, p in enumerate(st.params) if p is model.unused][0]
+            ok = ok and bool((st.flat_g[st.offsets[unused]:st.offsets[unused] + 1000] == 0).all())
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bf16_gradient_payload_gloo_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bf16_payload_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
+
+
 def test_bucketed_reducer_gloo_world2():
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")

@@ -139,14 +139,17 @@ counts = st.step(batch_size=torch.tensor(2 * sizes[rank], device=dev), num_token
 torch.cuda.synchronize()
 out["counts"] = counts.tolist()
 out["want_batch"] = nb
-worst, worst_frozen = 0.0, 0.0
+worst, worst_frozen, dsum, dn = 0.0, 0.0, 0.0, 0
 for (k, p), q, b in zip(mdl.named_parameters(), ref.parameters(), before):
     d = float((p.detach() - q.detach()).abs().max())
     if q.grad is None:
         worst_frozen = max(worst_frozen, float((p.detach() - b).abs().max()))
     else:
         worst = max(worst, d)
+        dsum += float((p.detach() - q.detach()).abs().sum())
+        dn += p.numel()
 out["max_param_diff_vs_reference"] = worst
+out["mean_param_diff_vs_reference"] = dsum / max(dn, 1)
 out["max_change_of_gradless_params"] = worst_frozen
 st.close()
 del st, mdl
@@ -214,12 +217,18 @@ sys.stdout.flush()
 '''
 
 
-def test_two_ranks_on_one_gpu_broadcast_order_and_train_semantics(tmp_path):
+@pytest.mark.parametrize("payload", ["f32", "bf16"])
+def test_two_ranks_on_one_gpu_broadcast_order_and_train_semantics(tmp_path, payload):
+    """payload = "bf16": the same protocol with the gradient buckets exchanged as bf16 (GradReducer(payload=), A8_GRAD_PAYLOAD).  The first
+    AdamW step moves every element by lr * g / (|g| + eps) ~ +-lr, so an element whose gradient is rounding noise around zero may land
+    2 lr away from the f32 reference (its sign is not information); what is bounded is the hard limit 2 lr on any element, a mean
+    deviation below 5 % of lr over all parameters (measured: 2 %), and bit-identical replicas."""
     script = tmp_path / "dp_ranks.py"
     script.write_text(_RANK_SCRIPT)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), str(script)]
-    r = subprocess.run(cmd, env=_clean_env(A8_REPO=ROOT), capture_output=True, text=True, timeout=900)
+    tol = 2e-5 if payload == "f32" else 2.05e-3
+    r = subprocess.run(cmd, env=_clean_env(A8_REPO=ROOT, A8_GRAD_PAYLOAD=payload), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     import re
     outs = {int(m.group(1)): json.loads(m.group(2)) for m in re.finditer(r"RANK(\d) (\{[^\n]*?\})(?=\s|RANK|$)", r.stdout)}
@@ -229,9 +238,10 @@ def test_two_ranks_on_one_gpu_broadcast_order_and_train_semantics(tmp_path):
         assert o["cached_matrices"] > 10 and o["cache_vs_cast_master_max_abs"] == 0.0, (rank, o)      # ... and the bf16 copies are THEIR casts
         assert o["collectives_inside_no_sync"] == 0
         assert o["counts"][0] == o["want_batch"] == 2 * (2 + 3) and o["counts"][1] > 0
-        assert o["max_param_diff_vs_reference"] < 2e-5, (rank, o)           # one lr = 1e-3 AdamW step: 2 % of the step size
+        assert o["max_param_diff_vs_reference"] < tol, (rank, o)            # one lr = 1e-3 AdamW step: 2 % of the step size (f32 payload)
+        assert o["mean_param_diff_vs_reference"] < (2e-6 if payload == "f32" else 5e-5), (rank, o)      # bf16: 2.0e-5 measured = 2 % of lr
         assert o["max_change_of_gradless_params"] == 0.0, (rank, o)         # frozen feature extractor: untouched (no decay either)
-        assert o["driver_order_max_param_diff_vs_reference"] < 2e-5 and o["driver_order_global_step"] == 1, (rank, o)
+        assert o["driver_order_max_param_diff_vs_reference"] < tol and o["driver_order_global_step"] == 1, (rank, o)
         assert o["sync_touched"] and o["layerdrop_params_identical"] and o["layerdrop_finite"], (rank, o)
         assert any(c > 0 for c in o["layerdrop_local_drop_counts"]), (rank, o)          # this rank did drop layers
     assert outs[0]["counts"] == outs[1]["counts"]
