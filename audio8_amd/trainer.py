@@ -437,11 +437,12 @@ class GradReducer:
             h.wait()
         self.handles = []
         for h, view, sv in self.deferred:                 # bf16 payload over a backend that completes on its own threads
-            h.wait()
             if self.on_gpu:
-                with torch.cuda.stream(self.side):
+                with torch.cuda.stream(self.side):        # wait() orders the CURRENT stream behind the backend's copy-back of the result:
+                    h.wait()                              # it must be the stream that casts it into the f32 slot
                     view.copy_(sv)
             else:
+                h.wait()
                 view.copy_(sv)
         self.deferred = []
         if self.on_gpu:
