@@ -444,3 +444,4 @@ def test_gemm_direct_epilogue_matches_lds_staged():
         Kn.gemm_grouped(L.NT, [even, odd])
         return (dx,)
     same(both(conv_dgrad_grouped), "conv dgrad, grouped even + odd")
+
