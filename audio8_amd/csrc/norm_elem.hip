@@ -278,7 +278,27 @@ __global__ __launch_bounds__(256) void gelu_bwd_bias_kernel(const T* __restrict_
     const int col = blockIdx.x * 512 + lane * 8;
     float ab[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (col < cols) {
-        for (int row = blockIdx.y * 4 + wv; row < rows; row += gridDim.y * 4) {
+        // four rows' loads in flight per wave (round 5: one dependent 16-byte load per iteration ran the pure column-sum use -- the q/k/v bias
+        // gradient over dqkv -- at 1.25 TB/s, waves waiting 86 % of their cycles); sums stay in row order
+        const int stride = gridDim.y * 4;
+        int row = blockIdx.y * 4 + wv;
+        for (; row + 3 * stride < rows; row += 4 * stride) {
+            float g[4][8], zz[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) load8(dy + ((long long)(row + u * stride) * cols + col), g[u]);
+            if (z) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) load8(z + ((long long)(row + u * stride) * cols + col), zz[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (z) mul_gelu_grad_n(g[u], zz[u]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ab[i] += g[u][i];
+                if (dz) store8(dz + ((long long)(row + u * stride) * cols + col), g[u]);
+            }
+        }
+        for (; row < rows; row += stride) {
             const long long off = (long long)row * cols + col;
             float g[8];
             load8(dy + off, g);

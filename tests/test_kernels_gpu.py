@@ -336,6 +336,43 @@ def test_attention_fwd_bwd(dtype, T, use_mask, attn_geometry):
     close(dbias, dbias0 + ref_b, tolb, "q/k/v bias gradients from the backward kernels")
 
 
+def test_attention_bf16_tolerance_detects_a_wrong_scale():
+    """What the 16-bit bounds of test_attention_fwd_bwd are worth: the same bf16 kernels run with the softmax scale 10 % off (the kind of
+    error a wrong 1 / sqrt(d_k) in one layer would be) must FAIL those bounds in the output and in every gradient, by a clear margin
+    over the error the right scale leaves.  The end-to-end bf16
+    band (test_fullsize_gpu.py) is wide by design -- cancellation over 12 layers; THIS is where a wrong constant in a bf16-only kernel
+    (attn_fwd32, the flagged backward instantiations) is caught."""
+    from audio8_amd import kernels as K
+    B, H, T = 2, 3, 200
+    d = H * 64
+    dtype = torch.bfloat16
+    qkv = (rnd((B * T, 3 * d), 1) * 2.0).to(dtype)                     # |scores| ~ 2: a softmax that is neither flat nor one-hot
+    dout = rnd((B * T, d), 2).to(dtype)
+    f = qkv.float().view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    q, k, v = (f[i].clone().requires_grad_(True) for i in range(3))
+    scale = 1 / 8.0
+    oref = _attn_ref(q, k, v, None, scale)
+    oref.backward(dout.float().view(B, T, H, 64).permute(0, 2, 1, 3))
+    g = qkv.cuda()
+
+    def run(s_):
+        o, lse = K.attn_fwd(g[:, :d], g[:, d:2 * d], g[:, 2 * d:], B, T, H, 3 * d, s_, None)
+        dq, dk, dv, _ = K.attn_bwd(g[:, :d], g[:, d:2 * d], g[:, 2 * d:], o, dout.cuda(), lse, B, T, H, 3 * d, s_, None)
+        return [(o.view(B, T, H, 64), oref.permute(0, 2, 1, 3), 2e-2), (dq.reshape(B, T, H, 64), q.grad.permute(0, 2, 1, 3), 3e-2),
+                (dk.reshape(B, T, H, 64), k.grad.permute(0, 2, 1, 3), 3e-2), (dv.reshape(B, T, H, 64), v.grad.permute(0, 2, 1, 3), 3e-2)]
+    def worst(got, ref):                                                 # close()'s own measure: max |got - ref| / (tol-free) scale
+        got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+        return float(((got - ref).abs() / (ref.abs() + max(1.0, float(ref.abs().max())))).max())
+    right = run(scale)
+    for got, ref, tol in right:                                          # the right scale passes ...
+        close(got, ref, tol)
+    for i, ((got, ref, tol), (g0, r0, _)) in enumerate(zip(run(scale * 1.10), right)):      # ... 10 % off fails every one of the four checks
+        print("check %d: error with the right scale %.2e, 10 %% off %.2e (bound %.0e)" % (i, worst(g0, r0), worst(got, ref), tol))
+        with pytest.raises(AssertionError):
+            close(got, ref, tol, "check %d must notice a 10 %% scale error" % i)
+        assert worst(got, ref) > 3 * worst(g0, r0), i
+
+
 def test_attention_dropout_mask_consistency():
     """Extract the kernel's keep-mask (q = k = 0 -> uniform P; V = I), then check fwd/bwd against a
     reference that applies exactly that mask."""

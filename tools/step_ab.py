@@ -6,6 +6,11 @@ import os
 import sys
 import time
 
+# the launching thread on 4 cores with 4 OpenMP threads, as bench.py places it (profiles/r05_host_affinity.txt: unpinned, the host side
+# jitters by several tenths of a millisecond per step -- more than most effects this tool is used to separate)
+os.sched_setaffinity(0, sorted(os.sched_getaffinity(0))[:4])
+os.environ.setdefault("OMP_NUM_THREADS", "4")
+
 import numpy as np
 import torch
 
