@@ -5,6 +5,9 @@ import os
 import sys
 import time
 
+os.sched_setaffinity(0, sorted(os.sched_getaffinity(0))[:4])       # launching thread placed as bench.py places it (profiles/r05_host_affinity.txt)
+os.environ.setdefault("OMP_NUM_THREADS", "4")
+
 import numpy as np
 import torch
 

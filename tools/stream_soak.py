@@ -55,9 +55,25 @@ for i in range(it):
         return (K.gemm(L.NT, A, B, M, N, K_, **kw),)
 
     tune(5, 0)
+    tune(14, 1)                                        # every problem on the asymmetric-ring kernel ...
+    tune(22, 1)                                        # ... with the LDS-staged epilogue: the reference
     ref = run()
     torch.cuda.synchronize()
+    # round 5: the same kernel with the LDS-free epilogue (no barrier between the main loop and the stores) under the same uneven load
+    tune(22, 0)
+    with torch.cuda.stream(side):
+        for _ in range(rng.randint(0, 2)):
+            noise_b.copy_(noise_a)
+            K.gemm(L.NT, na, nb, 3000, 768, 768)
+    got_d = [run() for _ in range(2)]
+    torch.cuda.synchronize()
+    for gg in got_d:
+        for r, o in zip(ref, gg):
+            if not torch.equal(r, o):
+                bad += 1
+                print("MISMATCH (direct epilogue) it %d M %d N %d K %d %s" % (i, M, N, K_, mode), flush=True)
     tune(5, 1)
+    tune(19, 1)                                        # plain (not row-remapped) problems through the stream kernel too
     tune(7, bm)
     with torch.cuda.stream(side):                      # uneven load beside the kernel under test
         for _ in range(rng.randint(0, 3)):
@@ -76,5 +92,7 @@ for i in range(it):
         print("it %d ok so far (bad %d)" % (i, bad), flush=True)
 tune(5, 20000)
 tune(7, 0)
+tune(19, 0)
+tune(14, 1000)
 print("stream soak: %d iterations, %d mismatching outputs" % (it, bad))
 sys.exit(1 if bad else 0)
