@@ -5,6 +5,7 @@ O(#params)-sized weight plumbing (conv-weight re-layout views, bias concatenatio
 flat-state layout) and the scalar composition of the loss.
 """
 import math
+import time
 
 import numpy as np
 import torch
@@ -73,6 +74,9 @@ class _NoPhase:
 
 
 _NO_PHASE = _NoPhase()
+
+
+HOST_DELAY_US = 0
 
 
 def phase(name):
@@ -834,6 +838,10 @@ class EncoderLayerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dx2):
+        if HOST_DELAY_US:                 # developer probe (tools/step_ab.py hostdelay=<us>): is the launching thread on the critical path?
+            t_end = time.perf_counter() + HOST_DELAY_US * 1e-6
+            while time.perf_counter() < t_end:
+                pass
         with phase("enc_bwd"):
             return EncoderLayerFn._backward(ctx, dx2)
 

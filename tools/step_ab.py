@@ -53,6 +53,7 @@ def apply(d):
     ops.HALF_BATCH_STREAMS = bool(d.get("half", 1))
     ops.HALF_BATCH_BWD = bool(d.get("halfbwd", 1))
     ops.LN_PARTIALS = bool(d.get("lnp", 1))
+    ops.HOST_DELAY_US = d.get("hostdelay", 0)
     ops.SPLITK_SLOTS = d.get("skslots", 512)
     ops.SPLITK_MIN_ROWS = d.get("skrows", 800)
 
