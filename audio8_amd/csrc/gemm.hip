@@ -341,7 +341,10 @@ A8_DEV void stamp(const GemmArgs&, int) {}
 // A3: the asymmetric ring (A three k-tiles deep, B two) of gemm_a3_kernel below
 // DIRECT: 16-bit NT outputs leave through gemm_epilogue_direct (no LDS, no barrier) whenever the problem allows (no f32 / atomic / column-sum
 // / per-row-bias output, not bias AND second input together); a8_set_tuning key 22 = 1 restores the LDS-staged epilogue (A/B runs)
-template <typename T, bool AKS, bool BKS, int KB, int NST, int NWM, bool A3 = false, bool DIRECT = false>
+// KFAST (NT, asymmetric ring; the host launches it when every k range is whole k-tiles): a piece's source is a fixed per-lane pointer plus a
+// block-uniform k offset -- one 64-bit add per piece per k-tile instead of a product, two compares and two selects; M / N tails by
+// clamped rows (valid bytes; the surplus rows / columns of a tile are never stored or summed) instead of the zero-fill predicate.
+template <typename T, bool AKS, bool BKS, int KB, int NST, int NWM, bool A3 = false, bool DIRECT = false, bool KFAST = false>
 A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const int kend) {
     typedef StageTile<T, KB> ST;
     typedef KcGeom<KB> G;
@@ -547,7 +550,24 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
         // ahead into a 3-deep ring, the B operand (weights, L2-resident) one k-tile ahead into a 2-deep ring: 3 x 16 + 2 x 16 = 80 KB,
         // still two blocks per CU.  Per iteration a wave issues its B pieces first and its A pieces last, so "all but the PPA
         // youngest" (vmcnt counts in issue order) is exactly: A(kb) and B(kb) have landed, A(kb+1) may still be in flight.
+        static_assert(!KFAST || (!AKS && !BKS), "KFAST: K-contiguous operands");
+        const char* a_src[PPA];
+        const char* b_src[PPB];
+        if constexpr (KFAST) {
+#pragma unroll
+            for (int j = 0; j < PPW; ++j) {
+                const int rl = G::RPP * (w + NW * j) + lane / G::SPR;
+                a_src[j] = g.A.p + (outer_off(g.A, min(m0 + rl, g.M - 1)) + kbeg + a_k[j]) * SZ;
+                b_src[j] = g.B.p + (outer_off(g.B, min(n0 + rl, g.N - 1)) + kbeg + b_k[j]) * SZ;
+            }
+        }
         auto issue_a = [&](int kb, char* ta) {
+            if constexpr (KFAST) {
+                const long long koff = (long long)min(kb, nkb - 1) * (BK * SZ);      // (look-ahead past the last k-tile re-reads it: valid, unused)
+#pragma unroll
+                for (int j = 0; j < PPA; ++j) glds16(a_src[j] + koff, ta + (w + NW * j) * 1024);
+                return;
+            }
             const int k0 = kbeg + kb * BK;
 #pragma unroll
             for (int j = 0; j < PPA; ++j) {
@@ -565,6 +585,12 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
             }
         };
         auto issue_b = [&](int kb, char* tb) {
+            if constexpr (KFAST) {
+                const long long koff = (long long)min(kb, nkb - 1) * (BK * SZ);
+#pragma unroll
+                for (int j = 0; j < PPB; ++j) glds16(b_src[j] + koff, tb + (w + NW * j) * 1024);
+                return;
+            }
             const int k0 = kbeg + kb * BK;
 #pragma unroll
             for (int j = 0; j < PPB; ++j) {
@@ -683,17 +709,17 @@ A8_DEV void gemm_core(const GemmArgs& g, const int tile, const int kbeg, const i
 #endif
 }
 
-template <typename T, bool AKS, bool BKS, int KB, int NST, int NWM, bool A3 = false, bool DIRECT = false>
+template <typename T, bool AKS, bool BKS, int KB, int NST, int NWM, bool A3 = false, bool DIRECT = false, bool KFAST = false>
 A8_DEV void gemm_body(const GemmArgs& g, const int bid) {
     const int split = bid / (g.tiles_m * g.tiles_n);
     const int kbeg = split * g.kchunk;
-    gemm_core<T, AKS, BKS, KB, NST, NWM, A3, DIRECT>(g, bid - split * (g.tiles_m * g.tiles_n), kbeg, min(g.K, kbeg + g.kchunk));
+    gemm_core<T, AKS, BKS, KB, NST, NWM, A3, DIRECT, KFAST>(g, bid - split * (g.tiles_m * g.tiles_n), kbeg, min(g.K, kbeg + g.kchunk));
 }
 
 // ---- the default 128 x 128 NT tile with the asymmetric ring (A three deep, B two deep: gemm_body, A3)
-template <typename T>
+template <typename T, bool KFAST = false>
 __global__ __launch_bounds__(512, 4) void gemm_a3_kernel(const GemmArgs g) {
-    gemm_body<T, false, false, 2, 2, 4, true, true>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n * g.nsplit));
+    gemm_body<T, false, false, 2, 2, 4, true, true, KFAST>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n * g.nsplit));
 }
 
 // the asymmetric ring for the weight-gradient layout (both operands K-strided; a8_set_tuning key 15 = 0 restores the symmetric ring):
@@ -730,13 +756,13 @@ __global__ __launch_bounds__(512, 4) void gemm_grouped_a3_tn_kernel(const GemmGr
 }
 
 // the grouped launch with the asymmetric ring of gemm_a3_kernel (bf16 NT; the conv data-gradient halves)
-template <typename T>
+template <typename T, bool KFAST = false>
 __global__ __launch_bounds__(512, 4) void gemm_grouped_a3_kernel(const GemmGroup grp) {
     const int bid = xcd_remap(blockIdx.x, grp.start[grp.n]);
     int i = 0;
     while (i + 1 < grp.n && bid >= grp.start[i + 1]) ++i;
     const GemmArgs g = grp.g[i];
-    gemm_body<T, false, false, 2, 2, 4, true, true>(g, bid - grp.start[i]);
+    gemm_body<T, false, false, 2, 2, 4, true, true, KFAST>(g, bid - grp.start[i]);
 }
 
 // bf16: 128 B of K per row, 2-deep ring, 8 waves (4 waves/SIMD at 2 blocks/CU);  f32: 64-byte rows, 4-deep ring, 4 waves
@@ -829,7 +855,9 @@ extern "C" int a8_gemm(const a8_gemm_desc* d, void* stream) {
     if (const int r = a8i_gemm_stream_try(d, stream)) return r > 0 ? A8_OK : -r;
     // Asymmetric ring (a8_set_tuning key 14: 0 = never, otherwise the minimum M; 1 = every bf16 NT problem)
     if (d->dtype == A8_BF16 && d->layout == A8_GEMM_NT && g_a8_tuning[14] > 0 && d->M >= g_a8_tuning[14]) {
-        hipLaunchKernelGGL(gemm_a3_kernel<bf16>, dim3((int)grid), dim3(512), 0, s, g);
+        // whole k-tiles in every split and M, N >= 1: the lean-addressing instantiation (a8_set_tuning key 25 = 1: never)
+        if (g.K % 64 == 0 && g.kchunk % 64 == 0 && d->M >= 1 && g_a8_tuning[25] == 0) hipLaunchKernelGGL((gemm_a3_kernel<bf16, true>), dim3((int)grid), dim3(512), 0, s, g);
+        else hipLaunchKernelGGL((gemm_a3_kernel<bf16, false>), dim3((int)grid), dim3(512), 0, s, g);
         return a8_check_launch("a8_gemm");
     }
     if (d->dtype == A8_BF16 && d->layout == A8_GEMM_TN && g_a8_tuning[15] > 0) {
@@ -875,7 +903,10 @@ extern "C" int a8_gemm_grouped(const a8_gemm_desc* descs, int n, void* stream) {
         bool a3 = descs[0].layout == A8_GEMM_NT && g_a8_tuning[14] > 0;
         for (int i = 0; i < n && a3; ++i) a3 = descs[i].M == 0 || descs[i].M >= g_a8_tuning[14];
         if (a3) {
-            hipLaunchKernelGGL(gemm_grouped_a3_kernel<bf16>, dim3((int)total), dim3(512), 0, s, grp);
+            bool kfast = g_a8_tuning[25] == 0;
+            for (int i = 0; i < grp.n && kfast; ++i) kfast = grp.g[i].K % 64 == 0 && grp.g[i].kchunk % 64 == 0;
+            if (kfast) hipLaunchKernelGGL((gemm_grouped_a3_kernel<bf16, true>), dim3((int)total), dim3(512), 0, s, grp);
+            else hipLaunchKernelGGL((gemm_grouped_a3_kernel<bf16, false>), dim3((int)total), dim3(512), 0, s, grp);
             return a8_check_launch("a8_gemm_grouped");
         }
         if (descs[0].layout == A8_GEMM_TN && g_a8_tuning[15] > 0) {

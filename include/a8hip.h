@@ -72,7 +72,8 @@ int a8_gemm_grouped(const a8_gemm_desc* descs, int n, void* stream);
  * most of their blocks sit alone on a CU, where the deeper A ring hides what a co-resident block otherwise would); 15 the same ring for
  * bf16 TN products (the weight gradients; default 1 = on); 19 = 1: the stream kernel also takes plain (not row-remapped) problems
  * (default 0: only the conv layers' remapped products -- a persistent block owns its CU, which costs the encoder's projections their
- * co-running streams). */
+ * co-running streams); 20 / 21 AdamW grid / cache policy; 22 = 1: LDS-staged epilogue in the 128 x 128 NT kernels; 23 = 1: residual add in the
+ * FFN data gradient's epilogue; 25 = 1: predicate-form operand addressing in the 128 x 128 NT kernels. */
 int a8_set_tuning(int key, int value);
 
 /* ---- per-step weight preparation (the f32 -> compute-dtype casts the reference's autocast-free f32 path never needs;

@@ -282,8 +282,8 @@ def test_full_ctc_finetune_step_cfg5():
 def test_cfg2_sequence_length_bf16_against_oracle():
     """The benchmark dtype at the benchmark depth AND sequence length against the oracle: wav2vec2-base (12 layers), 2 x 250 000 samples
     (T = 781 frames, 64-key attention tiles with a ragged last tile, conv layer 1 at 25 k rows per utterance); the oracle runs this in a
-    few seconds on the host.  Stated bf16 tolerance: loss within 2e-3, the whole gradient within 25 % (relative L2) of the oracle's and
-    cosine > 0.98; per-parameter detail is test_model_gpu.py::test_pretrain_step_parity_bf16_full_depth_base."""
+    few seconds on the host.  Stated bf16 tolerance: loss within 2e-3, the whole gradient within 12 % (relative L2) of the oracle's and
+    cosine > 0.995 (a wrong constant in a bf16-only kernel is caught at kernel level: test_attention_bf16_tolerance_detects_a_wrong_scale); per-parameter detail is test_model_gpu.py::test_pretrain_step_parity_bf16_full_depth_base."""
     from test_model_gpu import _pretrain_pair
     from audio8_amd import ops
     old = ops.compute_dtype()
@@ -296,7 +296,7 @@ def test_cfg2_sequence_length_bf16_against_oracle():
         gcos = float(torch.nn.functional.cosine_similarity(allg, allr, dim=0))
         grel = float((allg - allr).norm() / allr.norm())
         print("bf16, 12 layers, T = 781: loss %.5f vs %.5f, global cosine %.4f, global relative error %.3f" % (loss.item(), loss_ref.item(), gcos, grel))
-        assert gcos > 0.98 and grel < 0.25, (gcos, grel)
+        assert gcos > 0.995 and grel < 0.12, (gcos, grel)          # measured 0.9982 / 0.069 (rounds 3-5); the band was 0.98 / 0.25 until round 5
     finally:
         ops.set_compute_dtype(old)
 
