@@ -241,3 +241,27 @@ def test_native_negative_sampler_is_numpy_bit_for_bit():
     b = W.Sampler(4).indices_numpy(2, 50)
     g2 = np.random.normal()
     assert np.array_equal(a, b) and g1 == g2
+
+
+def test_pin_host_cores_takes_the_ranks_own_slice():
+    """trainer.pin_host_cores(n, rank, world): rank r of W gets n cores from the r-th of W equal slices of the allowed CPU list (what bench.py
+    does before importing torch); different ranks never share a core when the slices are at least n wide."""
+    import torch
+    from audio8_amd.trainer import pin_host_cores
+    before, threads = sorted(os.sched_getaffinity(0)), torch.get_num_threads()
+    try:
+        if len(before) < 2:
+            pytest.skip("needs two CPUs")
+        world = 2
+        per = len(before) // world
+        n = min(2, per)
+        got = []
+        for r in range(world):                               # (one call per process in real use: the slice is taken from the CURRENT mask)
+            os.sched_setaffinity(0, before)
+            got.append(pin_host_cores(n, rank=r, world=world))
+            assert sorted(os.sched_getaffinity(0)) == got[-1] and torch.get_num_threads() == n
+        assert all(len(g) == n for g in got) and not (set(got[0]) & set(got[1]))
+        assert got[0] == before[:n] and got[1] == before[per:per + n]
+    finally:
+        os.sched_setaffinity(0, before)
+        torch.set_num_threads(threads)
