@@ -206,6 +206,7 @@ struct AttnP {
 
 constexpr uint32_t HC1 = 0x9E3779B1u, HC2 = 0x2C1B3C6Du;
 constexpr float MASKED_LOG2 = -1.4426950408889634e9f;      // masked_fill(-1e9) in the log2 domain
+A8_DEV float mask_fill_value(int nattended) { return nattended == 0 ? 0.f : MASKED_LOG2; }   // (see mask_prefix_len)
 // dropout word of key quad `idx`: fin((idx + seed) * HC1); callers carry the product as a running sum
 A8_DEV uint32_t hfin(uint32_t h) { h ^= h >> 15; return h * HC2; }
 A8_DEV uint32_t pair_base(int bh, int T, int Th, int q) { return ((uint32_t)bh * (uint32_t)T + (uint32_t)q) * (uint32_t)Th; }
@@ -226,6 +227,49 @@ A8_DEV void block_coords(int nblk, int nbh, int& blk, int& bh) {
         bh = L / nblk;
         blk = L % nblk;
     }
+}
+
+// Key-padding masks are, in practice, PREFIX masks: eight_mile's sequence_mask marks the first n_b frames of utterance b (audio8/train.py:33,
+// audio8/wav2vec2.py:703-708).  One pass over the utterance's mask row (T bytes, all loads independent) tells a wave whether its row is
+// such a mask with at least one attended key, and n_b: the kernel then IS the unmasked kernel over n_b keys -- key tiles beyond n_b are
+// never staged, only the boundary tile tests keys (exact: a masked score of -1e9 has probability exp(-1e9 - max) = 0 in f32 whenever
+// one key is attended).  Returns -1 for a mask with holes and 0 when NOTHING is attended: the per-key path.  Round 5 tested km[key] per
+// score in every tile: the masked forward / dQ kernels ran 80 / 88 us per layer at cfg5 against 37 / 49 unmasked at cfg2 (profiles/r06_cfg5_*).
+// An utterance without any attended key: the reference's softmax over T equal scores of -1e9 is uniform, and its gradient reaches V only
+// (masked_fill cuts q and k off).  -1e9 + log2(T) is not representable in f32, so such a row stands in 0 for the fill value (mask_fill_value:
+// the softmax is shift-invariant) and masked keys get dS = 0 explicitly in the per-key path.
+struct MaskScan {
+    int v[16];
+    float cnt, last1, first0;
+    A8_DEV void acc(int k0, int lane) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float k = (float)(k0 + lane + 64 * i);
+            if (v[i] > 0) { cnt += 1.f; last1 = fmaxf(last1, k); }
+            else if (v[i] == 0) first0 = fminf(first0, k);
+        }
+    }
+    A8_DEV void fetch(const uint8_t* __restrict__ km, int T, int k0, int lane) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const int k = k0 + lane + 64 * i; v[i] = k < T ? (int)km[k] : -1; }
+    }
+    // requests the row's first 1024 bytes and returns with the loads in flight (rows longer than that: the rest first, synchronously)
+    A8_DEV void load(const uint8_t* __restrict__ km, int T, int lane) {
+        cnt = 0.f; last1 = -1.f; first0 = 16777216.f;
+        for (int k0 = 1024; k0 < T; k0 += 1024) { fetch(km, T, k0, lane); acc(k0, lane); }
+        fetch(km, T, 0, lane);
+    }
+    A8_DEV int finish(int lane) {
+        acc(0, lane);
+        const float c = wave_sum(cnt), l1 = wave_max(last1), f0 = -wave_max(-first0);
+        const int n = c > 0.f ? (f0 > l1 ? (int)c : -1) : 0;
+        return __builtin_amdgcn_readfirstlane(n);
+    }
+};
+A8_DEV int mask_prefix_len(const uint8_t* __restrict__ km, int T, int lane) {
+    MaskScan ms;
+    ms.load(km, T, lane);
+    return ms.finish(lane);
 }
 
 // out[c] += scale * sum over the block's valid rows of acc[.][c]: acc[j][db][r] is column 16 db + 4 (lane >> 4) + r of the row
@@ -311,6 +355,7 @@ __global__ __launch_bounds__(NW * 64, MW) void attn_fwd_kernel(const AttnP P) {
     const T* vb = reinterpret_cast<const T*>(P.v) + (long long)b * P.T * P.ld_qkv + h * DH;
     const uint8_t* km = P.keymask ? P.keymask + (long long)b * P.T : nullptr;
     const int ntiles = (P.T + BT - 1) / BT;
+    const float maskv = mask_fill_value(km ? mask_prefix_len(km, P.T, lane) : 1);
 
     RowFrags<T> qf[G];
     f32x4 oacc[G][4];
@@ -350,7 +395,7 @@ __global__ __launch_bounds__(NW * 64, MW) void attn_fwd_kernel(const AttnP P) {
                     for (int r = 0; r < 4; ++r) {
                         const int key = key0 + 16 * i + r;
                         float x = s[j][i][r] * P.scale;
-                        if (km && key < P.T && !km[key]) x = MASKED_LOG2;
+                        if (km && key < P.T && !km[key]) x = maskv;
                         if (key >= P.T) x = -INFINITY;
                         s[j][i][r] = x;              // already scaled on this path
                         mt = fmaxf(mt, x);
@@ -457,6 +502,23 @@ void attn_bwd_kv_kernel(const AttnP P) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { dk[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     }
+    float maskv = MASKED_LOG2;
+    if (masked) {
+        // a prefix key mask (mask_prefix_len): a block whose keys all lie beyond the attended prefix has p = 0 for every score -- dK = dV = 0
+        const int nv = mask_prefix_len(P.keymask + (long long)b * P.T, P.T, lane);
+        maskv = mask_fill_value(nv);
+        if (nv > 0 && blk * BK >= nv) {                // block-uniform
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+                if (key[j] < P.T) {
+                    T* dkp = reinterpret_cast<T*>(P.dk) + ((long long)b * P.T + key[j]) * P.ld_d + h * DH + 4 * g;
+                    T* dvp = reinterpret_cast<T*>(P.dv) + ((long long)b * P.T + key[j]) * P.ld_d + h * DH + 4 * g;
+#pragma unroll
+                    for (int db = 0; db < 4; ++db) { store4<T>(dkp + 16 * db, 0.f, 0.f, 0.f, 0.f); store4<T>(dvp + 16 * db, 0.f, 0.f, 0.f, 0.f); }
+                }
+            return;
+        }
+    }
     // per-tile softmax statistics ride along with the tiles: rows beyond T get Q = dO = 0 (staged zero) and
     // lse = delta = 0, which makes dS = 0 and P^T dO = 0 without any per-element test
     auto load_stat = [&](int t) -> float {
@@ -504,12 +566,13 @@ void attn_bwd_kv_kernel(const AttnP P) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float x = __builtin_fmaf(s[j][i][r], P.scale, -lse4[r]);
-                    if (masked && key_masked[j]) x = MASKED_LOG2 - lse4[r];
+                    if (masked && key_masked[j]) x = maskv - lse4[r];
                     const float p = fast_exp2(x);      // keys beyond T: harmless garbage in rows that are never stored
                     float pdrop = p;
                     if (drop) pdrop = (wr[r] & fmask) >= fthr ? p : 0.f;
                     s[j][i][r] = pdrop;                                                  // P (dropped, unscaled) for dV
                     dp[j][i][r] = __builtin_fmaf(pdrop, dp[j][i][r], -(p * del4[r]));    // dS / (softmax scale * pscale) for dK
+                    if (masked && key_masked[j]) dp[j][i][r] = 0.f;                      // a filled score does not depend on q or k
                 }
             }
             hk[j] += (uint32_t)BT * ThC;
@@ -562,7 +625,17 @@ void attn_bwd_q_kernel(const AttnP P) {
     const T* dob = reinterpret_cast<const T*>(P.dout) + (long long)b * P.T * P.ld_o + h * DH;
     const T* ob = reinterpret_cast<const T*>(P.o) + (long long)b * P.T * P.ld_o + h * DH;
     const uint8_t* km = masked ? P.keymask + (long long)b * P.T : nullptr;
-    const int ntiles = (P.T + BT - 1) / BT;
+    // prefix key mask: the unmasked kernel over the first Tk keys (tiles beyond them are never staged, only the boundary tile tests keys);
+    // any other mask: km[key] per score (mask_prefix_len)
+    int Tk = P.T;
+    bool holes = false;
+    float maskv = MASKED_LOG2;
+    if (masked) {
+        const int nv = mask_prefix_len(km, P.T, lane);
+        if (nv > 0) Tk = nv; else holes = true;
+        maskv = mask_fill_value(nv);
+    }
+    const int ntiles = (Tk + BT - 1) / BT;
 
     RowFrags<T> qf[G], dof[G];
     f32x4 dq[G][4];
@@ -605,14 +678,19 @@ void attn_bwd_q_kernel(const AttnP P) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float x = __builtin_fmaf(s[j][i][r], P.scale, nlse[j]);
-                    if (masked) {                                              // wave-uniform
+                    bool filled = false;                                        // (per-key path only) the score is the fill value: dS = 0
+                    if (masked) {                                              // block-uniform tests
                         const int key = kt_i * BT + 4 * g + 16 * i + r;
-                        if (key < P.T && !km[key]) x = MASKED_LOG2 + nlse[j];
+                        if (holes) {
+                            filled = key >= P.T || !km[min(key, P.T - 1)];     // (keys beyond T: with lse near -1e9 even a zero K row would give p = inf)
+                            if (filled) x = maskv + nlse[j];
+                        } else if ((kt_i + 1) * BT > Tk) { if (key >= Tk) x = MASKED_LOG2 + nlse[j]; }
                     }
                     const float p = fast_exp2(x);
                     float dpv = dp[j][i][r];
                     if (drop) dpv = (((h0 >> (8 * r)) & 0xFFu) >= P.thr) ? dpv : 0.f;
                     s[j][i][r] = p * __builtin_fmaf(dpv, P.pscale, ndelta[j]);      // dS^T[key][q] / softmax scale
+                    if (masked && holes && filled) s[j][i][r] = 0.f;
                 }
             }
             hb[j] += (uint32_t)(BT / 4) * HC1;
@@ -677,13 +755,18 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd32_kernel(const AttnP P) {
     const char* kb_ = reinterpret_cast<const char*>(reinterpret_cast<const bf16*>(P.k) + (long long)b * P.T * P.ld_qkv + h * DH);
     const char* vb_ = reinterpret_cast<const char*>(reinterpret_cast<const bf16*>(P.v) + (long long)b * P.T * P.ld_qkv + h * DH);
     const uint8_t* km = P.keymask ? P.keymask + (long long)b * P.T : nullptr;
-    const int ntiles = (P.T + BT - 1) / BT;
+    const int ntiles = (P.T + BT - 1) / BT;                  // tiles of the operands (DMA addressing / clamps)
     const long long row_bytes = P.ld_qkv * 2, tile_bytes = (long long)BT * row_bytes;
+    // Key mask: the row scan's loads are the OLDEST vector loads of the wave (retired with the Q loads by the counted wait below).
+    // Prefix mask -> Tk attended keys, ntl key tiles walked; anything else -> per-key tests (holes).
+    MaskScan ms;
+    if (km) ms.load(km, P.T, lane);
 
     // ---- this wave's four DMA pieces of a tile (1 KB each; 16 per tile: 0..7 = K rows 8p.., 8..15 = V blocks 4(p-8)..; with 5 waves
     // four pieces are staged twice -- same bytes, same place).  Rows beyond T are clamped to row T-1 (finite data whose
     // probabilities are zero): only the last tile has any, and it takes its own, precomputed, offsets.
-    unsigned soff[4], soff_last[4]; int dst[4]; bool is_k[4];
+    unsigned soff[4], soff_clamp[4]; int dst[4]; bool is_k[4];      // soff_clamp: what the last tile's row clamp takes off (a value select:
+                                                                    // a select between two ARRAYS becomes a dynamic index and parks both in scratch)
     const int last_rows = P.T - (ntiles - 1) * BT;           // valid rows of the last tile (1..64)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -699,11 +782,13 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd32_kernel(const AttnP P) {
         }
         is_k[j] = pid < 8;
         soff[j] = (unsigned)(row * (int)row_bytes + chunk * 16);
-        soff_last[j] = (unsigned)(min(row, last_rows - 1) * (int)row_bytes + chunk * 16);
+        soff_clamp[j] = (unsigned)((row - min(row, last_rows - 1)) * (int)row_bytes);
         dst[j] = pid * 1024;
     }
-    auto issue = [&](int t, int slot) {
-        const bool live = t < ntiles;                    // wave-uniform
+    // (nlive is a parameter, not a capture: a by-reference capture that is assigned between two calls keeps the whole closure -- and the
+    // offset arrays it points to -- in scratch memory)
+    auto issue = [&](int t, int slot, int nlive) __attribute__((always_inline)) {
+        const bool live = t < nlive;                     // wave-uniform
         const int tt = live ? t : ntiles - 1;            // past the end: a harmless re-read of the last tile into the dummy page
         const char* kbase = kb_ + (long long)tt * tile_bytes;
         const char* vbase = vb_ + (long long)tt * tile_bytes;
@@ -711,7 +796,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd32_kernel(const AttnP P) {
         const bool lastt = tt == ntiles - 1;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            attn_glds16((is_k[j] ? kbase : vbase) + (lastt ? soff_last[j] : soff[j]), base + (live ? dst[j] : 0));
+            attn_glds16((is_k[j] ? kbase : vbase) + (soff[j] - (lastt ? soff_clamp[j] : 0u)), base + (live ? dst[j] : 0));
     };
 
     // ---- Q fragments (B operand: lane holds Q[query][16 ks + 8 half + 0..7]); dropout word base; accumulators
@@ -722,12 +807,16 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd32_kernel(const AttnP P) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
         qf[ks] = q_ok ? *reinterpret_cast<const bf16x8*>(qb + (long long)q * P.ld_qkv + 16 * ks + 8 * hh) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-    issue(0, 0);
-    issue(1, 1);
-    // The Q loads are older than the eight DMAs: retire them HERE, with a wait the compiler's counter pass can see (an inline-asm wait
-    // is invisible to it) -- otherwise it protects the first use of qf inside the loop with a vmcnt(0) that would drain the ring's
-    // prefetches in every iteration.
+    issue(0, 0, ntiles);                         // (liveness by T here: a second tile beyond a short attended prefix is staged and never read)
+    issue(1, 1, ntiles);
+    // The Q loads (and the mask scan's) are older than the eight DMAs: retire them HERE, with a wait the compiler's counter pass can see
+    // (an inline-asm wait is invisible to it) -- otherwise it protects the first use of qf inside the loop with a vmcnt(0) that would
+    // drain the ring's prefetches in every iteration.
     __builtin_amdgcn_s_waitcnt(0x0F78);          // vmcnt(8) alone (expcnt 7, lgkmcnt 15)
+    const int nv = km ? ms.finish(lane) : 1;
+    const bool holes = km != nullptr && nv <= 0;
+    const float maskv = mask_fill_value(nv);
+    const int Tk = (km != nullptr && nv > 0) ? nv : P.T, ntl = (Tk + BT - 1) / BT;
     f32x16 o[2];
 #pragma unroll
     for (int db = 0; db < 2; ++db)
@@ -742,7 +831,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd32_kernel(const AttnP P) {
     for (int ks = 0; ks < 4; ++ks) kaddr[ks] = r * 128 + (((2 * ks + hh) ^ kkey) << 4);
 
     int slot = 0;
-    for (int t = 0; t < ntiles; ++t) {
+    for (int t = 0; t < ntl; ++t) {
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");          // this wave's pieces of tile t have landed (tile t+1 may be in flight)
         __builtin_amdgcn_s_barrier();                             // ... and everybody else's; nobody reads tile t-1's slot any more
         int nslot = slot + 2; nslot = nslot >= NBUF ? nslot - NBUF : nslot;
@@ -760,7 +849,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd32_kernel(const AttnP P) {
                 s[kb] = mfma32(*reinterpret_cast<const bf16x8*>(kt + kb * 4096 + kaddr[ks]), qf[ks], s[kb]);
         }
         // ---- probabilities against the current reference max; the row sum is the overflow test
-        const bool edge = km != nullptr || (t + 1) * BT > P.T;    // wave-uniform
+        const bool edge = holes || (t + 1) * BT > Tk;             // wave-uniform
         float tsum = 0.f;
         bool rescale = edge || t == 0;                            // (the first tile has no reference max yet: straight to the rescale path)
         if (!rescale) {
@@ -785,8 +874,8 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd32_kernel(const AttnP P) {
                     float x = s[kb][i] * P.scale;
                     if (edge) {
                         const int key = t * BT + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                        if (km && key < P.T && !km[key]) x = MASKED_LOG2;
-                        if (key >= P.T) x = -INFINITY;
+                        if (holes && key < P.T && !km[key]) x = maskv;
+                        if (key >= Tk) x = key < P.T ? MASKED_LOG2 : -INFINITY;
                     }
                     s[kb][i] = x;
                     mt = fmaxf(mt, x);
@@ -847,7 +936,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd32_kernel(const AttnP P) {
         // Tile t+2 goes into the slot tile t-1 was read from (free since this iteration's barrier).  Issued at the END of the body:
         // the transposed-read builtin carries no alias information, so hipcc drains every pending LDS-DMA (vmcnt(0)) in front of the
         // first V read that follows one -- placed here, that wait falls in the NEXT iteration, a whole K phase + softmax after the issue.
-        issue(t + 2, nslot);
+        issue(t + 2, nslot, ntl);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the dummy DMAs past the last tile
     // ---- epilogue: the two half-waves of a query hold complementary halves of its row sum

@@ -1,16 +1,21 @@
-// a8hip: CTC loss forward + gradient, one wavefront per utterance (F.ctc_loss native path with cuDNN
-// disabled, blank = Offsets.GO = 0, zero_infinity -- audio8/ctc.py:186-206).
+// a8hip: CTC loss forward + gradient (F.ctc_loss native path with cuDNN disabled, blank = Offsets.GO = 0,
+// zero_infinity -- audio8/ctc.py:186-206).
 //
-// The alpha/beta recurrences over the 2S+1 extended labels are serial in time and tiny per step, so the
-// kernel is latency-bound: each lane keeps a CONTIGUOUS run of SPL states in registers, the s-1 / s-2
-// neighbours of a run's first states come from the previous lane by wave shuffle, and nothing but the
-// per-frame class log-probabilities passes through LDS.
-//
-// Numerics: ATen recurses on raw log-alpha, whose f32 values reach about -2000 at T = 624 (one ulp = 1.2e-4, so
-// its own gradients carry ~1e-3 of noise).  Here the recursion runs in the log2 domain on PER-FRAME-NORMALISED
-// values: after every frame log2-alpha is shifted by the frame's log-sum (kept separately), so the stored numbers
-// stay near 0 where f32 resolves ~1e-7, while tight alignments (T barely above S), whose end-state mass is
-// 1e-40 of the prefix mass, neither underflow nor lose precision.  Posteriors are normalised per frame.
+// The alpha / beta recurrences over the 2S+1 extended labels are serial in time and tiny per step: the loss is LATENCY, and it
+// sits between the model's forward and its backward with nothing to overlap it (round 5: one wave per utterance running alpha,
+// then beta + gradient, with a global-memory round trip per frame in each: 6.5 ms of the 21.4 ms cfg5 step).  Round 6:
+//   * alpha and beta run CONCURRENTLY, one wave each per utterance (grid B x 2), and only recurse; both store their per-frame
+//     normalised log2 values; the posteriors and the gradient are a third, fully parallel launch (one wave per frame);
+//   * no memory round trip on the recurrence: the utterance's log-probability rows are staged through LDS in chunks of
+//     1024 floats (32 frames at V = 32), the next chunk's global loads in flight in registers while the current one is walked;
+//   * each lane keeps a CONTIGUOUS run of SPL states in registers (SPL = ceil((2 Smax + 1) / 64), one instantiation per value),
+//     the s-1 / s-2 neighbours of a run's ends come from the adjacent lane by wave shuffle;
+//   * log2(2^a + 2^b + 2^c) as max3 / med3 / min3 + two v_exp_f32 + one v_log_f32.
+// Numerics: ATen recurses on raw log-alpha, whose f32 values reach about -2000 at T = 624 (one ulp = 1.2e-4, so its own
+// gradients carry ~1e-3 of noise).  Here both recursions run in the log2 domain on PER-FRAME-NORMALISED values: after every
+// frame the values are shifted by the frame's maximum (the shifts are summed separately for the likelihood), so the stored
+// numbers stay near 0 where f32 resolves ~1e-7, while tight alignments (T barely above S), whose end-state mass is 1e-40 of
+// the prefix mass, neither underflow nor lose precision.  Posteriors are normalised per frame.
 #include "a8_common.h"
 #include "a8hip_internal.h"
 
@@ -18,162 +23,248 @@ namespace {
 
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 constexpr float NEG = -INFINITY;
+constexpr int CTC_CHUNK = 1024;              // floats of log-probabilities staged per LDS buffer (V <= CTC_CHUNK: whole frames)
 
 A8_DEV float lse2_3(float a, float b, float c) {           // log2(2^a + 2^b + 2^c), -inf safe
-    const float m = fmaxf(a, fmaxf(b, c));
-    if (m == NEG) return NEG;
-    return m + log2f(exp2f(a - m) + exp2f(b - m) + exp2f(c - m));
+    const float m = fmaxf(a, fmaxf(b, c));                  // v_max3_f32
+    const float lo = fminf(a, fminf(b, c));                 // v_min3_f32
+    const float mid = __builtin_amdgcn_fmed3f(a, b, c);
+    const float r = m + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(mid - m) + __builtin_amdgcn_exp2f(lo - m));
+    return m == NEG ? NEG : r;                              // (m = -inf: the differences are NaN)
 }
-A8_DEV float wave_lse2(float v) {                            // log2 sum_lanes 2^v, -inf safe
-    const float m = wave_max(v);
-    if (m == NEG) return NEG;
-    return m + log2f(wave_sum(exp2f(v - m)));
+A8_DEV float lse2_2(float a, float b) {
+    const float m = fmaxf(a, b), lo = fminf(a, b);
+    const float r = m + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(lo - m));
+    return m == NEG ? NEG : r;
 }
 
+// The staged log-probability rows of one utterance, walked forwards (alpha) or backwards (beta).  V <= CTC_CHUNK: chunks of
+// F = CTC_CHUNK / V whole frames (at most 64), double-buffered, chunk k + 1 requested (16 loads per lane, addresses clamped to the
+// utterance's last row) before chunk k is walked and written to the other buffer behind it.  V > CTC_CHUNK (BPE vocabularies):
+// one frame at a time, synchronously.
+struct LpStage {
+    const float* lp; float* sm;
+    long long rowstride;         // floats between frames of this utterance: B * V
+    int V, F, Tmax, nchunk, big;
+    float r[16];
+    A8_DEV void init(const float* lp_b, float* sm_, int V_, int B, int Tmax_, int Tb) {
+        lp = lp_b; sm = sm_; V = V_; Tmax = Tmax_; rowstride = (long long)B * V_;
+        big = V_ > CTC_CHUNK;
+        F = big ? 1 : min(64, CTC_CHUNK / V_);
+        nchunk = (Tb + F - 1) / F;
+    }
+    A8_DEV void request(int k) {                                  // chunk k -> registers (small V only)
+        const int lane = threadIdx.x, n = F * V;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int e = lane + 64 * i;
+            const int f = e / V, c = e - f * V;
+            const int t = min(k * F + f, Tmax - 1);
+            r[i] = e < n ? lp[(long long)t * rowstride + c] : 0.f;
+        }
+    }
+    A8_DEV void commit(int buf) {                                 // registers -> LDS buffer, in log2 units
+        const int lane = threadIdx.x, n = F * V;
+        __syncthreads();                                          // (one wave: orders the LDS reads of this buffer's last user)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int e = lane + 64 * i;
+            if (e < n) sm[buf * CTC_CHUNK + e] = r[i] * LOG2E;
+        }
+        __syncthreads();
+    }
+    A8_DEV const float* frame_big(int t) {                        // V > CTC_CHUNK: frame t synchronously into the single buffer
+        __syncthreads();
+        for (int c = threadIdx.x; c < V; c += 64) sm[c] = lp[(long long)t * rowstride + c] * LOG2E;
+        __syncthreads();
+        return sm;
+    }
+};
+
+// dir = blockIdx.y: 0 = alpha (frames ascending), 1 = beta (descending).  ab / bb: [B][Tmax][64 SPL] normalised log2 values, element
+// (lane, j) = state lane * SPL + j at index j * 64 + lane (coalesced).  status[b] = 1 when the utterance has a valid alignment.
 template <int SPL>
-__global__ __launch_bounds__(64) void ctc_kernel(const float* __restrict__ lp, const int32_t* __restrict__ targets,
-                                                 const int32_t* __restrict__ tgt_off, const int32_t* __restrict__ in_len,
-                                                 float* __restrict__ nll, float* __restrict__ grad, float* __restrict__ abuf,
-                                                 int Tmax, int B, int V, int Lmax, int blank, int zero_infinity) {
-    extern __shared__ float sm[];            // pr[V] (log2 class probabilities of the frame) | occ[V]
-    float* pr = sm;
-    float* occ = sm + V;
-    const int b = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(64) void ctc_ab_kernel(const float* __restrict__ lp, const int32_t* __restrict__ targets,
+                                                    const int32_t* __restrict__ tgt_off, const int32_t* __restrict__ in_len,
+                                                    float* __restrict__ nll, float* __restrict__ abuf, float* __restrict__ bbuf,
+                                                    int32_t* __restrict__ status, int Tmax, int B, int V, int blank, int zero_infinity) {
+    extern __shared__ float sm[];
+    const int b = blockIdx.x, dir = blockIdx.y, lane = threadIdx.x;
     const int S = tgt_off[b + 1] - tgt_off[b];
     const int L = 2 * S + 1;
-    int Tb = in_len[b];
-    if (Tb > Tmax) Tb = Tmax;
+    const int Tb = min(in_len[b], Tmax);
     const int32_t* lab = targets + tgt_off[b];
-    float* ab = abuf + (long long)b * Tmax * Lmax;       // normalised log2-alpha of every frame
-
-    // gradient defaults to zero (frames beyond the input length, infeasible utterances)
-    for (int t = 0; t < Tmax; ++t)
-        for (int c = lane; c < V; c += 64) grad[((long long)t * B + b) * V + c] = 0.f;
-    if (Tb <= 0 || L > 64 * SPL) { if (lane == 0) nll[b] = zero_infinity ? 0.f : INFINITY; return; }
+    if (Tb <= 0 || L > 64 * SPL) {
+        if (dir == 0 && lane == 0) { nll[b] = zero_infinity ? 0.f : INFINITY; status[b] = 0; }
+        return;
+    }
+    constexpr int PITCH = 64 * SPL;
+    float* const out = (dir == 0 ? abuf : bbuf) + (long long)b * Tmax * PITCH;
 
     int ext[SPL];
-    bool skip[SPL];
+    bool valid[SPL], skip[SPL];          // skip[j]: alpha may come from s - 2 (dir 0) / beta may go to s + 2 (dir 1)
 #pragma unroll
     for (int j = 0; j < SPL; ++j) {
         const int s = lane * SPL + j;
-        ext[j] = (s < L && (s & 1)) ? lab[s >> 1] : blank;
-        skip[j] = (s < L) && (s & 1) && s >= 3 && lab[s >> 1] != lab[(s >> 1) - 1];
+        valid[j] = s < L;
+        ext[j] = (valid[j] && (s & 1)) ? lab[s >> 1] : blank;
+        if (dir == 0) skip[j] = valid[j] && (s & 1) && s >= 3 && lab[s >> 1] != lab[(s >> 1) - 1];
+        else skip[j] = (s + 2 < L) && (s & 1) && lab[(s + 2) >> 1] != lab[s >> 1];
     }
+    LpStage st;
+    st.init(lp + (long long)b * V, sm, V, B, Tmax, Tb);
+
     float a[SPL];
+    // alpha: the virtual frame -1 holds all mass in state 0 with the emission-free step into frame 0 (alpha_0(0) = p(blank),
+    // alpha_0(1) = p(l_1)); beta_{T-1} (own emission excluded) = 1 on the last two states
 #pragma unroll
-    for (int j = 0; j < SPL; ++j) a[j] = NEG;
-    float ll2 = 0.f;                         // log2-likelihood accumulated from the per-frame normalisers
-    // ---------------- forward
-    for (int t = 0; t < Tb; ++t) {
-        __syncthreads();
-        for (int c = lane; c < V; c += 64) pr[c] = lp[((long long)t * B + b) * V + c] * LOG2E;
-        __syncthreads();
+    for (int j = 0; j < SPL; ++j) {
+        const int s = lane * SPL + j;
+        a[j] = dir == 0 ? (s == 0 ? 0.f : NEG) : ((valid[j] && (s == L - 1 || s == L - 2)) ? 0.f : NEG);
+    }
+    float ll2 = 0.f;                         // log2-likelihood accumulated from the per-frame shifts (alpha)
+    bool dead = false;
+
+    auto alpha_frame = [&](const float* pr, int t) {
+        const float up1 = __shfl_up(a[SPL - 1], 1, 64);
+        const float up2 = SPL >= 2 ? __shfl_up(a[SPL >= 2 ? SPL - 2 : 0], 1, 64) : __shfl_up(a[0], 2, 64);
+        const float p1 = lane >= 1 ? up1 : NEG;
+        const float p2 = SPL >= 2 ? (lane >= 1 ? up2 : NEG) : (lane >= 2 ? up2 : NEG);
         float na[SPL];
-        if (t == 0) {
-#pragma unroll
-            for (int j = 0; j < SPL; ++j) { const int s = lane * SPL + j; na[j] = (s < 2 && s < L) ? pr[ext[j]] : NEG; }
-        } else {
-            const float up1 = __shfl_up(a[SPL - 1], 1, 64);
-            const float up2 = SPL >= 2 ? __shfl_up(a[SPL >= 2 ? SPL - 2 : 0], 1, 64) : __shfl_up(a[0], 2, 64);
-            const float p1 = lane >= 1 ? up1 : NEG;
-            const float p2 = SPL >= 2 ? (lane >= 1 ? up2 : NEG) : (lane >= 2 ? up2 : NEG);
-#pragma unroll
-            for (int j = 0; j < SPL; ++j) {
-                const int s = lane * SPL + j;
-                const float m1 = j >= 1 ? a[j >= 1 ? j - 1 : 0] : p1;
-                const float m2 = j >= 2 ? a[j >= 2 ? j - 2 : 0] : (j == 1 ? p1 : p2);
-                const float v = lse2_3(a[j], m1, skip[j] ? m2 : NEG);
-                na[j] = s < L ? v + pr[ext[j]] : NEG;
-            }
-        }
-        float mx = NEG;
-#pragma unroll
-        for (int j = 0; j < SPL; ++j) mx = fmaxf(mx, na[j]);
-        mx = wave_max(mx);
-        float sum = 0.f;
-        if (mx != NEG) {
-#pragma unroll
-            for (int j = 0; j < SPL; ++j) sum += exp2f(na[j] - mx);
-        }
-        sum = wave_sum(sum);
-        const float c2 = mx == NEG ? NEG : mx + log2f(sum);          // log2 of the frame's total mass
-        if (c2 == NEG) {                                             // no alignment survives: infeasible
-            if (lane == 0) nll[b] = zero_infinity ? 0.f : INFINITY;
-            return;
-        }
-        ll2 += c2;
-#pragma unroll
-        for (int j = 0; j < SPL; ++j) {
-            a[j] = na[j] - c2;
-            const int s = lane * SPL + j;
-            if (s < L) ab[(long long)t * Lmax + s] = a[j];
-        }
-    }
-    // termination: log2 Z = log2(alpha_{T-1}(L-1) + alpha_{T-1}(L-2)) in normalised units
-    float zt = NEG;
-#pragma unroll
-    for (int j = 0; j < SPL; ++j) { const int s = lane * SPL + j; if (s == L - 1 || s == L - 2) zt = zt == NEG ? a[j] : lse2_3(zt, a[j], NEG); }
-    const float z2 = wave_lse2(zt);
-    if (z2 == NEG) {
-        if (lane == 0) nll[b] = zero_infinity ? 0.f : INFINITY;
-        return;
-    }
-    if (lane == 0) nll[b] = -(ll2 + z2) * LN2;
-    // ---------------- backward + gradient (beta excludes the emission of its own frame; re-normalised per frame)
-    float bt[SPL];
-#pragma unroll
-    for (int j = 0; j < SPL; ++j) { const int s = lane * SPL + j; bt[j] = (s < L && (s == L - 1 || s == L - 2)) ? 0.f : NEG; }
-    for (int t = Tb - 1; t >= 0; --t) {
-        __syncthreads();
-        for (int c = lane; c < V; c += 64) { pr[c] = lp[((long long)t * B + b) * V + c] * LOG2E; occ[c] = 0.f; }
-        __syncthreads();
-        // posterior occupancy of frame t: 2^(alpha + beta) normalised over the states
-        float g2[SPL];
         float mx = NEG;
 #pragma unroll
         for (int j = 0; j < SPL; ++j) {
-            const int s = lane * SPL + j;
-            g2[j] = s < L ? ab[(long long)t * Lmax + s] + bt[j] : NEG;
-            mx = fmaxf(mx, g2[j]);
+            const float m1 = j >= 1 ? a[j >= 1 ? j - 1 : 0] : p1;
+            const float m2 = j >= 2 ? a[j >= 2 ? j - 2 : 0] : (j == 1 ? p1 : p2);
+            const float v = lse2_3(a[j], m1, skip[j] ? m2 : NEG);
+            na[j] = valid[j] ? v + pr[ext[j]] : NEG;
+            mx = fmaxf(mx, na[j]);
         }
         mx = wave_max(mx);
-        float sum = 0.f;
+        if (mx == NEG) { dead = true; return; }                   // no alignment survives (wave-uniform)
+        ll2 += mx;
 #pragma unroll
-        for (int j = 0; j < SPL; ++j) { g2[j] = g2[j] == NEG ? 0.f : exp2f(g2[j] - mx); sum += g2[j]; }
-        const float inv = 1.0f / wave_sum(sum);
+        for (int j = 0; j < SPL; ++j) {
+            a[j] = na[j] - mx;
+            out[(long long)t * PITCH + j * 64 + lane] = a[j];
+        }
+    };
+    auto beta_frame = [&](const float* pr, int t) {
 #pragma unroll
-        for (int j = 0; j < SPL; ++j)
-            if (g2[j] != 0.f) atomicAdd(&occ[ext[j]], g2[j] * inv);
-        __syncthreads();
-        for (int c = lane; c < V; c += 64) grad[((long long)t * B + b) * V + c] = exp2f(pr[c]) - occ[c];
-        if (t == 0) break;
-        // beta_{t-1}(s) = sum_{s' in {s, s+1, s+2 if skip(s+2)}} beta_t(s') p_t(s'), then shift by the frame's log-sum
+        for (int j = 0; j < SPL; ++j) out[(long long)t * PITCH + j * 64 + lane] = a[j];
+        if (t == 0) return;
+        // beta_{t-1}(s) = sum_{s' in {s, s+1, s+2 if skip}} beta_t(s') p_t(s')
         float w[SPL];
-        bool sk[SPL];
 #pragma unroll
-        for (int j = 0; j < SPL; ++j) { w[j] = bt[j] + pr[ext[j]]; sk[j] = skip[j]; }
+        for (int j = 0; j < SPL; ++j) w[j] = valid[j] ? a[j] + pr[ext[j]] : NEG;
         const float dn1 = __shfl_down(w[0], 1, 64);
         const float dn2 = SPL >= 2 ? __shfl_down(w[SPL >= 2 ? 1 : 0], 1, 64) : __shfl_down(w[0], 2, 64);
-        const int dsk1i = __shfl_down((int)sk[0], 1, 64);
-        const int dsk2i = SPL >= 2 ? __shfl_down((int)sk[SPL >= 2 ? 1 : 0], 1, 64) : __shfl_down((int)sk[0], 2, 64);
-        const bool has1 = lane < 63, has2 = SPL >= 2 ? lane < 63 : lane < 62;
+        const float q1 = lane < 63 ? dn1 : NEG;
+        const float q2 = SPL >= 2 ? (lane < 63 ? dn2 : NEG) : (lane < 62 ? dn2 : NEG);
         float nb[SPL];
         float bm = NEG;
 #pragma unroll
         for (int j = 0; j < SPL; ++j) {
-            const int s = lane * SPL + j;
-            const float n1 = j + 1 < SPL ? w[j + 1 < SPL ? j + 1 : 0] : (has1 ? dn1 : NEG);
-            float n2; bool s2;
-            if (j + 2 < SPL) { n2 = w[j + 2 < SPL ? j + 2 : 0]; s2 = sk[j + 2 < SPL ? j + 2 : 0]; }
-            else if (j + 1 < SPL) { n2 = has1 ? dn1 : NEG; s2 = has1 && dsk1i; }       // j == SPL-2: next lane's state 0
-            else { n2 = has2 ? dn2 : NEG; s2 = has2 && dsk2i; }                          // next lane's state 1 (or lane+2's, SPL == 1)
-            nb[j] = s < L ? lse2_3(w[j], n1, s2 ? n2 : NEG) : NEG;
+            const float n1 = j + 1 < SPL ? w[j + 1 < SPL ? j + 1 : 0] : q1;
+            const float n2 = j + 2 < SPL ? w[j + 2 < SPL ? j + 2 : 0] : (j + 1 < SPL ? q1 : q2);
+            nb[j] = valid[j] ? lse2_3(w[j], n1, skip[j] ? n2 : NEG) : NEG;
             bm = fmaxf(bm, nb[j]);
         }
-        bm = wave_max(bm);                     // keep beta near 0: subtract the frame maximum (any shift cancels in the posterior)
+        bm = wave_max(bm);                     // keep beta near 0 (any per-frame shift cancels in the posterior)
 #pragma unroll
-        for (int j = 0; j < SPL; ++j) bt[j] = nb[j] == NEG ? NEG : nb[j] - bm;
+        for (int j = 0; j < SPL; ++j) a[j] = bm == NEG ? NEG : nb[j] - bm;
+    };
+
+    if (st.big) {
+        for (int i = 0; i < Tb && !dead; ++i) {
+            const int t = dir == 0 ? i : Tb - 1 - i;
+            const float* pr = st.frame_big(t);
+            if (dir == 0) alpha_frame(pr, t); else beta_frame(pr, t);
+        }
+    } else {
+        const int F = st.F, nch = st.nchunk;
+        int k = dir == 0 ? 0 : nch - 1, buf = 0;
+        st.request(k);
+        st.commit(0);
+        for (int c = 0; c < nch && !dead; ++c) {
+            const int kn = dir == 0 ? k + 1 : k - 1;
+            const bool more = c + 1 < nch;
+            if (more) st.request(kn);                             // in flight while this chunk is walked
+            const float* base = sm + buf * CTC_CHUNK;
+            const int f_end = min(F, Tb - k * F);
+            if (dir == 0) {
+                for (int f = 0; f < f_end && !dead; ++f) alpha_frame(base + f * V, k * F + f);
+            } else {
+                for (int f = f_end - 1; f >= 0; --f) beta_frame(base + f * V, k * F + f);
+            }
+            if (more) st.commit(buf ^ 1);
+            buf ^= 1;
+            k = kn;
+        }
     }
+    if (dir != 0) return;
+    if (dead) {
+        if (lane == 0) { nll[b] = zero_infinity ? 0.f : INFINITY; status[b] = 0; }
+        return;
+    }
+    // termination: log2 Z = log2(alpha_{T-1}(L-1) + alpha_{T-1}(L-2)) in normalised units
+    float zt = NEG;
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) { const int s = lane * SPL + j; if (valid[j] && (s == L - 1 || s == L - 2)) zt = lse2_2(zt, a[j]); }
+    const float zm = wave_max(zt);
+    if (zm == NEG) {
+        if (lane == 0) { nll[b] = zero_infinity ? 0.f : INFINITY; status[b] = 0; }
+        return;
+    }
+    const float z2 = zm + log2f(wave_sum(zt == NEG ? 0.f : exp2f(zt - zm)));
+    if (lane == 0) { nll[b] = -(ll2 + z2) * LN2; status[b] = 1; }
+}
+
+// grad[t, b, :] = softmax probabilities of the frame - the posterior occupancy of its classes; one wave per (frame, utterance).
+//   occupancy(c) = sum_{s: ext(s) = c} 2^(alpha_t(s) + beta_t(s)) / sum_s 2^(alpha_t(s) + beta_t(s))
+// Frames beyond the input length and utterances without a valid alignment get zeros (zero_infinity).
+__global__ __launch_bounds__(64) void ctc_grad_kernel(const float* __restrict__ lp, const int32_t* __restrict__ targets,
+                                                      const int32_t* __restrict__ tgt_off, const int32_t* __restrict__ in_len,
+                                                      const float* __restrict__ abuf, const float* __restrict__ bbuf,
+                                                      const int32_t* __restrict__ status, float* __restrict__ grad,
+                                                      int Tmax, int B, int V, int spl, int blank) {
+    extern __shared__ float occ[];           // [V]
+    const int t = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    float* const grow = grad + ((long long)t * B + b) * V;
+    const int Tb = min(in_len[b], Tmax);
+    const int S = tgt_off[b + 1] - tgt_off[b], L = 2 * S + 1;
+    if (t >= Tb || L > 64 * spl || status[b] == 0) {
+        for (int c = lane; c < V; c += 64) grow[c] = 0.f;
+        return;
+    }
+    const int pitch = 64 * spl;
+    const float* ar = abuf + ((long long)b * Tmax + t) * pitch;
+    const float* br = bbuf + ((long long)b * Tmax + t) * pitch;
+    const int32_t* lab = targets + tgt_off[b];
+    for (int c = lane; c < V; c += 64) occ[c] = 0.f;
+    float mx = NEG;
+    for (int j = 0; j < spl; ++j) {
+        const int s = lane * spl + j;
+        if (s < L) mx = fmaxf(mx, ar[j * 64 + lane] + br[j * 64 + lane]);
+    }
+    mx = wave_max(mx);                       // finite: the utterance has an alignment, so every frame carries mass
+    __syncthreads();
+    float sum = 0.f;
+    for (int j = 0; j < spl; ++j) {
+        const int s = lane * spl + j;
+        if (s < L) {
+            const float g = ar[j * 64 + lane] + br[j * 64 + lane];
+            if (g != NEG) {
+                const float p = exp2f(g - mx);
+                sum += p;
+                atomicAdd(&occ[(s & 1) ? lab[s >> 1] : blank], p);
+            }
+        }
+    }
+    const float inv = 1.0f / wave_sum(sum);
+    __syncthreads();
+    const float* prow = lp + ((long long)t * B + b) * V;
+    for (int c = lane; c < V; c += 64) grow[c] = exp2f(prow[c] * LOG2E) - occ[c] * inv;
 }
 
 // ---- greedy decode (audio8/ctc.py:156-159: argmax over labels, unique_consecutive, drop blanks), one wave per
@@ -256,24 +347,32 @@ extern "C" int a8_ctc_pack_targets(const int64_t* targets, const int32_t* target
 }
 
 extern "C" int a8_ctc_fwd_bwd(const float* lp, const int32_t* targets, const int32_t* tgt_off, const int32_t* in_len,
-                              float* nll, float* grad, float* alpha, int T_, int B, int V, int Smax, int blank, int zero_infinity,
+                              float* nll, float* grad, float* scratch, int T_, int B, int V, int Smax, int blank, int zero_infinity,
                               void* stream) {
     A8_REQUIRE(T_ >= 1 && B >= 1 && V >= 1, "a8_ctc_fwd_bwd: bad sizes T=%d B=%d V=%d", T_, B, V);
     A8_REQUIRE(blank >= 0 && blank < V, "a8_ctc_fwd_bwd: bad blank index");
     const int Lmax = 2 * Smax + 1;
     A8_REQUIRE(Smax >= 0 && Lmax <= 64 * 16, "a8_ctc_fwd_bwd: Smax=%d exceeds the supported 511 labels", Smax);
+    A8_REQUIRE(V <= 8192, "a8_ctc_fwd_bwd: V=%d labels exceed the 8192 the per-frame LDS rows hold", V);
+    A8_REQUIRE(B <= 65535, "a8_ctc_fwd_bwd: B=%d exceeds the grid's second dimension", B);
     const int spl = (Lmax + 63) / 64;
-    const size_t shm = sizeof(float) * 2 * V;
-    A8_REQUIRE(shm <= 64 * 1024, "a8_ctc_fwd_bwd: V=%d labels exceed the 8192 the per-frame LDS rows hold", V);
+    // scratch (A8_CTC_SCRATCH_FLOATS): alpha [B][T][64 spl] | beta [B][T][64 spl] | status i32 [B]
+    const size_t plane = (size_t)B * T_ * 64 * spl;
+    float* abuf = scratch;
+    float* bbuf = scratch + plane;
+    int32_t* status = reinterpret_cast<int32_t*>(scratch + 2 * plane);
+    const size_t shm_ab = sizeof(float) * (V > CTC_CHUNK ? (size_t)V : 2 * (size_t)CTC_CHUNK);
     hipStream_t s = (hipStream_t)stream;
-#define A8_CTC_LAUNCH(N) hipLaunchKernelGGL(ctc_kernel<N>, dim3(B), dim3(64), shm, s, lp, targets, tgt_off, in_len, nll, grad, alpha, T_, B, V, Lmax, blank, zero_infinity)
-    if (spl <= 1) A8_CTC_LAUNCH(1);
-    else if (spl <= 2) A8_CTC_LAUNCH(2);
-    else if (spl <= 4) A8_CTC_LAUNCH(4);
-    else if (spl <= 8) A8_CTC_LAUNCH(8);
-    else A8_CTC_LAUNCH(16);
+#define A8_CTC_LAUNCH(N) case N: hipLaunchKernelGGL(ctc_ab_kernel<N>, dim3(B, 2), dim3(64), shm_ab, s, lp, targets, tgt_off, in_len, nll, abuf, bbuf, status, T_, B, V, blank, zero_infinity); break;
+    switch (spl) {
+        A8_CTC_LAUNCH(1) A8_CTC_LAUNCH(2) A8_CTC_LAUNCH(3) A8_CTC_LAUNCH(4) A8_CTC_LAUNCH(5) A8_CTC_LAUNCH(6) A8_CTC_LAUNCH(7) A8_CTC_LAUNCH(8)
+        A8_CTC_LAUNCH(9) A8_CTC_LAUNCH(10) A8_CTC_LAUNCH(11) A8_CTC_LAUNCH(12) A8_CTC_LAUNCH(13) A8_CTC_LAUNCH(14) A8_CTC_LAUNCH(15)
+        default: hipLaunchKernelGGL(ctc_ab_kernel<16>, dim3(B, 2), dim3(64), shm_ab, s, lp, targets, tgt_off, in_len, nll, abuf, bbuf, status, T_, B, V, blank, zero_infinity); break;
+    }
 #undef A8_CTC_LAUNCH
-    return a8_check_launch("a8_ctc_fwd_bwd");
+    if (int e = a8_check_launch("a8_ctc_fwd_bwd (alpha / beta)")) return e;
+    hipLaunchKernelGGL(ctc_grad_kernel, dim3(T_, B), dim3(64), sizeof(float) * V, s, lp, targets, tgt_off, in_len, abuf, bbuf, status, grad, T_, B, V, spl, blank);
+    return a8_check_launch("a8_ctc_fwd_bwd (gradient)");
 }
 
 extern "C" int a8_ctc_greedy_decode(int dtype, const void* lp, const int32_t* in_len, int32_t* tokens, int32_t* out_len,

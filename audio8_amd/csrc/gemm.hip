@@ -855,8 +855,9 @@ extern "C" int a8_gemm(const a8_gemm_desc* d, void* stream) {
     if (const int r = a8i_gemm_stream_try(d, stream)) return r > 0 ? A8_OK : -r;
     // Asymmetric ring (a8_set_tuning key 14: 0 = never, otherwise the minimum M; 1 = every bf16 NT problem)
     if (d->dtype == A8_BF16 && d->layout == A8_GEMM_NT && g_a8_tuning[14] > 0 && d->M >= g_a8_tuning[14]) {
-        // whole k-tiles in every split and M, N >= 1: the lean-addressing instantiation (a8_set_tuning key 25 = 1: never)
-        if (g.K % 64 == 0 && g.kchunk % 64 == 0 && d->M >= 1 && g_a8_tuning[25] == 0) hipLaunchKernelGGL((gemm_a3_kernel<bf16, true>), dim3((int)grid), dim3(512), 0, s, g);
+        // at least one whole k-tile, whole k-tiles in every split and M, N >= 1: the lean-addressing instantiation (a8_set_tuning key 25 = 1: never).
+        // K = 0 (an empty reduction: C = bias / epilogue of zero) has no k-tile to clamp to and takes the predicate form, which reads the zero line
+        if (g.K >= 64 && g.K % 64 == 0 && g.kchunk % 64 == 0 && d->M >= 1 && g_a8_tuning[25] == 0) hipLaunchKernelGGL((gemm_a3_kernel<bf16, true>), dim3((int)grid), dim3(512), 0, s, g);
         else hipLaunchKernelGGL((gemm_a3_kernel<bf16, false>), dim3((int)grid), dim3(512), 0, s, g);
         return a8_check_launch("a8_gemm");
     }
@@ -904,7 +905,7 @@ extern "C" int a8_gemm_grouped(const a8_gemm_desc* descs, int n, void* stream) {
         for (int i = 0; i < n && a3; ++i) a3 = descs[i].M == 0 || descs[i].M >= g_a8_tuning[14];
         if (a3) {
             bool kfast = g_a8_tuning[25] == 0;
-            for (int i = 0; i < grp.n && kfast; ++i) kfast = grp.g[i].K % 64 == 0 && grp.g[i].kchunk % 64 == 0;
+            for (int i = 0; i < grp.n && kfast; ++i) kfast = grp.g[i].K >= 64 && grp.g[i].K % 64 == 0 && grp.g[i].kchunk % 64 == 0;      // (K = 0: nkb = 0, the lean form would address k-tile -1)
             if (kfast) hipLaunchKernelGGL((gemm_grouped_a3_kernel<bf16, true>), dim3((int)total), dim3(512), 0, s, grp);
             else hipLaunchKernelGGL((gemm_grouped_a3_kernel<bf16, false>), dim3((int)total), dim3(512), 0, s, grp);
             return a8_check_launch("a8_gemm_grouped");

@@ -518,7 +518,8 @@ def ctc_fwd_bwd(lp, targets_flat_i32, tgt_off_i32, in_len_i32, Smax, blank=0, ze
     T, B, V = lp.shape
     nll = torch.empty((B,), device=lp.device, dtype=torch.float32)
     grad = torch.empty_like(lp)
-    alpha = torch.empty((B, T, 2 * Smax + 2), device=lp.device, dtype=torch.float32)
+    # A8_CTC_SCRATCH_FLOATS(T, B, Smax): normalised log2 alpha | beta, [B][T][64 ceil((2 Smax + 1) / 64)] each, + a flag per utterance
+    alpha = torch.empty((2 * B * T * 64 * ((2 * Smax + 1 + 63) // 64) + B,), device=lp.device, dtype=torch.float32)
     L.check(L.lib().a8_ctc_fwd_bwd(L.ptr(_c(lp)), L.ptr(targets_flat_i32), L.ptr(tgt_off_i32), L.ptr(in_len_i32), L.ptr(nll), L.ptr(grad),
                                    L.ptr(alpha), T, B, V, Smax, blank, 1 if zero_infinity else 0, L.stream()), "a8_ctc_fwd_bwd")
     return nll, grad

@@ -680,8 +680,10 @@ def pin_host_cores(n=4, rank=None, world=None):
     world = max(1, int(os.environ.get("WORLD_SIZE", "1")) if world is None else world)
     rank = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0"))) if rank is None else rank
     cpus = sorted(os.sched_getaffinity(0))
-    per = max(1, len(cpus) // world)
-    mine = cpus[(rank % world) * per:(rank % world) * per + per][:n] or cpus[:n]
+    # NB: call this in the RANK process on the mask the launcher left it -- a launcher that pinned itself first hands every rank the same
+    # few cores (bench.py's launcher stays unpinned for that reason)
+    per = len(cpus) // world
+    mine = cpus[(rank % world) * per:(rank % world + 1) * per][:n] if per else [cpus[rank % len(cpus)]]
     os.sched_setaffinity(0, mine)
     torch.set_num_threads(len(mine))
     return mine

@@ -25,16 +25,41 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what 
 # launching thread of the SAME code is slower (host 9.5 vs 7.0 ms per step) and the step with it (11.86-11.92 vs 11.73-11.75 ms;
 # 16 cores / 16 threads: 12.3 ms) -- profiles/r05_host_affinity.txt.  --host-cores 0 leaves the process unpinned; --host-cores 1 / 2 is
 # the host-side stress of VERDICT r4 item 8b (the step must stay GPU-bound: host_ms_per_step < ms_per_step).
+def _early_arg(name, default):
+    """`--name V` or `--name=V` from argv, before argparse (the placement below must precede `import torch`)."""
+    for i, a in enumerate(sys.argv):
+        if a == name and i + 1 < len(sys.argv):
+            return sys.argv[i + 1]
+        if a.startswith(name + "="):
+            return a.split("=", 1)[1]
+    return default
+
+
+# The launcher (`--gpus N` with no rendezvous in the environment) must NOT pin itself: its children inherit its mask, and N ranks
+# slicing an already 4-core mask end up on the same four cores (ADVICE round 5).  It hands the host's full CPU list to its ranks in
+# A8_HOST_CPUS instead; a rank slices THAT list (or, started by an outside torchrun, the mask it inherited).
+IS_LAUNCHER = int(_early_arg("--gpus", "1")) > 1 and "WORLD_SIZE" not in os.environ
 ALL_CPUS = sorted(os.sched_getaffinity(0))
-HOST_CORES = 4
-if "--host-cores" in sys.argv:
-    HOST_CORES = int(sys.argv[sys.argv.index("--host-cores") + 1])
-if "--dry-run" in sys.argv:
-    HOST_CORES = 0
-if HOST_CORES > 0:
+if os.environ.get("A8_HOST_CPUS") and not IS_LAUNCHER:
+    try:
+        ALL_CPUS = sorted(int(c) for c in os.environ["A8_HOST_CPUS"].split(",") if c != "") or ALL_CPUS
+    except ValueError:
+        pass
+HOST_CORES = int(_early_arg("--host-cores", "0" if "--dry-run" in sys.argv else "4"))     # (a dry run pins only when asked to)
+
+
+def host_slice(cpus, world, rank, cores):
+    """The `cores` first CPUs of the rank's own 1/world slice of `cpus` (slices are disjoint; a slice shorter than `cores` is taken
+    whole; more ranks than CPUs: ranks share round-robin)."""
+    per = len(cpus) // max(1, world)
+    if per == 0:
+        return [cpus[rank % len(cpus)]]
+    return cpus[rank * per:(rank + 1) * per][:cores]
+
+
+if HOST_CORES > 0 and not IS_LAUNCHER:
     _w, _r = max(1, int(os.environ.get("WORLD_SIZE", "1"))), int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
-    _per = max(1, len(ALL_CPUS) // _w)
-    _mine = ALL_CPUS[(_r % _w) * _per:(_r % _w) * _per + _per][:HOST_CORES] or ALL_CPUS[:HOST_CORES]
+    _mine = host_slice(ALL_CPUS, _w, _r % _w, HOST_CORES)
     try:
         os.sched_setaffinity(0, _mine)
         os.environ["OMP_NUM_THREADS"] = str(len(_mine))
@@ -127,7 +152,9 @@ def spawn_ranks(n):
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4")))
+    # the ranks place themselves (prelude above) inside the launcher's UNPINNED mask, handed over explicitly
+    return subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4"),
+                                         A8_HOST_CPUS=",".join(str(c) for c in ALL_CPUS)))
 
 
 def dry_run(args):
@@ -141,12 +168,16 @@ def dry_run(args):
     if os.environ.get("A8_BENCH_FAIL_AFTER_INIT") == str(rank):
         raise RuntimeError("bench.py: injected failure of rank %d after init_process_group" % rank)
     t = torch.tensor([float(rank + 1)])
+    masks = [sorted(os.sched_getaffinity(0))]
     if world > 1:
         dist.all_reduce(t)
+        masks = [None] * world
+        dist.all_gather_object(masks, sorted(os.sched_getaffinity(0)))
         dist.barrier()
     if rank == 0:
         print(json.dumps({"metric": "dry run (launcher / rendezvous rehearsal, no GPU work)", "value": None, "n_gpus": world, "dry_run": True,
-                          "rank_sum": float(t.item()), "config": {"global_batch": world * args.batch, "parallelism": "dp%d" % world}}))
+                          "rank_sum": float(t.item()), "config": {"global_batch": world * args.batch, "parallelism": "dp%d" % world,
+                                                                  "host_cores": HOST_CORES, "rank_cpu_masks": masks}}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

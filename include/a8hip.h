@@ -280,7 +280,11 @@ int a8_contrastive_bwd(int dtype, const void* ctx, const void* lat, const int32_
 
 /* ---- CTC (F.ctc_loss native path, audio8/ctc.py:186-206) + log_softmax head (audio8/wav2vec2.py:770) ----
  * lp f32 [T,B,V] log-probs; targets i32 flat (PAD/EOS already stripped), tgt_off i32 [B+1]; nll f32 [B];
- * alpha is scratch f32 [B, T, 2*Smax+2]; grad f32 [T,B,V] = d nll_b / d lp (zero_infinity applied). */
+ * grad f32 [T,B,V] = d nll_b / d lp (zero_infinity applied); scratch: A8_CTC_SCRATCH_FLOATS(T, B, Smax) floats (the per-frame
+ * normalised log2 alpha and beta of every utterance + a feasibility flag each).  Two launches: alpha and beta recurse concurrently
+ * (one wave each per utterance, the log-probability rows staged through LDS ahead of the recurrence), then one wave per frame forms
+ * the posteriors and the gradient. */
+#define A8_CTC_SCRATCH_FLOATS(T, B, Smax) (2 * (size_t)(B) * (size_t)(T) * (64 * ((2 * (size_t)(Smax) + 1 + 63) / 64)) + (size_t)(B))
 /* targets i64 [B,S] padded with PAD / EOS (audio8/ctc.py:193-194 `targets.masked_select(pad_mask)`) -> flat i32 [<= B*S] and
  * tgt_off i32 [B+1] = exclusive prefix sum of target_lengths i32 [B]; everything on the device (the reference's masked_select
  * is a host sync).  Row b's labels land at tgt_off[b], cut at target_lengths[b]; status (optional, i32 [2]) = {rows whose count of
@@ -288,7 +292,7 @@ int a8_contrastive_bwd(int dtype, const void* ctx, const void* lat, const int32_
 int a8_ctc_pack_targets(const int64_t* targets, const int32_t* target_lengths, int32_t* flat, int32_t* tgt_off, int32_t* status,
                         int B, int S, int pad, int eos, void* stream);
 int a8_ctc_fwd_bwd(const float* lp, const int32_t* targets, const int32_t* tgt_off, const int32_t* in_len,
-                   float* nll, float* grad, float* alpha, int T, int B, int V, int Smax, int blank, int zero_infinity,
+                   float* nll, float* grad, float* scratch, int T, int B, int V, int Smax, int blank, int zero_infinity,
                    void* stream);
 /* greedy decode for the metrics (audio8/ctc.py:156-159): per utterance argmax over labels of frames [0, min(in_len, T)),
  * collapse repeats, drop blanks.  lp element (b,t,v) at b*stride_b + t*stride_t + v.  tokens i32 [B,T] (first out_len[b]

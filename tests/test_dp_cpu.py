@@ -312,6 +312,43 @@ def test_bench_gpus_8_dry_run_is_eight_ranks_and_one_json_line():
     assert out["n_gpus"] == 8 and out["rank_sum"] == 36.0 and out["config"]["global_batch"] == 64 and out["config"]["parallelism"] == "dp8"
 
 
+@pytest.mark.parametrize("form", ["--host-cores 2", "--host-cores=2"])
+def test_bench_launcher_leaves_every_rank_its_own_host_slice(form):
+    """the launcher used to pin ITSELF to four cores; its ranks inherited that mask and sliced it again, so all ranks sat on
+    the same cores.  Two ranks started through spawn_ranks must end up on disjoint masks of the requested size, whichever way argparse
+    would accept the flag, and the launcher's own mask must reach them whole (A8_HOST_CPUS)."""
+    import json
+    cpus = sorted(os.sched_getaffinity(0))
+    if len(cpus) < 4:
+        pytest.skip("needs >= 4 CPUs")
+    r = _bench(["--gpus", "2", "--dry-run"] + form.split())
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    m0, m1 = out["config"]["rank_cpu_masks"]
+    assert out["config"]["host_cores"] == 2 and len(m0) == 2 and len(m1) == 2, out
+    assert not set(m0) & set(m1), out
+    half = len(cpus) // 2
+    assert set(m0) <= set(cpus[:half]) and set(m1) <= set(cpus[half:2 * half]), (out, cpus)
+
+
+def test_host_slice_rule():
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    argv, sys.argv = sys.argv, ["bench.py", "--host-cores", "0"]           # importing bench.py runs its placement prelude: keep it off
+    try:
+        spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+        b = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(b)
+    finally:
+        sys.argv = argv
+    cpus = list(range(100, 116))
+    sl = [b.host_slice(cpus, 8, r, 4) for r in range(8)]
+    assert all(len(x) == 2 for x in sl) and sorted(sum(sl, [])) == cpus            # 16 CPUs / 8 ranks: two each, a partition
+    assert [b.host_slice(cpus, 1, 0, 4), b.host_slice(cpus, 2, 1, 4)] == [[100, 101, 102, 103], [108, 109, 110, 111]]
+    assert [b.host_slice([7, 9], 4, r, 4) for r in range(4)] == [[7], [9], [7], [9]]   # more ranks than CPUs: shared round-robin, never empty
+
+
 @pytest.mark.parametrize("when", ["A8_BENCH_FAIL_BEFORE_INIT", "A8_BENCH_FAIL_AFTER_INIT"])
 def test_bench_rank_failure_makes_the_launcher_exit_nonzero(when):
     """One rank raising -- before it reaches init_process_group, or after the group exists -- must end the whole launch with a

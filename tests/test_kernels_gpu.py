@@ -336,6 +336,53 @@ def test_attention_fwd_bwd(dtype, T, use_mask, attn_geometry):
     close(dbias, dbias0 + ref_b, tolb, "q/k/v bias gradients from the backward kernels")
 
 
+@pytest.mark.parametrize("dtype", DT)
+def test_attention_key_mask_shapes(dtype):
+    """Round 6: a key-padding mask that is a PREFIX of attended keys (what sequence_mask produces, audio8/train.py:33) runs as the unmasked
+    kernel over the attended keys -- key tiles beyond the prefix are never staged, dK/dV blocks beyond it store zeros -- and any other mask
+    (holes, nothing attended) keeps the per-key path.  Every shape must still equal masked_fill(-1e9) + softmax (audio8's eight_mile
+    attention): prefix lengths on, next to and far from the 64-key tile / 64-key block boundaries, one attended key, a full
+    row, a row with holes, and a row with no attended key at all (uniform attention over every key, as the reference's -1e9 fill gives)."""
+    from audio8_amd import kernels as K
+    T, H = 333, 2
+    d = H * 64
+    rows = []
+    for n in (1, 63, 64, 65, 128, 130, 300, 333):
+        m = torch.zeros(T, dtype=torch.uint8)
+        m[:n] = 1
+        rows.append(m)
+    holes = torch.ones(T, dtype=torch.uint8)
+    holes[10:20] = 0
+    holes[200:260] = 0
+    rows.append(holes)
+    late = torch.zeros(T, dtype=torch.uint8)          # attended keys that do not start at 0: not a prefix
+    late[100:180] = 1
+    rows.append(late)
+    rows.append(torch.zeros(T, dtype=torch.uint8))    # nothing attended
+    keymask = torch.stack(rows)
+    B = keymask.shape[0]
+    qkv = rnd((B * T, 3 * d), 11).to(dtype)
+    dout = rnd((B * T, d), 12).to(dtype)
+    f = qkv.float().view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    q, k, v = (f[i].clone().requires_grad_(True) for i in range(3))
+    oref = _attn_ref(q, k, v, keymask, 0.125)
+    oref.backward(dout.float().view(B, T, H, 64).permute(0, 2, 1, 3))
+    g = qkv.cuda()
+    km = keymask.cuda()
+    o, lse = K.attn_fwd(g[:, :d], g[:, d:2 * d], g[:, 2 * d:], B, T, H, 3 * d, 0.125, km)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    tolb = 1e-4 if dtype == torch.float32 else 3e-2
+    dq, dk, dv, _ = K.attn_bwd(g[:, :d], g[:, d:2 * d], g[:, 2 * d:], o, dout.cuda(), lse, B, T, H, 3 * d, 0.125, km)
+    for b in range(B):                                 # per utterance: an error in one mask shape must not hide in the batch norm
+        tag = "mask row %d (%d attended)" % (b, int(keymask[b].sum()))
+        close(o.view(B, T, H, 64)[b], oref.permute(0, 2, 1, 3)[b], tol, "o, " + tag)
+        close(dq.reshape(B, T, H, 64)[b], q.grad.permute(0, 2, 1, 3)[b], tolb, "dq, " + tag)
+        close(dk.reshape(B, T, H, 64)[b], k.grad.permute(0, 2, 1, 3)[b], tolb, "dk, " + tag)
+        close(dv.reshape(B, T, H, 64)[b], v.grad.permute(0, 2, 1, 3)[b], tolb, "dv, " + tag)
+    # masked keys of a prefix row get EXACTLY zero gradient (their dK/dV blocks are stored, not computed)
+    assert float(dk.reshape(B, T, H, 64)[2, 64:].abs().max()) == 0.0 and float(dv.reshape(B, T, H, 64)[2, 64:].abs().max()) == 0.0
+
+
 def test_attention_bf16_tolerance_detects_a_wrong_scale():
     """What the 16-bit bounds of test_attention_fwd_bwd are worth: the same bf16 kernels run with the softmax scale 10 % off (the kind of
     error a wrong 1 / sqrt(d_k) in one layer would be) must FAIL those bounds in the output and in every gradient, by a clear margin

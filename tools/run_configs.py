@@ -21,7 +21,11 @@ def synth(B, L, seed=1234):
     return (0.1 * torch.randn(B, L, generator=g)).clamp_(-1, 1)
 
 
-def timed(fn, warm=2, steps=5):
+STEPS = 5
+
+
+def timed(fn, warm=2, steps=None):
+    steps = steps or STEPS
     for _ in range(warm):
         v = fn()
     torch.cuda.synchronize()
@@ -76,6 +80,12 @@ def cfg5():
 
 
 if __name__ == "__main__":
+    # usage: run_configs.py [cfg4|cfg5|both] [timed steps]   (under rocprofv3: `-- python3 tools/run_configs.py cfg5 3`)
+    which = sys.argv[1] if len(sys.argv) > 1 else "both"
+    if len(sys.argv) > 2:
+        STEPS = int(sys.argv[2])
     ops.set_compute_dtype(torch.bfloat16)
-    cfg4()
-    cfg5()
+    if which in ("cfg4", "both"):
+        cfg4()
+    if which in ("cfg5", "both"):
+        cfg5()
