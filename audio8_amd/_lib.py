@@ -27,6 +27,8 @@ ARGTYPES = {
     "a8_encoder_layer_fwd": [C.c_void_p, C.c_void_p],
     "a8_encoder_layer_bwd": [C.c_void_p, C.c_void_p],
     "a8_set_tuning": [C.c_int, C.c_int],
+    "a8_get_tuning": [C.c_int, C.c_void_p],
+    "a8_delay_us": [C.c_float, C.c_void_p],
     "a8_prepare_weights": [C.c_int, C.c_void_p, C.c_int, C.c_void_p],
     "a8_prepare_weights_device": [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p],
     "a8_conv0_gn_gelu_fwd": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p],
@@ -75,6 +77,7 @@ ARGTYPES = {
 
 class GemmDesc(C.Structure):
     _fields_ = [
+        ("size", C.c_int),                       # sizeof(a8_gemm_desc): GEMM_DESC_SIZE below
         ("dtype", C.c_int), ("layout", C.c_int),
         ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
         ("A", C.c_void_p), ("lda", C.c_int64), ("a_rpb", C.c_int64), ("a_bs", C.c_int64),
@@ -90,14 +93,14 @@ class GemmDesc(C.Structure):
 
 
 class EncoderLayerDesc(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("dtype", "B", "T", "H", "d", "dff")] + [("p", C.c_float), ("eps", C.c_float)] + \
+    _fields_ = [(n, C.c_int) for n in ("size", "dtype", "B", "T", "H", "d", "dff")] + [("p", C.c_float), ("eps", C.c_float)] + \
                [(n, C.c_uint32) for n in ("seed_attn", "seed1", "seed2")] + [("b0", C.c_int)] + \
                [(n, C.c_void_p) for n in ("x", "keymask", "wqkv", "wo", "w1", "w2", "bqkv", "bo", "b1", "b2", "g1", "be1", "g2", "be2",
                                           "qkv", "o", "ao", "x1", "z1", "h", "f", "x2", "lse", "mean2", "rstd2", "mean1", "rstd1")]
 
 
 class EncoderLayerBwdDesc(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("dtype", "B", "T", "H", "d", "dff")] + [("p", C.c_float)] + \
+    _fields_ = [(n, C.c_int) for n in ("size", "dtype", "B", "T", "H", "d", "dff")] + [("p", C.c_float)] + \
                [(n, C.c_uint32) for n in ("seed_attn", "seed1", "seed2")] + [("b0", C.c_int)] + \
                [(n, C.c_void_p) for n in ("dx2", "x", "qkv", "o", "ao", "x1", "z1", "f", "keymask", "lse", "mean2", "rstd2", "mean1", "rstd1", "g1", "g2",
                                           "w2_t", "w1_t", "wo_t", "dg1", "dbe1", "dg2", "dbe2", "db2", "db1", "dbo",
@@ -109,7 +112,8 @@ class WPrepDesc(C.Structure):
                 ("tap", C.c_int), ("ld_dst", C.c_int), ("ld_dstT", C.c_int)]
 
 
-ABI_VERSION = 110            # include/a8hip.h: A8HIP_VERSION
+GEMM_DESC_SIZE, ENC_DESC_SIZE, ENC_BWD_DESC_SIZE = C.sizeof(GemmDesc), C.sizeof(EncoderLayerDesc), C.sizeof(EncoderLayerBwdDesc)
+ABI_VERSION = 120            # include/a8hip.h: A8HIP_VERSION
 
 
 def lib():
@@ -169,7 +173,7 @@ def require_cuda(*ts):
 
 
 EXPORTS = [
-    "a8_version", "a8_last_error", "a8_gemm", "a8_gemm_grouped", "a8_set_tuning", "a8_encoder_layer_fwd", "a8_encoder_layer_bwd", "a8_prepare_weights", "a8_prepare_weights_device",
+    "a8_version", "a8_last_error", "a8_gemm", "a8_gemm_grouped", "a8_set_tuning", "a8_get_tuning", "a8_delay_us", "a8_encoder_layer_fwd", "a8_encoder_layer_bwd", "a8_prepare_weights", "a8_prepare_weights_device",
     "a8_conv0_gn_gelu_fwd", "a8_conv0_gn_gelu_bwd", "a8_col2im_gelu_grad",
     "a8_layernorm_fwd", "a8_layernorm_bwd", "a8_layernorm_bwd_partial_rows", "a8_colsum_partials_reduce",
     "a8_cast", "a8_dropout", "a8_mask_fill_rows", "a8_mask_fill_rows_bwd", "a8_mask_zero_cols", "a8_zero_rows",

@@ -13,6 +13,7 @@ namespace {
 a8_gemm_desc nt_desc(int dtype, const void* A, const void* B, void* C, int M, int N, int K, const float* bias) {
     a8_gemm_desc d;
     std::memset(&d, 0, sizeof(d));
+    d.size = (int)sizeof(d);
     d.dtype = dtype; d.layout = A8_GEMM_NT;
     d.M = M; d.N = N; d.K = K;
     d.A = A; d.lda = K;
@@ -32,6 +33,7 @@ a8_gemm_desc nt_desc(int dtype, const void* A, const void* B, void* C, int M, in
 //   h = gelu(z1 = x1 W1^T + b1);  f = h W2^T + b2;  x2 = LN1(x1 + drop(f))
 extern "C" int a8_encoder_layer_fwd(const a8_encoder_layer_desc* e, void* stream) {
     A8_REQUIRE(e != nullptr, "a8_encoder_layer_fwd: null descriptor");
+    A8_REQUIRE(e->size == (int)sizeof(*e), "a8_encoder_layer_fwd: descriptor size %d, expected %d", e->size, (int)sizeof(*e));
     A8_REQUIRE(e->B > 0 && e->T > 0 && e->H > 0 && e->d == e->H * 64 && e->dff > 0 && e->b0 >= 0, "a8_encoder_layer_fwd: bad sizes B=%d T=%d H=%d d=%d dff=%d b0=%d",
                e->B, e->T, e->H, e->d, e->dff, e->b0);
     const int M = e->B * e->T, d = e->d, esz = e->dtype == A8_BF16 ? 2 : 4;
@@ -63,6 +65,7 @@ extern "C" int a8_encoder_layer_fwd(const a8_encoder_layer_desc* e, void* stream
 // (pass the same pointers).
 extern "C" int a8_encoder_layer_bwd(const a8_encoder_layer_bwd_desc* e, void* stream) {
     A8_REQUIRE(e != nullptr, "a8_encoder_layer_bwd: null descriptor");
+    A8_REQUIRE(e->size == (int)sizeof(*e), "a8_encoder_layer_bwd: descriptor size %d, expected %d", e->size, (int)sizeof(*e));
     A8_REQUIRE(e->B > 0 && e->T > 0 && e->H > 0 && e->d == e->H * 64 && e->dff > 0, "a8_encoder_layer_bwd: bad sizes B=%d T=%d H=%d d=%d dff=%d",
                e->B, e->T, e->H, e->d, e->dff);
     A8_REQUIRE(e->p > 0.f || (e->dx1_res == e->df && e->dx_res == e->dao), "a8_encoder_layer_bwd: with p = 0, dx1_res / dx_res must alias df / dao");

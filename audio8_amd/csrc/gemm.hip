@@ -803,6 +803,8 @@ extern "C" int a8_debug_set_stamps(void* p) { g_stamps = (unsigned long long*)p;
 // validates one descriptor and fills the kernel arguments; *grid = blocks it needs
 static int build_args(const a8_gemm_desc* d, GemmArgs& g, long long* grid) {
     A8_REQUIRE(d != nullptr, "a8_gemm: null descriptor");
+    A8_REQUIRE(d->size == (int)sizeof(a8_gemm_desc), "a8_gemm: descriptor size %d, this library's a8_gemm_desc has %d bytes (binding built against another a8hip.h)",
+               d->size, (int)sizeof(a8_gemm_desc));
     A8_REQUIRE(d->dtype == A8_F32 || d->dtype == A8_BF16, "a8_gemm: bad dtype %d", d->dtype);
     A8_REQUIRE(d->M >= 0 && d->N > 0 && d->K >= 0, "a8_gemm: bad sizes M=%d N=%d K=%d", d->M, d->N, d->K);
     const int esz = d->dtype == A8_BF16 ? 2 : 4, epc = 16 / esz;

@@ -510,6 +510,7 @@ extern "C" int a8_contrastive_bwd(int dtype, const void* ctx, const void* lat, c
         for (int i = 0; i < cnt; ++i) {
             const size_t off = (size_t)(g0 + i) * rpg;
             d[i] = a8_gemm_desc{};
+            d[i].size = (int)sizeof(a8_gemm_desc);
             d[i].dtype = dtype; d[i].layout = A8_GEMM_TN; d[i].M = rpg4; d[i].N = 256; d[i].K = rpg;
             d[i].A = (const char*)amat + off * rpg4 * esz; d[i].lda = rpg4;
             d[i].B = (const char*)bmat + off * 256 * esz; d[i].ldb = 256;

@@ -41,7 +41,7 @@ def _gemm_desc(layout, A, B, M, N, K, *, out=None, out_dtype=None, lda=None, ldb
         out = torch.empty((M, N), device=A.device, dtype=out_dtype or A.dtype)
     esz = A.element_size()
     # one positional construction (field order of include/a8hip.h): a third of the host time of thirty attribute stores
-    d = L.GemmDesc(dtype, layout, M, N, K,
+    d = L.GemmDesc(L.GEMM_DESC_SIZE, dtype, layout, M, N, K,
                    A.data_ptr() + a_off * esz, lda, a_rpb, a_bs,
                    B.data_ptr(), ldb, b_rpb, b_bs,
                    out.data_ptr() + c_off * out.element_size(), ldc, c_rpb, c_bs,
@@ -88,7 +88,7 @@ def encoder_layer_fwd(x, keymask, B, T, H, p, eps, seeds, wqkv, bqkv, wo, bo, w1
     def desc(b0, nb):
         """descriptor of utterances [b0, b0 + nb): every buffer advanced to their rows"""
         r0, es = b0 * T, x.element_size()
-        return L.EncoderLayerDesc(L.dt(x), nb, T, H, d, dff, p, eps, _u32(seeds[0]), _u32(seeds[1]), _u32(seeds[2]), b0,
+        return L.EncoderLayerDesc(L.ENC_DESC_SIZE, L.dt(x), nb, T, H, d, dff, p, eps, _u32(seeds[0]), _u32(seeds[1]), _u32(seeds[2]), b0,
                                   x.data_ptr() + r0 * d * es, keymask.data_ptr() + b0 * T if keymask is not None else None,
                                   wqkv.data_ptr(), wo.data_ptr(), w1.data_ptr(), w2.data_ptr(),
                                   bqkv.data_ptr(), bo.data_ptr(), b1.data_ptr(), b2.data_ptr(), g1.data_ptr(), be1.data_ptr(), g2.data_ptr(), be2.data_ptr(),
@@ -145,7 +145,7 @@ def encoder_layer_bwd(dx2, x, keymask, qkv, o, lse, ao, x1, mean2, rstd2, z1, f,
         r0 = b0 * T
         rd, rf = r0 * d * es, r0 * dff * es
         wp = [ws[k].data_ptr() + prow0[i] * 3 * d * 4 for k in (0, 1)] if ws is not None else [None, None]
-        return L.EncoderLayerBwdDesc(L.dt(x), nb, T, H, d, dff, p, _u32(seeds[0]), _u32(seeds[1]), _u32(seeds[2]), b0,
+        return L.EncoderLayerBwdDesc(L.ENC_BWD_DESC_SIZE, L.dt(x), nb, T, H, d, dff, p, _u32(seeds[0]), _u32(seeds[1]), _u32(seeds[2]), b0,
                                      dx2.data_ptr() + rd, x.data_ptr() + rd, qkv.data_ptr() + 3 * rd, o.data_ptr() + rd, ao.data_ptr() + rd,
                                      x1.data_ptr() + rd, z1.data_ptr() + rf, f.data_ptr() + rd,
                                      keymask.data_ptr() + r0 if keymask is not None else None,

@@ -866,6 +866,12 @@ class EncoderLayerFn(torch.autograd.Function):
             # no prepared weight copies (no Stepper): the casts above were enqueued on this stream just now, and the half-batch stream
             # only met this one at the top of the stack
             HALF_STREAM.wait_stream(torch.cuda.current_stream())
+            # ... and they are temporaries: under no_grad nothing keeps them alive past this call, so without a note to the allocator
+            # the next layer's casts could be handed their memory while the half-batch stream still reads it (round 6: the bf16 eval-mode
+            # acoustic model without a Stepper decoded differently from run to run, tests/test_parity_hardening_gpu.py)
+            for w_ in (wqkv_c, wo_c, w1_c, w2_c, bqkv):
+                if w_ is not None and w_.is_cuda:
+                    w_.record_stream(HALF_STREAM)
         if COMPOSITE_ENCODER_FWD and K.GEMM_PROFILE is None and x.is_contiguous():
             # the whole launch sequence below behind one C call (a8_encoder_layer_fwd); the per-launch path stays for the instrumented
             # roofline steps of bench.py (per-GEMM events) and as the readable statement of the sequence

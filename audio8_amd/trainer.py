@@ -213,8 +213,11 @@ class GradReducer:
         # close() restores the value found here
         self._stream_grid_saved = None
         if self.on_gpu and os.environ.get("A8_STREAM_GRID", "") != "":
+            import ctypes
             from . import _lib as L
-            self._stream_grid_saved = 1
+            found = ctypes.c_int(0)
+            L.check(L.lib().a8_get_tuning(8, ctypes.addressof(found)), "a8_get_tuning")
+            self._stream_grid_saved = int(found.value)               # (whatever the caller or A8_TUNE had set: restored by Stepper.close())
             L.check(L.lib().a8_set_tuning(8, int(os.environ["A8_STREAM_GRID"])), "a8_set_tuning")
         # RCCL enqueues a collective on the stream it is issued from, so kernels behind it on that stream see the reduced data;
         # gloo (CPU rehearsals of the GPU path) completes on its own threads: only wait() orders it

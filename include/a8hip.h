@@ -19,10 +19,12 @@
 extern "C" {
 #endif
 
-/* Bumped whenever a descriptor struct's layout or an entry point's meaning changes (round 4 appended ln1_partials / ln2_partials to
- * a8_encoder_layer_bwd_desc without doing so).  A binding built against another value must refuse to load: the descriptors carry no
- * size field, a shorter struct would be read past its end.  audio8_amd/_lib.py checks a8_version() == the value it was written for. */
-#define A8HIP_VERSION 110
+/* Bumped whenever a descriptor struct's layout or an entry point's meaning changes.  A binding built against another value must refuse
+ * to load (audio8_amd/_lib.py checks a8_version() == the value it was written for).  Since 120 every descriptor struct also starts with
+ * `size` = sizeof(the struct as the CALLER compiled it): an entry point returns A8_ERR_ARG instead of reading a shorter or longer struct
+ * than its own (120: size fields; a8_ctc_fwd_bwd's scratch grew to A8_CTC_SCRATCH_FLOATS; a8_get_tuning, a8_delay_us,
+ * a8_encoder_stack_bwd). */
+#define A8HIP_VERSION 120
 
 enum { A8_DT_F32 = 0, A8_DT_BF16 = 1 };
 enum { A8_GEMM_NT = 0, A8_GEMM_NN = 1, A8_GEMM_TN = 2 };
@@ -41,6 +43,7 @@ const char* a8_last_error(void);      /* thread-local text of the last non-zero 
  * written once, by the same lane); they must not otherwise overlap A, B or zin.  The library sends an aliased problem to the
  * 128 x 128 kernels (the stream kernel's shifted last tile stores some rows twice). */
 typedef struct a8_gemm_desc {
+    int size;                             /* sizeof(a8_gemm_desc) */
     int dtype, layout;
     int M, N, K;
     const void* A; int64_t lda, a_rpb, a_bs;
@@ -75,6 +78,14 @@ int a8_gemm_grouped(const a8_gemm_desc* descs, int n, void* stream);
  * co-running streams); 20 / 21 AdamW grid / cache policy; 22 = 1: LDS-staged epilogue in the 128 x 128 NT kernels; 23 = 1: residual add in the
  * FFN data gradient's epilogue; 25 = 1: predicate-form operand addressing in the 128 x 128 NT kernels. */
 int a8_set_tuning(int key, int value);
+/* The knobs are PROCESS-WIDE (one table per loaded library): they choose among kernel variants with bit-identical results, so models or
+ * threads sharing a process can only affect each other's speed.  Reads and writes are atomic; a change applies to launches issued after
+ * a8_set_tuning returns.  a8_get_tuning reads a key back (so that a caller can restore what it found). */
+int a8_get_tuning(int key, int* value);
+/* Measurement helper: one wave that holds `stream` for `us` microseconds of wall clock -- the stand-in for a collective's transport
+ * time when the exposed (un-overlapped) part of the gradient exchange is measured on one GPU (audio8/pretrain.py:152-159,179: DDP's
+ * bucketed all-reduce under backward).  No memory traffic, one wave slot. */
+int a8_delay_us(float us, void* stream);
 
 /* ---- per-step weight preparation (the f32 -> compute-dtype casts the reference's autocast-free f32 path never needs;
  * conv kernels [rows][cols/kw][kw] are re-laid-out to [rows][kk*(cols/kw) + ci]).  dst [rows][cols] and/or dstT [cols][rows]. */
@@ -183,6 +194,7 @@ int a8_attn_bwd(int dtype, const void* q, const void* k, const void* v, const vo
  * x, qkv [M,3d], o, ao, x1, f, x2 [M,d], z1, h [M,dff] in dtype; lse f32 [B,H,T]; mean / rstd f32 [M]; weights in dtype, row-major
  * [out,in] (wqkv = [3d,d]); biases and LayerNorm parameters f32.  Seeds as a8_attn_fwd / a8_layernorm_fwd take them (p = 0: unused). */
 typedef struct a8_encoder_layer_desc {
+    int size;                /* sizeof(a8_encoder_layer_desc) */
     int dtype, B, T, H, d, dff;
     float p, eps;
     uint32_t seed_attn, seed1, seed2;
@@ -204,6 +216,7 @@ int a8_encoder_layer_fwd(const a8_encoder_layer_desc* e, void* stream);
  * Written: df, dz1, dx1_ffn, dao, dout_o, dqkv [M,3d], delta f32 [B,H,T], and with p > 0 dx1_res, dx_res (p = 0: pass df / dao again).
  * The weight gradients and the QKV data gradient (dx = dqkv Wqkv + dx_res) are the caller's. */
 typedef struct a8_encoder_layer_bwd_desc {
+    int size;                /* sizeof(a8_encoder_layer_bwd_desc) */
     int dtype, B, T, H, d, dff;
     float p;
     uint32_t seed_attn, seed1, seed2;

@@ -14,7 +14,9 @@ def main():
     # holds model set-up copies and every kernel's first launch, which includes loading its code object)
     trace = list(csv.DictReader(open(tr)))
     trace.sort(key=lambda r: int(r["Start_Timestamp"]))
-    ends = [i for i, r in enumerate(trace) if "adamw" in r["Kernel_Name"]]
+    # one optimizer step = one sumsq_final launch (AdamW itself is one launch per run of parameters that have a gradient: two or more
+    # per step with a frozen feature extractor, cfg5); traces without the fused norm fall back to the AdamW launches
+    ends = [i for i, r in enumerate(trace) if "sumsq_final" in r["Kernel_Name"]] or [i for i, r in enumerate(trace) if "adamw" in r["Kernel_Name"]]
     steady, nst = trace[ends[0] + 1: ends[-1] + 1], len(ends) - 1
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in steady:

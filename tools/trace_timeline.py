@@ -12,7 +12,7 @@ def main():
     rows = list(csv.DictReader(open(glob.glob(d + "/*kernel_trace.csv")[0])))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     # split steps by adamw launches
-    ends = [i for i, r in enumerate(rows) if "adamw" in r["Kernel_Name"]]
+    ends = [i for i, r in enumerate(rows) if "sumsq_final" in r["Kernel_Name"]] or [i for i, r in enumerate(rows) if "adamw" in r["Kernel_Name"]]
     if len(ends) >= 4:
         analyse(rows[ends[-4] + 1:ends[-3] + 1], "last timed step")
     analyse(rows[ends[-2] + 1:ends[-1] + 1], "last step (instrumented)")
