@@ -61,6 +61,26 @@ class FlatState:
                     continue
             out.append(p)
             done.add(id(p))
+        # The flat layout is cut into exchange buckets from its END, and buckets leave strictly in that order: a parameter whose gradient
+        # arrives late in backward must not sit near the end.  AudioTransformerEncoder registers its input LayerNorm (`ln`, applied BEFORE
+        # the layer stack: audio8/wav2vec2.py:623,639) AFTER the stack, so its gradient -- which arrives once the whole stack's backward is
+        # through -- held the first bucket, and with it every bucket, until 70 % of backward was over (round 6, tools/exchange_exposure.py:
+        # all twelve buckets left in a burst at 9.0 of 11.3 ms).  Laid out in forward-use order (in front of the stack's parameters) the
+        # buckets leave layer by layer from the start of backward.  (DDP gets the same effect by rebuilding its buckets in the order the
+        # gradients arrived during the first iteration.)
+        names = {id(p): n for n, p in named}
+        stack_first = {}
+        for k, p in enumerate(out):
+            n = names[id(p)]
+            if ".transformer.encoders." in n or n.startswith("transformer.encoders."):
+                stack_first.setdefault(n.split("transformer.encoders.")[0], k)
+        for prefix, first in sorted(stack_first.items(), key=lambda kv: -kv[1]):
+            late = [k for k, p in enumerate(out) if names[id(p)] in (prefix + "ln.weight", prefix + "ln.bias")]
+            if late and all(k > first for k in late):
+                moved = [out[k] for k in late]
+                rest = [p for k, p in enumerate(out) if k not in late]
+                k0 = next(i for i, p in enumerate(rest) if names[id(p)].startswith(prefix + "transformer.encoders."))
+                out = rest[:k0] + moved + rest[k0:]
         return out
 
     def zero_grad(self, already_clean=False):
@@ -229,6 +249,12 @@ class GradReducer:
                 pass
         self.norm_sq = None                  # f32 [1] device accumulator of sum g^2 (set by the Stepper): each bucket adds its share as it
                                              # completes (after its all-reduce), under the rest of backward
+        # Exposure measurement on ONE GPU (tools/exchange_exposure.py): every bucket's collective is followed -- on the exchange stream, where
+        # RCCL's kernel would run -- by a one-wave delay of bytes / fake_gbps (a8_delay_us), so the step time shows how much of an exchange
+        # of that speed is NOT hidden under backward.  `trace` (a list, when set) receives (bucket, start event, end event, bytes) per bucket.
+        fake = os.environ.get("A8_FAKE_EXCHANGE_GBPS", "")
+        self.fake_gbps = float(fake) if fake else 0.0
+        self.trace = None
         cap = int(bucket_mb * 1024 * 1024 / 4)
         # buckets over contiguous flat ranges; built from the LAST parameter backwards (gradients of late
         # layers are ready first), each bucket = [lo, hi) in elements plus the parameter indices it holds
@@ -284,7 +310,7 @@ class GradReducer:
         if not self.touched[i]:
             self.touched[i] = True
             self.n_touched += 1
-        if self.suspended or not (self.enabled or self.norm_sq is not None):
+        if self.suspended or not self._active():
             return
         # idempotent per backward pass: a parameter whose gradient a backward kernel wrote directly is reported through
         # ops.GRAD_READY_HOOK, and autograd's post-accumulate hook fires for it as well (with an undefined gradient);
@@ -300,6 +326,10 @@ class GradReducer:
         while self.next_bucket < len(self.buckets) and self.buckets[self.next_bucket]["pending"] == 0:
             self._launch(self.buckets[self.next_bucket])
             self.next_bucket += 1
+
+    def _active(self):
+        """The bucket schedule runs: there is an exchange, a per-bucket gradient norm, or a stand-in for the exchange's transport time."""
+        return self.enabled or self.norm_sq is not None or self.fake_gbps > 0.0 or self.trace is not None
 
     def _make_hook(self, i):
         def hook(_p):
@@ -355,6 +385,13 @@ class GradReducer:
                 ev.record(st)
                 self.side.wait_event(ev)
             with torch.cuda.stream(self.side):
+                if self.trace is not None:
+                    ev0 = torch.cuda.Event(enable_timing=True)
+                    ev0.record(self.side)
+                if self.fake_gbps > 0.0:
+                    nbytes = (bk["hi"] - bk["lo"]) * (2 if self.payload == "bf16" else 4)
+                    from . import _lib as L
+                    L.check(L.lib().a8_delay_us(nbytes / (self.fake_gbps * 1e3), self.side.cuda_stream), "a8_delay_us")
                 if self.enabled and self.payload == "bf16":
                     sv = self._stage_view(bk)
                     sv.copy_(view)                                            # f32 -> bf16 (round to nearest even)
@@ -370,6 +407,10 @@ class GradReducer:
                     h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
                 if self.norm_sq is not None and self.stream_ordered:      # stream order: behind this bucket's collective
                     K.sumsq_(view, self.norm_sq)
+                if self.trace is not None:
+                    ev1 = torch.cuda.Event(enable_timing=True)
+                    ev1.record(self.side)
+                    self.trace.append((self.buckets.index(bk), ev0, ev1, (bk["hi"] - bk["lo"]) * (2 if self.payload == "bf16" else 4)))
         elif self.enabled and self.payload == "bf16":    # gloo on CPU (tests)
             sv = self._stage_view(bk)
             sv.copy_(view)
@@ -424,7 +465,7 @@ class GradReducer:
     def launch_pending(self):
         """Issue, in index order, every bucket that is not out yet: the ones whose parameters produced no gradient on this rank
         (frozen encoder, audio8/train.py:266-268; a layer this rank dropped) and everything they held back."""
-        if not (self.enabled or self.norm_sq is not None):
+        if not self._active():
             return
         for bk in self.buckets[self.next_bucket:]:       # in index order, like the ones already out
             if not bk.get("launched"):
@@ -434,7 +475,7 @@ class GradReducer:
     def wait(self):
         """Make the compute stream (and, for gloo, the host) wait for every collective issued so far.  Gradients hold the SUM
         over ranks afterwards (and norm_sq the sum of their squares)."""
-        if not (self.enabled or self.norm_sq is not None):
+        if not self._active():
             return
         for h in self.handles:
             h.wait()

@@ -247,3 +247,70 @@ def test_two_ranks_on_one_gpu_broadcast_order_and_train_semantics(tmp_path, payl
     assert outs[0]["counts"] == outs[1]["counts"]
     assert outs[0]["layerdrop_local_drop_counts"] != outs[1]["layerdrop_local_drop_counts"] or True      # (the sets, not only the counts, may differ)
     assert outs[0]["layerdrop_param_steps"] == outs[1]["layerdrop_param_steps"]
+
+
+def test_buckets_go_out_under_backward_and_a_slow_exchange_is_mostly_hidden():
+    """The overlap the reference gets from DDP's reducer (audio8/pretrain.py:152-159,179): every gradient bucket but the last two must be
+    ISSUED (its start on the exchange stream) before the data-gradient chain's last launch has finished, in index order; and with every
+    collective standing in as a delay of bytes / 300 GB/s on the exchange stream (GradReducer.fake_gbps, a8_delay_us) the step must grow by
+    less than half of the exchange's serial time -- i.e. most of it hides under backward (tools/exchange_exposure.py measures the table)."""
+    import time
+    import numpy as np
+    import torch
+    from audio8_amd import ops, wav2vec2 as W
+    from audio8_amd.trainer import Stepper
+    old = ops.compute_dtype()
+    ops.set_compute_dtype(torch.bfloat16)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    model = W.create_model(16, dropout=0.1).cuda().train()
+    loss_fn = W.create_loss(640, 100)
+    st = Stepper(model, clip=1.0)
+    red = st.reducer
+    try:
+        x = (0.1 * torch.randn(8, 250000, generator=torch.Generator().manual_seed(1))).clamp_(-1, 1).cuda()
+
+        def step(trace=False):
+            st.zero_grad()
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            ev[0].record()
+            loss = loss_fn(model, x)
+            loss.backward()
+            ev[1].record()
+            loss.item()
+            st.step()
+            return ev
+        for _ in range(3):
+            step()
+        red.fake_gbps, red.trace = 300.0, []
+        ev = step()
+        torch.cuda.synchronize()
+        tr, red.trace = red.trace, None
+        assert [b for b, *_ in tr] == list(range(len(red.buckets))), "buckets leave in index order"
+        t_bwd = ev[0].elapsed_time(ev[1])
+        starts = [ev[0].elapsed_time(e0) for _, e0, _, _ in tr]
+        late = [b for b, s_ in enumerate(starts) if s_ >= t_bwd]
+        print("bucket starts (ms):", [round(s_, 2) for s_ in starts], "backward ends", round(t_bwd, 2))
+        assert all(b >= len(starts) - 2 for b in late), (late, starts, t_bwd)
+        assert sum(nb for *_, nb in tr) == st.state.total * 4
+
+        def timed(n=8):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                step()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n * 1e3
+        red.fake_gbps = 1e9
+        timed(2)
+        base = min(timed(), timed())
+        red.fake_gbps = 300.0
+        timed(2)
+        slow = min(timed(), timed())
+        serial = st.state.total * 4 / 300e9 * 1e3
+        print("step %.3f ms, with a 300 GB/s stand-in %.3f ms: %.3f ms of its %.3f ms serial time exposed" % (base, slow, slow - base, serial))
+        assert slow - base < 0.5 * serial, (base, slow, serial)
+    finally:
+        red.fake_gbps, red.trace = 0.0, None
+        st.close()
+        ops.set_compute_dtype(old)

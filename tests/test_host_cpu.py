@@ -267,3 +267,27 @@ def test_pin_host_cores_takes_the_ranks_own_slice():
     finally:
         os.sched_setaffinity(0, before)
         torch.set_num_threads(threads)
+
+
+def test_flat_layout_keeps_late_gradients_out_of_the_first_buckets():
+    """trainer.FlatState lays parameters out in forward-use order: exchange buckets are cut from the END of the layout and leave in that
+    order, so the encoder's input LayerNorm (`ln`: registered after the layer stack, audio8/wav2vec2.py:613-623, but applied before it --
+    its gradient arrives when the whole stack's backward is through) must sit in FRONT of the stack's parameters, next to the positional
+    conv; each block's w_Q / w_K / w_V stay adjacent (the fused QKV product addresses them as one matrix)."""
+    from audio8_amd import wav2vec2 as W
+    from audio8_amd.trainer import FlatState
+    for model in (W.create_model(16, num_layers=3), W.create_acoustic_model(32, 16, num_layers=3)):
+        for p in model.parameters():
+            p.requires_grad_(True)
+        names = {id(p): n for n, p in model.named_parameters()}
+        order = [names[id(p)] for p in FlatState._ordered(model)]
+        assert sorted(order) == sorted(names.values())                       # a permutation: nothing lost, nothing twice
+        ln = [k for k, n in enumerate(order) if n.endswith("encoder.ln.weight") or n.endswith("encoder.ln.bias")]
+        stack = [k for k, n in enumerate(order) if "transformer.encoders." in n]
+        posconv = [k for k, n in enumerate(order) if "pos_conv" in n]
+        assert len(ln) == 2 and max(posconv) < min(ln) and max(ln) < min(stack), order
+        assert stack == list(range(min(stack), max(stack) + 1))              # the stack's parameters stay one contiguous run
+        for k, n in enumerate(order):
+            if n.endswith("w_Q.layer.weight"):
+                stem = n[:-len("w_Q.layer.weight")]
+                assert order[k:k + 6] == [stem + f"w_{c}.layer.{leaf}" for leaf in ("weight", "bias") for c in "QKV"]
