@@ -964,6 +964,452 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd32_kernel(const AttnP P) {
     if (q_ok && hh == 0) P.lse[(long long)bh * P.T + q] = m + log2f(l);       // log2-domain log-sum-exp
 }
 
+// ================================================================== backward, 16-bit: 32x32x16 MFMA (round 6)
+// The 16 x 16 backward kernels above read every staged operand tile twice per 16-row wave tile (row fragments for S / dP, transposed
+// fragments for dV / dK or dQ: 0.75 KB of LDS reads per MFMA), stage through registers with a block barrier per tile, and fetch the
+// softmax statistics of a key-stationary block from LDS per 16 x 16 fragment.  These two kernels are the forward's geometry
+// (attn_fwd32_kernel) applied to the backward products:
+//   * a wave owns 32 queries (dQ) / 32 keys (dK, dV) and multiplies on v_mfma_f32_32x32x16_bf16: half the LDS operand bytes per FLOP,
+//     an MFMA blocks the vector issue for 8 of its 32 cycles instead of 8 of 16;
+//   * dQ: S^T = K Q^T and dP^T = V dO^T with lane = query, so lse / delta are one register each and a dropout word covers four
+//     consecutive registers (as in the forward); dK / dV: S = Q K^T and dP = dO V^T with lane = key, K and V stationary in registers as
+//     the B operands; in both, the score registers 8 s .. 8 s + 7 ARE the B operand of the following product for 16-row step s;
+//   * operand tiles arrive by LDS-DMA into a 3-deep ring (one barrier per 64-row tile, two tiles in flight, no staging registers);
+//   * ONE LDS image per tile serves both read patterns: 128-byte rows, 16-byte chunk c of row r at c ^ swz3((r >> 1) & 7).  Row reads
+//     (b128, 16 consecutive rows per quarter wave) need the keys of same-parity rows distinct: any bijection of (r >> 1) & 7.  Transposed
+//     reads (ds_read_b64_tr_b16: a half-wave covers 8 consecutive rows x 64 bytes) need the keys' bit 2 to alternate over rows r, r + 2 of
+//     an aligned group of 8: swz3 swaps bits 0 and 2.  (Round 3's 32 x 32 dQ kernel kept two K images and lost to the 16 x 16 one.)
+//   * the transposed reads are inline assembly with their own lgkmcnt wait: in front of the builtin hipcc drains every LDS-DMA in flight.
+// Dropout words, seeds and masks are those of the kernels above; results agree with them to bf16 rounding of P / dS (same products,
+// another summation order).
+A8_DEV int swz3(int t) { return ((t & 1) << 2) | (t & 2) | ((t >> 2) & 1); }
+A8_DEV u32x2 lds_tr64(unsigned addr) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+A8_DEV void attn_glds4(const char* src, char* lds_dst_wave_uniform) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_dst_wave_uniform, 4, 0, 0);
+}
+A8_DEV uint32_t pack2(float a, float b) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, (bf16x2){(bf16)a, (bf16)b});
+}
+A8_DEV bf16x8 pack8(const f32x16& v, int o) {
+    return (bf16x8){(bf16)v[o], (bf16)v[o + 1], (bf16)v[o + 2], (bf16)v[o + 3], (bf16)v[o + 4], (bf16)v[o + 5], (bf16)v[o + 6], (bf16)v[o + 7]};
+}
+// acc[db][i] = value of (row = lane & 31 of the wave's 32, column 32 db + (i & 3) + 8 (i >> 2) + 4 (lane >> 5)), scaled, as bf16 rows of 64:
+// one permlane32 swap per register pair gives every lane 8 consecutive columns (16-byte stores), as in the forward's epilogue
+A8_DEV void store_rows32(bf16* rowp /* + 8 * hh */, const f32x16 (&acc)[2], float sc, bool ok) {
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int mq = 0; mq < 4; mq += 2) {
+            u32x2 a = __builtin_bit_cast(u32x2, (bf16x4){(bf16)(acc[db][4 * mq] * sc), (bf16)(acc[db][4 * mq + 1] * sc), (bf16)(acc[db][4 * mq + 2] * sc), (bf16)(acc[db][4 * mq + 3] * sc)});
+            u32x2 c = __builtin_bit_cast(u32x2, (bf16x4){(bf16)(acc[db][4 * mq + 4] * sc), (bf16)(acc[db][4 * mq + 5] * sc), (bf16)(acc[db][4 * mq + 6] * sc), (bf16)(acc[db][4 * mq + 7] * sc)});
+            auto x0 = __builtin_amdgcn_permlane32_swap(a[0], c[0], false, false);
+            auto x1 = __builtin_amdgcn_permlane32_swap(a[1], c[1], false, false);
+            const u32x4 v = {x0[0], x1[0], x0[1], x1[1]};
+            if (ok) *reinterpret_cast<u32x4*>(rowp + 32 * db + 8 * mq) = v;
+        }
+}
+
+// ---- dQ (query block stationary): streams K / V tiles of 64 keys
+template <int NW, bool DROP>
+__global__ __launch_bounds__(NW * 64, 3) void attn_bwd_q32_kernel(const AttnP P) {
+    constexpr int BQ = NW * 32, NBUF = 3;
+    __shared__ __attribute__((aligned(1024))) char lds[NBUF * F32_TILE + 1024];
+    const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int blk, bh;
+    block_coords((P.T + BQ - 1) / BQ, P.B * P.H, blk, bh);
+    const int b = bh / P.H, h = bh % P.H;
+    const bf16* qb = reinterpret_cast<const bf16*>(P.q) + (long long)b * P.T * P.ld_qkv + h * DH;
+    const char* kb_ = reinterpret_cast<const char*>(reinterpret_cast<const bf16*>(P.k) + (long long)b * P.T * P.ld_qkv + h * DH);
+    const char* vb_ = reinterpret_cast<const char*>(reinterpret_cast<const bf16*>(P.v) + (long long)b * P.T * P.ld_qkv + h * DH);
+    const bf16* dob = reinterpret_cast<const bf16*>(P.dout) + (long long)b * P.T * P.ld_o + h * DH;
+    const bf16* ob = reinterpret_cast<const bf16*>(P.o) + (long long)b * P.T * P.ld_o + h * DH;
+    const uint8_t* km = P.keymask ? P.keymask + (long long)b * P.T : nullptr;
+    const int ntiles = (P.T + BT - 1) / BT;
+    const long long row_bytes = P.ld_qkv * 2, tile_bytes = (long long)BT * row_bytes;
+    MaskScan ms;
+    if (km) ms.load(km, P.T, lane);
+
+    // ---- DMA pieces (1 KB = 8 rows each; 0..7 = K rows 8 p.., 8..15 = V rows 8 (p - 8)..): LDS slot lane % 8 of row 8 p + lane / 8 takes the
+    // source chunk slot ^ swz3((row >> 1) & 7); rows beyond T are clamped to row T - 1 (their probabilities are zero)
+    unsigned soff[4], soff_clamp[4]; int dst[4]; bool is_k[4];
+    const int last_rows = P.T - (ntiles - 1) * BT;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int pid = (wv + NW * j) & 15;
+        const int row = 8 * (pid & 7) + (lane >> 3);
+        const int chunk = (lane & 7) ^ swz3((row >> 1) & 7);
+        is_k[j] = pid < 8;
+        soff[j] = (unsigned)(row * (int)row_bytes + chunk * 16);
+        soff_clamp[j] = (unsigned)((row - min(row, last_rows - 1)) * (int)row_bytes);
+        dst[j] = pid * 1024;
+    }
+    auto issue = [&](int t, int slot, int nlive) __attribute__((always_inline)) {
+        const bool live = t < nlive;
+        const int tt = live ? t : ntiles - 1;
+        const char* kbase = kb_ + (long long)tt * tile_bytes;
+        const char* vbase = vb_ + (long long)tt * tile_bytes;
+        char* base = live ? lds + slot * F32_TILE : lds + NBUF * F32_TILE;
+        const bool lastt = tt == ntiles - 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            attn_glds16((is_k[j] ? kbase : vbase) + (soff[j] - (lastt ? soff_clamp[j] : 0u)), base + (live ? dst[j] : 0));
+    };
+
+    // ---- this lane's query: Q and dO fragments (B operands: [query][16 ks + 8 half + 0..7]), O for delta, lse
+    const int q = blk * BQ + wv * 32 + r;
+    const bool q_ok = q < P.T;
+    const bool wave_live = blk * BQ + wv * 32 < P.T;
+    bf16x8 qf[4], dof[4], of[4];
+    const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        qf[ks] = q_ok ? *reinterpret_cast<const bf16x8*>(qb + (long long)q * P.ld_qkv + 16 * ks + 8 * hh) : z8;
+        dof[ks] = q_ok ? *reinterpret_cast<const bf16x8*>(dob + (long long)q * P.ld_o + 16 * ks + 8 * hh) : z8;
+        of[ks] = q_ok ? *reinterpret_cast<const bf16x8*>(ob + (long long)q * P.ld_o + 16 * ks + 8 * hh) : z8;
+    }
+    const float lse_q = q_ok ? P.lse[(long long)bh * P.T + q] : 0.f;
+    issue(0, 0, ntiles);
+    issue(1, 1, ntiles);
+    __builtin_amdgcn_s_waitcnt(0x0F78);          // vmcnt(8): everything older than the eight DMAs (see attn_fwd32_kernel)
+    const int nv = km ? ms.finish(lane) : 1;
+    const bool holes = km != nullptr && nv <= 0;
+    const float maskv = mask_fill_value(nv);
+    const int Tk = (km != nullptr && nv > 0) ? nv : P.T, ntl = (Tk + BT - 1) / BT;
+    // delta = rowsum(dO * O) of this lane's query (its two half-waves hold complementary halves of the head dimension); published for
+    // the dK / dV kernel in units of the dropout scale -- stored at the END (a store in flight would sit in the DMA ring's counted waits)
+    float dl = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl = __builtin_fmaf((float)of[ks][e], (float)dof[ks][e], dl);
+    {
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(dl), __float_as_uint(dl), false, false);
+        dl = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+    const float nlse = -lse_q, ndelta = -dl;
+    f32x16 dq[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dq[db][i] = 0.f;
+    uint32_t hbase = (pair_base(bh + P.bh0, P.T, P.Th, q) + (uint32_t)hh + P.seed) * HC1;
+    // row reads: row 32 kb + r, chunk 2 ks + half
+    int kaddr[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kaddr[ks] = r * 128 + (((2 * ks + hh) ^ swz3((r >> 1) & 7)) << 4);
+    // transposed reads of the K image (A = K^T: lane's d = 32 db + 16 mh + i, k-slots = keys 16 s + 4 half + (0..3 | 8..11)):
+    // lane (i = lane & 15, mh = (lane >> 4) & 1) reads 8 bytes of row 4 half + i / 4 (+ 8), columns 32 db + 16 mh + 4 (i & 3) ..
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    unsigned tr1[2], tr2[2];
+    {
+        const int i = lane & 15, mh = (lane >> 4) & 1, rowA = 4 * hh + (i >> 2), p = i & 3;
+        const int f1 = swz3(rowA >> 1), f2 = swz3((rowA >> 1) + 4);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            const int c = 4 * db + 2 * mh + (p >> 1);
+            tr1[db] = lds0 + (unsigned)(rowA * 128 + ((c ^ f1) << 4) + (p & 1) * 8);
+            tr2[db] = lds0 + (unsigned)((rowA + 8) * 128 + ((c ^ f2) << 4) + (p & 1) * 8);
+        }
+    }
+
+    int slot = 0;
+    for (int t = 0; t < ntl; ++t) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int nslot = slot + 2; nslot = nslot >= NBUF ? nslot - NBUF : nslot;
+        const int toff = slot * F32_TILE;
+        const char* kt = lds + toff;
+        const char* vt = kt + 8192;
+        slot = slot + 1 == NBUF ? 0 : slot + 1;
+        if (wave_live) {
+            const bool edge = holes || (t + 1) * BT > Tk;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                f32x16 s, dp;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) s = mfma32(*reinterpret_cast<const bf16x8*>(kt + kb * 4096 + kaddr[ks]), qf[ks], s);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) dp = mfma32(*reinterpret_cast<const bf16x8*>(vt + kb * 4096 + kaddr[ks]), dof[ks], dp);
+                // the K^T fragments of this key block for dQ: requested now, consumed behind the softmax arithmetic
+                u32x2 ka[2][2][2];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        ka[s2][db][0] = lds_tr64(tr1[db] + (unsigned)(toff + kb * 4096 + s2 * 2048));
+                        ka[s2][db][1] = lds_tr64(tr2[db] + (unsigned)(toff + kb * 4096 + s2 * 2048));
+                    }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float x = __builtin_fmaf(s[i], P.scale, nlse);
+                    bool filled = false;
+                    if (edge) {
+                        const int key = t * BT + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                        if (holes) {
+                            filled = key >= P.T || !km[min(key, P.T - 1)];
+                            if (filled) x = maskv + nlse;
+                        } else if (key >= Tk) x = -INFINITY;
+                    }
+                    const float p = fast_exp2(x);
+                    float dpv = dp[i];
+                    if (DROP) {
+                        // one hash word per key quad = 4 consecutive registers (the forward's words)
+                        const uint32_t h0 = hfin(hbase + (uint32_t)(8 * kb + 2 * (i >> 2)) * HC1);
+                        dpv = (((h0 >> (8 * (i & 3))) & 0xFFu) >= P.thr) ? dpv : 0.f;
+                    }
+                    s[i] = (edge && filled) ? 0.f : p * __builtin_fmaf(dpv, P.pscale, ndelta);      // dS^T[key][q] / softmax scale
+                }
+                const bf16x8 dsf[2] = {pack8(s, 0), pack8(s, 8)};
+                __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): the transposed reads above
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        const u32x4 av = {ka[s2][db][0][0], ka[s2][db][0][1], ka[s2][db][1][0], ka[s2][db][1][1]};
+                        dq[db] = mfma32(__builtin_bit_cast(bf16x8, av), dsf[s2], dq[db]);
+                    }
+            }
+            hbase += (uint32_t)(BT / 4) * HC1;
+        }
+        issue(t + 2, nslot, ntl);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (q_ok && hh == 0) P.delta[(long long)bh * P.T + q] = dl * P.ipscale;
+    store_rows32(reinterpret_cast<bf16*>(P.dq) + ((long long)b * P.T + q) * P.ld_d + h * DH + 8 * hh, dq, P.dscale, q_ok);
+}
+
+// ---- dK, dV (key block stationary): streams Q / dO tiles of 64 queries + their lse / delta
+constexpr int KV32_TILE = 17408;                // Q image 8 KB | dO image 8 KB | lse[64] delta[64] f32 | pad
+template <int NW, bool DROP>
+__global__ __launch_bounds__(NW * 64, 2) void attn_bwd_kv32_kernel(const AttnP P) {
+    constexpr int BK = NW * 32, NBUF = 3;
+    __shared__ __attribute__((aligned(1024))) char lds[NBUF * KV32_TILE + 1024];
+    const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int blk, bh;
+    block_coords((P.T + BK - 1) / BK, P.B * P.H, blk, bh);
+    const int b = bh / P.H, h = bh % P.H;
+    const char* qb_ = reinterpret_cast<const char*>(reinterpret_cast<const bf16*>(P.q) + (long long)b * P.T * P.ld_qkv + h * DH);
+    const bf16* kb = reinterpret_cast<const bf16*>(P.k) + (long long)b * P.T * P.ld_qkv + h * DH;
+    const bf16* vb = reinterpret_cast<const bf16*>(P.v) + (long long)b * P.T * P.ld_qkv + h * DH;
+    const char* dob_ = reinterpret_cast<const char*>(reinterpret_cast<const bf16*>(P.dout) + (long long)b * P.T * P.ld_o + h * DH);
+    const float* lseb = P.lse + (long long)bh * P.T;
+    const float* delb = P.delta + (long long)bh * P.T;
+    const int ntiles = (P.T + BT - 1) / BT;
+    const int key = blk * BK + wv * 32 + r;
+    const bool k_ok = key < P.T;
+    const bool wave_live = blk * BK + wv * 32 < P.T;
+    float maskv = MASKED_LOG2;
+    bool key_masked = false;
+    if (P.keymask) {
+        // prefix key mask: blocks beyond the attended prefix store zeros (see attn_bwd_kv_kernel)
+        const int nv = mask_prefix_len(P.keymask + (long long)b * P.T, P.T, lane);
+        maskv = mask_fill_value(nv);
+        key_masked = k_ok && !P.keymask[(long long)b * P.T + key];
+        if (nv > 0 && blk * BK >= nv) {
+            f32x16 zz[2];
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) zz[db][i] = 0.f;
+            store_rows32(reinterpret_cast<bf16*>(P.dk) + ((long long)b * P.T + key) * P.ld_d + h * DH + 8 * hh, zz, 1.f, k_ok);
+            store_rows32(reinterpret_cast<bf16*>(P.dv) + ((long long)b * P.T + key) * P.ld_d + h * DH + 8 * hh, zz, 1.f, k_ok);
+            return;
+        }
+    }
+    const long long qrow_bytes = P.ld_qkv * 2, orow_bytes = P.ld_o * 2;
+
+    // ---- DMA pieces: 0..7 = Q rows 8 p.., 8..15 = dO rows 8 (p - 8)..; plus one 4-byte-per-lane piece per wave: lse (even waves) /
+    // delta (odd waves) of the tile's 64 queries (two waves stage each: same bytes, same place -- every wave issues 5 pieces per tile).
+    // Wave wv stages pieces wv, wv + 4 (Q) and wv + 8, wv + 12 (dO): their rows' swizzle keys ((row >> 1) & 7 = 4 (piece & 1) + lane / 16)
+    // are the same, so a lane's source offset is ONE register per operand; the last tile's row clamp is formed when it is needed.
+    static_assert(NW == 4, "piece map");
+    const int last_rows = P.T - (ntiles - 1) * BT;
+    const int lrow = lane >> 3;
+    const int chunk = (lane & 7) ^ swz3((4 * (wv & 1) + (lane >> 4)) & 7);
+    const unsigned qlane = (unsigned)(lrow * (int)qrow_bytes + chunk * 16), olane = (unsigned)(lrow * (int)orow_bytes + chunk * 16);
+    const float* statb = (wv & 1) ? delb : lseb;
+    const int stat_dst = 16384 + (wv & 1) * 256;
+    auto issue = [&](int t, int slot, int nlive) __attribute__((always_inline)) {
+        const bool live = t < nlive;
+        const int tt = live ? t : ntiles - 1;
+        const char* qbase = qb_ + (long long)tt * BT * qrow_bytes;
+        const char* obase = dob_ + (long long)tt * BT * orow_bytes;
+        char* base = live ? lds + slot * KV32_TILE : lds + NBUF * KV32_TILE;
+        const bool lastt = tt == ntiles - 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pid = wv + 4 * j, prow = 8 * (pid & 7);
+            const long long rb = j < 2 ? qrow_bytes : orow_bytes;
+            long long off = (long long)prow * rb + (j < 2 ? qlane : olane);       // (signed: the clamp may exceed the lane's own part)
+            if (lastt) off -= (long long)max(0, prow + lrow - (last_rows - 1)) * rb;
+            attn_glds16((j < 2 ? qbase : obase) + off, base + (live ? pid * 1024 : 0));
+        }
+        attn_glds4(reinterpret_cast<const char*>(statb + min(tt * BT + lane, P.T - 1)), base + (live ? stat_dst : 0));
+    };
+
+    // ---- this lane's key: K and V fragments (B operands: [key][16 ks + 8 half + 0..7])
+    bf16x8 kf[4], vf[4];
+    const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        kf[ks] = k_ok ? *reinterpret_cast<const bf16x8*>(kb + (long long)key * P.ld_qkv + 16 * ks + 8 * hh) : z8;
+        vf[ks] = k_ok ? *reinterpret_cast<const bf16x8*>(vb + (long long)key * P.ld_qkv + 16 * ks + 8 * hh) : z8;
+    }
+    issue(0, 0, ntiles);
+    issue(1, 1, ntiles);
+    __builtin_amdgcn_s_waitcnt(0x0F7A);          // vmcnt(10): the K / V fragment loads are older than the ten DMAs
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { dk[db][i] = 0.f; dv[db][i] = 0.f; }
+    // Dropout word of (query, key quad): the four lanes of a quad hold the four keys of one key quad and need the same 16 words per 32
+    // queries; lane (key & 3) = r4 hashes the words of queries 4 m + r4 (+ 4 half) only, the quad exchanges them by DPP (as the 16 x 16 kernel)
+    const uint32_t ThC = (uint32_t)P.Th * HC1;
+    uint32_t hk = (pair_base(bh + P.bh0, P.T, P.Th, 4 * hh + (lane & 3)) + (uint32_t)(key >> 2) + P.seed) * HC1;
+    const uint32_t fmask = 0xFFu << (8 * (lane & 3)), fthr = P.thr << (8 * (lane & 3));
+    int raddr[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) raddr[ks] = r * 128 + (((2 * ks + hh) ^ swz3((r >> 1) & 7)) << 4);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    unsigned tr1[2], tr2[2];
+    {
+        const int i = lane & 15, mh = (lane >> 4) & 1, rowA = 4 * hh + (i >> 2), p = i & 3;
+        const int f1 = swz3(rowA >> 1), f2 = swz3((rowA >> 1) + 4);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            const int c = 4 * db + 2 * mh + (p >> 1);
+            tr1[db] = lds0 + (unsigned)(rowA * 128 + ((c ^ f1) << 4) + (p & 1) * 8);
+            tr2[db] = lds0 + (unsigned)((rowA + 8) * 128 + ((c ^ f2) << 4) + (p & 1) * 8);
+        }
+    }
+
+    int slot = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int nslot = slot + 2; nslot = nslot >= NBUF ? nslot - NBUF : nslot;
+        const int toff = slot * KV32_TILE;
+        const char* qt = lds + toff;
+        const char* dot = qt + 8192;
+        const float* stat = reinterpret_cast<const float*>(qt + 16384);
+        slot = slot + 1 == NBUF ? 0 : slot + 1;
+        if (wave_live) {
+            const bool edge = (t + 1) * BT > P.T;                 // wave-uniform: the last tile's rows beyond T are copies of row T - 1
+#pragma unroll
+            for (int qb2 = 0; qb2 < 2; ++qb2) {
+                // Four phases per 32 queries, ordered for register pressure (K, V fragments and both accumulators are 96 registers):
+                // S -> P -> dV += dO^T P, then dP -> dS -> dK += Q^T dS; each transposed operand is requested one phase ahead of its MFMAs.
+                const unsigned o = (unsigned)(toff + qb2 * 4096);
+                f32x16 s;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s[i] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) s = mfma32(*reinterpret_cast<const bf16x8*>(qt + qb2 * 4096 + raddr[ks]), kf[ks], s);
+                u32x2 oa[2][2][2];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        oa[s2][db][0] = lds_tr64(tr1[db] + o + (unsigned)(s2 * 2048) + 8192u);
+                        oa[s2][db][1] = lds_tr64(tr2[db] + o + (unsigned)(s2 * 2048) + 8192u);
+                    }
+                uint32_t pw[8];                                   // P as bf16 pairs: registers 2 w, 2 w + 1
+                uint32_t keep = 0xFFFFu;                          // bit i: score register i survives the dropout
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {                     // queries 32 qb2 + 8 m + 4 half + 0..3 = registers 4 m .. 4 m + 3
+                    const f32x4 lse4 = *reinterpret_cast<const f32x4*>(stat + 32 * qb2 + 8 * m + 4 * hh);
+                    uint32_t w = 0;
+                    if (DROP) w = hfin(hk + (uint32_t)(32 * qb2 + 8 * m) * ThC);
+                    const uint32_t wr[4] = {quad_bcast<0>(w), quad_bcast<1>(w), quad_bcast<2>(w), quad_bcast<3>(w)};
+                    float pq[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = 4 * m + e;
+                        float x = __builtin_fmaf(s[i], P.scale, -lse4[e]);
+                        if (key_masked) x = maskv - lse4[e];
+                        if (edge && t * BT + 32 * qb2 + 8 * m + 4 * hh + e >= P.T) x = -INFINITY;
+                        const float p = fast_exp2(x);
+                        s[i] = p;
+                        bool kp = true;
+                        if (DROP) { kp = (wr[e] & fmask) >= fthr; if (!kp) keep &= ~(1u << i); }
+                        pq[e] = kp ? p : 0.f;                                             // P (dropped, unscaled) for dV
+                    }
+                    pw[2 * m] = pack2(pq[0], pq[1]);
+                    pw[2 * m + 1] = pack2(pq[2], pq[3]);
+                }
+                const bf16x8 pf[2] = {__builtin_bit_cast(bf16x8, (u32x4){pw[0], pw[1], pw[2], pw[3]}), __builtin_bit_cast(bf16x8, (u32x4){pw[4], pw[5], pw[6], pw[7]})};
+                __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): the dO^T fragments
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        const u32x4 ov = {oa[s2][db][0][0], oa[s2][db][0][1], oa[s2][db][1][0], oa[s2][db][1][1]};
+                        dv[db] = mfma32(__builtin_bit_cast(bf16x8, ov), pf[s2], dv[db]);
+                    }
+                f32x16 dp;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dp[i] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) dp = mfma32(*reinterpret_cast<const bf16x8*>(dot + qb2 * 4096 + raddr[ks]), vf[ks], dp);
+                uint32_t dw[8];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const f32x4 del4 = *reinterpret_cast<const f32x4*>(stat + 64 + 32 * qb2 + 8 * m + 4 * hh);      // delta / pscale (see the dQ kernel)
+                    float dq4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = 4 * m + e;
+                        const float dpv = (!DROP || ((keep >> i) & 1u)) ? dp[i] : 0.f;
+                        float ds = s[i] * (dpv - del4[e]);                                // dS / (softmax scale * pscale) for dK
+                        if (key_masked) ds = 0.f;                                         // a filled score does not depend on q or k
+                        dq4[e] = ds;
+                    }
+                    dw[2 * m] = pack2(dq4[0], dq4[1]);
+                    dw[2 * m + 1] = pack2(dq4[2], dq4[3]);
+                }
+                const bf16x8 dsf[2] = {__builtin_bit_cast(bf16x8, (u32x4){dw[0], dw[1], dw[2], dw[3]}), __builtin_bit_cast(bf16x8, (u32x4){dw[4], dw[5], dw[6], dw[7]})};
+                // (requested only now: sixteen more registers across the dS arithmetic spill the K / V fragments at 3 waves per SIMD)
+                __builtin_amdgcn_sched_barrier(0);
+                u32x2 qa[2][2][2];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        qa[s2][db][0] = lds_tr64(tr1[db] + o + (unsigned)(s2 * 2048));
+                        qa[s2][db][1] = lds_tr64(tr2[db] + o + (unsigned)(s2 * 2048));
+                    }
+                __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): the Q^T fragments
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        const u32x4 qv = {qa[s2][db][0][0], qa[s2][db][0][1], qa[s2][db][1][0], qa[s2][db][1][1]};
+                        dk[db] = mfma32(__builtin_bit_cast(bf16x8, qv), dsf[s2], dk[db]);
+                    }
+            }
+            hk += (uint32_t)BT * ThC;
+        }
+        issue(t + 2, nslot, ntiles);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    store_rows32(reinterpret_cast<bf16*>(P.dk) + ((long long)b * P.T + key) * P.ld_d + h * DH + 8 * hh, dk, P.dscale * P.pscale, k_ok);
+    store_rows32(reinterpret_cast<bf16*>(P.dv) + ((long long)b * P.T + key) * P.ld_d + h * DH + 8 * hh, dv, P.pscale, k_ok);
+}
+
 void set_softmax_params(AttnP& P, float scale, float p, uint32_t seed) {
     P.scale = scale * 1.4426950408889634f;
     P.dscale = scale;
@@ -1063,9 +1509,21 @@ int a8i_attn_bwd(int dtype, const void* q, const void* k, const void* v, const v
     hipStream_t s = (hipStream_t)stream;
     // dQ first: it computes delta = rowsum(dO * O) for its own query rows and publishes it for the dK/dV kernel
     const int flags = (P.thr != 0 ? 1 : 0) + (keymask ? 2 : 0);
-    if (dtype == A8_BF16 && g_a8_tuning[4] == 41) A8_ATTN_LAUNCH_FLAGS(attn_bwd_q_kernel, 4, 1, 1)
+    // a8_set_tuning keys 4 (dQ) / 3 (dK, dV) = 32: the 32 x 32-MFMA kernels of round 6 (16-bit data, no fused bias gradients)
+    const bool can32 = dtype == A8_BF16 && dbias == nullptr && ld_qkv % 8 == 0 && ld_o % 8 == 0 && ld_dqkv % 8 == 0;
+    if (can32 && g_a8_tuning[4] == 32) {
+        const dim3 grid(cdiv(T_, 128) * B * H);
+        if (P.thr) hipLaunchKernelGGL((attn_bwd_q32_kernel<4, true>), grid, dim3(256), 0, s, P);
+        else hipLaunchKernelGGL((attn_bwd_q32_kernel<4, false>), grid, dim3(256), 0, s, P);
+    }
+    else if (dtype == A8_BF16 && (g_a8_tuning[4] == 41 || g_a8_tuning[4] == 32)) A8_ATTN_LAUNCH_FLAGS(attn_bwd_q_kernel, 4, 1, 1)
     else A8_ATTN_LAUNCH(attn_bwd_q_kernel, 4, "a8_attn_bwd")
-    if (dtype == A8_BF16 && g_a8_tuning[3] == 41) A8_ATTN_LAUNCH_FLAGS(attn_bwd_kv_kernel, 4, 1, 3)
+    if (can32 && g_a8_tuning[3] == 32) {
+        const dim3 grid(cdiv(T_, 128) * B * H);
+        if (P.thr) hipLaunchKernelGGL((attn_bwd_kv32_kernel<4, true>), grid, dim3(256), 0, s, P);
+        else hipLaunchKernelGGL((attn_bwd_kv32_kernel<4, false>), grid, dim3(256), 0, s, P);
+    }
+    else if (dtype == A8_BF16 && (g_a8_tuning[3] == 41 || g_a8_tuning[3] == 32)) A8_ATTN_LAUNCH_FLAGS(attn_bwd_kv_kernel, 4, 1, 3)
     else A8_ATTN_LAUNCH(attn_bwd_kv_kernel, 3, "a8_attn_bwd")
     return a8_check_launch("a8_attn_bwd");
 }

@@ -285,7 +285,7 @@ def _attn_ref(q, k, v, keymask, scale, drop_keep=None, p=0.0):
     return torch.matmul(a, v)
 
 
-@pytest.fixture(params=[(41, 41, 41), (22, 22, 22), (42, 42, 42), (4, 41, 41), (5, 41, 41), (0, 41, 41)], ids=lambda g: "fwd%d-kv%d-q%d" % g)
+@pytest.fixture(params=[(41, 41, 41), (22, 22, 22), (42, 42, 42), (4, 41, 41), (5, 41, 41), (0, 41, 41), (0, 32, 32), (0, 32, 41), (0, 41, 32)], ids=lambda g: "fwd%d-kv%d-q%d" % g)
 def attn_geometry(request):
     """Launch geometry (a8_set_tuning keys 2, 3, 4) of the forward, dK/dV and dQ attention kernels: 41 / 22 / 42 = the 16x16-MFMA kernels
     (waves per block * 10 + 16-row groups per wave); forward values below 10 = the 32x32-MFMA kernel for 16-bit data (4 / 5 waves of 32
@@ -334,10 +334,15 @@ def test_attention_fwd_bwd(dtype, T, use_mask, attn_geometry):
     close(dv.reshape(B, T, H, 64), v.grad.permute(0, 2, 1, 3), tolb, "attn dv")
     ref_b = torch.cat([x.grad.permute(0, 2, 1, 3).reshape(B * T, d).sum(0) for x in (q, k, v)])     # column sums of dq | dk | dv
     close(dbias, dbias0 + ref_b, tolb, "q/k/v bias gradients from the backward kernels")
+    # without the fused bias gradients (what the step runs; the 32 x 32-MFMA backward kernels of round 6 take only this form)
+    dq, dk, dv, _ = K.attn_bwd(g[:, :d], g[:, d:2 * d], g[:, 2 * d:], o, dout.to(dev), lse, B, T, H, 3 * d, scale, km)
+    close(dq.reshape(B, T, H, 64), q.grad.permute(0, 2, 1, 3), tolb, "attn dq (no dbias)")
+    close(dk.reshape(B, T, H, 64), k.grad.permute(0, 2, 1, 3), tolb, "attn dk (no dbias)")
+    close(dv.reshape(B, T, H, 64), v.grad.permute(0, 2, 1, 3), tolb, "attn dv (no dbias)")
 
 
 @pytest.mark.parametrize("dtype", DT)
-def test_attention_key_mask_shapes(dtype):
+def test_attention_key_mask_shapes(dtype, attn_geometry):
     """Round 6: a key-padding mask that is a PREFIX of attended keys (what sequence_mask produces, audio8/train.py:33) runs as the unmasked
     kernel over the attended keys -- key tiles beyond the prefix are never staged, dK/dV blocks beyond it store zeros -- and any other mask
     (holes, nothing attended) keeps the per-key path.  Every shape must still equal masked_fill(-1e9) + softmax (audio8's eight_mile
