@@ -376,50 +376,40 @@ __global__ __launch_bounds__(256) void conv0_bwd_main_kernel(const float* __rest
 // Wave w owns channels 128 w .. 128 w + 127 (so per-(b,c) sums never cross waves); lane li of channel block j holds channel
 // 128 w + 8 li + j, i.e. 8 consecutive channels across j: one 16-byte dout load per frame.
 constexpr int BSUB = 256;                                        // frames per image rebuild
-// Round 6: 41 VALU per MFMA at 2 waves per SIMD left the kernel latency-exposed (4.6 % MFMA busy, 243 us for 0.41 GB).
-//   * the conv weight operand of a lane's 8 channels is built ONCE, in registers, from the f32 weights and statistics (it was a 32 KB
-//     LDS image rebuilt per block and re-read per 256 frames): 37 KB of LDS per block instead of 69 KB, 3 blocks per CU;
-//   * __launch_bounds__(256, 3): 168 registers, three waves per SIMD overlap each other's dout loads, MFMA and GELU' chains;
-//   * xim rows are 64 bytes: the 16 lanes of a fragment read rows 64 bytes apart -- four of them in the same banks (3.4 M conflict
-//     cycles per launch in profiles/r05_kernel_sq_counters.txt).  The 16-byte chunk c of row r now sits at c ^ ((r >> 2) & 3).
-__global__ __launch_bounds__(256, 3) void conv0_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wg,
+__global__ __launch_bounds__(256, 2) void conv0_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wg,
                                                              const float* __restrict__ gn_w, const float* __restrict__ gn_b,
                                                              const float* __restrict__ stats, const bf16* __restrict__ dout,
                                                              float* __restrict__ acc, double* __restrict__ xr, int L, int L0, int fpb) {
     __shared__ __attribute__((aligned(16))) float xs[ST * BSUB + 8];
-    __shared__ __attribute__((aligned(16))) bf16 xim[BSUB][32];           // per frame: the 32 k-slots of the conv operand (as in the forward), chunks swizzled
+    __shared__ __attribute__((aligned(16))) bf16 xim[BSUB][32];           // per frame: the 32 k-slots of the conv operand (as in the forward)
     __shared__ __attribute__((aligned(16))) bf16 x2im[BSUB / 16][64][8];  // per 16-frame step and lane: x[5 frame(slot) + tap], tap = lane & 15
+    __shared__ __attribute__((aligned(16))) bf16 wim[CC][32];             // per channel: taps * rstd (hi, hi, lo), -mean * rstd (hi, lo)
     __shared__ float xr_s[NXR];
-    __shared__ __attribute__((aligned(16))) float gwb[CC][2];             // GroupNorm gamma, beta per channel (read per use: 16 registers less)
     const int b = blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6, g = lane >> 4, li = lane & 15;
     auto split = [](float v, bf16& hi, bf16& lo) { hi = (bf16)v; lo = (bf16)(v - (float)hi); };
-    if (tid < NXR) xr_s[tid] = 0.f;
-    for (int c = tid; c < CC; c += 256) { gwb[c][0] = gn_w[c]; gwb[c][1] = gn_b[c]; }
-    const int cbase = 128 * wv + 8 * li;                 // this lane's 8 channels (one per channel block j)
-    float s1[8], s2[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-    f32x4 accA[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) accA[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // conv weights of this lane's 8 channels, k-slots 8 g .. 8 g + 7 of the 32-slot operand row
-    //   [hi0..hi7 | hi8 hi9 hi0..hi5 | hi6..hi9 lo0..lo3 | lo4..lo9 shift_hi shift_lo]   (taps * rstd and -mean * rstd, hi / lo split)
-    bf16x8 wf[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int c = cbase + j;
+    for (int cc = 0; cc < 2; ++cc) {
+        const int c = tid + 256 * cc;
         const float mu = stats[((long long)b * CC + c) * 2], rs = stats[((long long)b * CC + c) * 2 + 1];
         bf16 hi[KW], lo[KW], shh, shl;
 #pragma unroll
         for (int k = 0; k < KW; ++k) split(wg[c * KW + k] * rs, hi[k], lo[k]);
         split(-mu * rs, shh, shl);
-        const bf16x8 r0 = {hi[0], hi[1], hi[2], hi[3], hi[4], hi[5], hi[6], hi[7]};
-        const bf16x8 r1 = {hi[8], hi[9], hi[0], hi[1], hi[2], hi[3], hi[4], hi[5]};
-        const bf16x8 r2 = {hi[6], hi[7], hi[8], hi[9], lo[0], lo[1], lo[2], lo[3]};
-        const bf16x8 r3 = {lo[4], lo[5], lo[6], lo[7], lo[8], lo[9], shh, shl};
-        wf[j] = g == 0 ? r0 : (g == 1 ? r1 : (g == 2 ? r2 : r3));
+        bf16x8* row = reinterpret_cast<bf16x8*>(&wim[c][0]);
+        row[0] = (bf16x8){hi[0], hi[1], hi[2], hi[3], hi[4], hi[5], hi[6], hi[7]};
+        row[1] = (bf16x8){hi[8], hi[9], hi[0], hi[1], hi[2], hi[3], hi[4], hi[5]};
+        row[2] = (bf16x8){hi[6], hi[7], hi[8], hi[9], lo[0], lo[1], lo[2], lo[3]};
+        row[3] = (bf16x8){lo[4], lo[5], lo[6], lo[7], lo[8], lo[9], shh, shl};
     }
+    if (tid < NXR) xr_s[tid] = 0.f;
+    const int cbase = 128 * wv + 8 * li;                 // this lane's 8 channels (one per channel block j)
+    float gw[8], gb[8], s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { gw[j] = gn_w[cbase + j]; gb[j] = gn_b[cbase + j]; s1[j] = 0.f; s2[j] = 0.f; }
+    f32x4 accA[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) accA[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float* xb = x + (long long)b * L;
     const int tb = blockIdx.x * fpb, te = min(L0, tb + fpb);
     for (int t0 = tb; t0 < te; t0 += BSUB) {             // block-uniform bounds
@@ -436,11 +426,10 @@ __global__ __launch_bounds__(256, 3) void conv0_bwd_mfma_kernel(const float* __r
             for (int k = 0; k < KW; ++k) split(xs[ST * tid + k], hi[k], lo[k]);
             const bf16 one = (bf16)1.0f;
             bf16x8* row = reinterpret_cast<bf16x8*>(&xim[tid][0]);
-            const int sw = (tid >> 2) & 3;                                  // chunk c of row r at c ^ ((r >> 2) & 3): conflict-free fragment reads
-            row[0 ^ sw] = (bf16x8){hi[0], hi[1], hi[2], hi[3], hi[4], hi[5], hi[6], hi[7]};
-            row[1 ^ sw] = (bf16x8){hi[8], hi[9], lo[0], lo[1], lo[2], lo[3], lo[4], lo[5]};
-            row[2 ^ sw] = (bf16x8){lo[6], lo[7], lo[8], lo[9], hi[0], hi[1], hi[2], hi[3]};
-            row[3 ^ sw] = (bf16x8){hi[4], hi[5], hi[6], hi[7], hi[8], hi[9], one, one};
+            row[0] = (bf16x8){hi[0], hi[1], hi[2], hi[3], hi[4], hi[5], hi[6], hi[7]};
+            row[1] = (bf16x8){hi[8], hi[9], lo[0], lo[1], lo[2], lo[3], lo[4], lo[5]};
+            row[2] = (bf16x8){lo[6], lo[7], lo[8], lo[9], hi[0], hi[1], hi[2], hi[3]};
+            row[3] = (bf16x8){hi[4], hi[5], hi[6], hi[7], hi[8], hi[9], one, one};
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
                 const int st = (tid >> 6) + 4 * h, ln = tid & 63, gg = ln >> 4, tap = ln & 15;
@@ -453,20 +442,33 @@ __global__ __launch_bounds__(256, 3) void conv0_bwd_mfma_kernel(const float* __r
                 *reinterpret_cast<bf16x8*>(&x2im[st][ln][0]) = v;
             }
         }
-        {   // waveform moments of these frames (one frame per thread): 65 wave sums -> LDS atomics.  Each product is formed and reduced on
-            // the spot: a 65-register array of partial sums on top of the loop's persistent state spilled at three waves per SIMD.
-            float xv[KW];
+        {   // waveform moments of these frames: thread-strided, LDS atomics (65 values)
+            float sx[KW], rx[KW * (KW + 1) / 2];
 #pragma unroll
-            for (int k = 0; k < KW; ++k) xv[k] = tid < nfr ? xs[ST * tid + k] : 0.f;
+            for (int k = 0; k < KW; ++k) sx[k] = 0.f;
 #pragma unroll
-            for (int k = 0; k < KW; ++k) { const float t = wave_sum(xv[k]); if (lane == 0) atomicAdd(&xr_s[k], t); }
-            int n = 0;
+            for (int i = 0; i < KW * (KW + 1) / 2; ++i) rx[i] = 0.f;
+            if (tid < nfr) {
+                float xv[KW];
 #pragma unroll
-            for (int j = 0; j < KW; ++j)
+                for (int k = 0; k < KW; ++k) xv[k] = xs[ST * tid + k];
+                int n = 0;
 #pragma unroll
-                for (int k = j; k < KW; ++k) { const float t = wave_sum(xv[j] * xv[k]); if (lane == 0) atomicAdd(&xr_s[KW + n], t); ++n; }
+                for (int j = 0; j < KW; ++j) {
+                    sx[j] += xv[j];
+#pragma unroll
+                    for (int k = j; k < KW; ++k) { rx[n] = xv[j] * xv[k]; ++n; }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KW; ++k) { const float t = wave_sum(sx[k]); if (lane == 0) atomicAdd(&xr_s[k], t); }
+#pragma unroll
+            for (int i = 0; i < KW * (KW + 1) / 2; ++i) { const float t = wave_sum(rx[i]); if (lane == 0) atomicAdd(&xr_s[KW + i], t); }
         }
         __syncthreads();
+        bf16x8 wf[8];                                    // conv weights of this lane's 8 channels: the MFMA's column operand
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(&wim[cbase + j][8 * g]);
         const int nstep = (nfr + 15) / 16;
         // dout of frames 16 st + 4 g + r, channels cbase .. cbase + 7 (rows beyond the utterance read as zero); the next step's
         // rows are requested before this step's arithmetic starts
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(256, 3) void conv0_bwd_mfma_kernel(const float* __r
         load_dg(0, dg);
         for (int st = 0; st < nstep; ++st) {
             if (st + 1 < nstep) load_dg(st + 1, dn);
-            const bf16x8 xf0 = *reinterpret_cast<const bf16x8*>(&xim[16 * st + li][8 * (g ^ ((li >> 2) & 3))]);
+            const bf16x8 xf0 = *reinterpret_cast<const bf16x8*>(&xim[16 * st + li][8 * g]);
             const bf16x8 x2 = *reinterpret_cast<const bf16x8*>(&x2im[st][lane][0]);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -489,9 +491,8 @@ __global__ __launch_bounds__(256, 3) void conv0_bwd_mfma_kernel(const float* __r
                 const f32x4 h0 = Mma<bf16>::mma(xf0, wf[j], (f32x4){0.f, 0.f, 0.f, 0.f});
                 bf16x8 du = {0, 0, 0, 0, 0, 0, 0, 0};
                 float dd[4], zz[4];
-                const f32x2 gwj = *reinterpret_cast<const f32x2*>(&gwb[cbase + j][0]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { dd[r] = (float)dg[r][j]; zz[r] = fmaf(h0[r], gwj[0], gwj[1]); }
+                for (int r = 0; r < 4; ++r) { dd[r] = (float)dg[r][j]; zz[r] = fmaf(h0[r], gw[j], gb[j]); }
                 mul_gelu_grad_n(dd, zz);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -604,7 +605,7 @@ extern "C" int a8_conv0_gn_gelu_bwd(int dtype, const float* x, const float* w, c
     if (hipMemsetAsync(red, 0, sizeof(float) * A8_CONV0_BWD_SCRATCH_FLOATS(B), s) != hipSuccess)
         return a8_set_error(A8_ERR_LAUNCH, "a8_conv0_gn_gelu_bwd: memset failed");
     if (dtype == A8_BF16 && g_a8_tuning[9] == 0) {
-        const int fpb = conv0_frames_per_block(B, L0, 768);        // 168 registers, 37 KB of LDS: three blocks per CU, one round
+        const int fpb = conv0_frames_per_block(B, L0, 512);        // 256 registers: two blocks per CU
         hipLaunchKernelGGL(conv0_bwd_mfma_kernel, dim3(cdiv(L0, fpb), B), dim3(256), 0, s, x, w, gn_w, gn_b, stats, (const bf16*)dout, acc, xr, L, L0, fpb);
     }
     else if (dtype == A8_BF16)
