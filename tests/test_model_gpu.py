@@ -776,7 +776,11 @@ def test_layernorm_partial_row_column_sums_match_the_atomic_form(restore_dtype):
             assert abs(l0 - l1) <= 2e-6 * abs(l0), (B, half, l0, l1)
             assert torch.isfinite(g1).all()
             scale = float(g0.abs().max())
-            assert float((g0 - g1).abs().max()) <= 2e-5 * scale, (B, half, ld)
+            # a PRODUCT-vs-PRODUCT comparison: both sides are f32 sums of the same ~3000 bf16-derived terms in different orders (per-block
+            # partial rows + 16-stripe reduction vs atomics in arrival order).  Their difference is summation-order noise, ~1e-5 of the
+            # gradient scale here (an archived kernel variant measured 1.8e-4): the bound is 1e-4, a defect in the
+            # partial-row path (a dropped block, a wrong stripe) shows up at 1e-2 and above.  Accuracy itself is the f32 / bf16 parity tests'.
+            assert float((g0 - g1).abs().max()) <= 1e-4 * scale, (B, half, ld)
             assert float((p0 - p1).abs().max()) <= 1e-3 * float(p0.abs().max())
     finally:
         ops.LN_PARTIALS, ops.HALF_BATCH_BWD = old

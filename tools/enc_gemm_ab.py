@@ -11,7 +11,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from audio8_amd import _lib as L, kernels as K  # noqa: E402
 
-DEFAULTS = {5: 20000, 7: 0, 8: 0, 14: 1000, 15: 1, 19: 0, 22: 0, 23: 0, 24: 0, 25: 0}
+DEFAULTS = {5: 20000, 7: 0, 8: 0, 14: 1000, 15: 1, 19: 0, 22: 0, 23: 0, 25: 0}      # (key 24 selected the round-5 wide-tile kernel, which lives only in tools/ubench/round5_gemm_wide: no library code reads it)
 cfgs = []
 for part in (sys.argv[1] if len(sys.argv) > 1 else "base:").split(";"):
     name, _, kv = part.partition(":")

@@ -85,6 +85,8 @@ if __name__ == "__main__":
     if len(sys.argv) > 2:
         STEPS = int(sys.argv[2])
     ops.set_compute_dtype(torch.bfloat16)
+    if os.environ.get("A8_HALF_BATCH", "1") == "0":        # developer A/B: the encoder stack as one whole-batch launch sequence
+        ops.HALF_BATCH_STREAMS = False
     if which in ("cfg4", "both"):
         cfg4()
     if which in ("cfg5", "both"):

@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from audio8_amd import _lib as L, ops, wav2vec2 as W  # noqa: E402
 from audio8_amd.trainer import Stepper  # noqa: E402
 
-DEFAULTS = {1: 802, 2: 0, 3: 41, 4: 41, 5: 20000, 6: 3, 7: 0, 8: 0, 14: 1000, 15: 1, 17: 801, 19: 0, 20: 0, 21: 0, 22: 0, 23: 0, 24: 0, 25: 0}
+DEFAULTS = {1: 802, 2: 0, 3: 41, 4: 41, 5: 20000, 6: 3, 7: 0, 8: 0, 14: 1000, 15: 1, 17: 801, 19: 0, 20: 0, 21: 0, 22: 0, 23: 0, 25: 0}      # (key 24 selected the round-5 wide-tile kernel, which lives only in tools/ubench/round5_gemm_wide: no library code reads it)
 cfgs = []
 for part in (sys.argv[1] if len(sys.argv) > 1 else "base:").split(";"):
     name, _, kv = part.partition(":")
