@@ -204,6 +204,9 @@ class WeightCache:
         ops.WPREP_EVENT = done                            # taken (and cleared) by ops.wait_weight_prep() in front of the first consumer
 
 
+WAIT_ALL_STREAMS = os.environ.get("A8_BUCKET_WAIT_ALL", "0") == "1"       # developer A/B: every bucket waits for every stream (round 5)
+
+
 class GradReducer:
     """Bucketed all-reduce of the flat gradient buffer, overlapped with backward."""
 
@@ -227,6 +230,8 @@ class GradReducer:
         self.enabled = self.world > 1 or (dist.is_initialized() and os.environ.get("A8_FORCE_REDUCER", "0") == "1")
         self.on_gpu = state.flat_g.is_cuda
         self.side = torch.cuda.Stream() if self.on_gpu else None     # exchange + per-bucket gradient-norm stream
+        self._dev_index = state.flat_g.device.index if self.on_gpu else None
+        self._wgrad_raw = None              # raw handle of the weight-gradient stream (set with extra_streams by the Stepper)
         # a8_set_tuning key 8 (the conv layers' persistent stream GEMMs launched as n CUs' worths of blocks: shorter static shares, the
         # surplus dispatched as CUs free up -- work-conserving when RCCL kernels hold CUs at launch) costs 0.09 ms per step alone on the
         # GPU and has never been measured under real RCCL traffic: it stays at the library default (1) unless A8_STREAM_GRID=<n> asks;
@@ -320,6 +325,17 @@ class GradReducer:
         self.marked[i] = True
         bk = self.buckets[self.bucket_of[i]]
         bk["pending"] -= 1
+        if self.on_gpu:
+            # the stream(s) this gradient was enqueued on: the caller's current stream (backward kernels report from the context they launched
+            # in -- the weight-gradient stream for almost every parameter) and, while a split backward is in flight outside that stream,
+            # the half-batch stream too.  The bucket's collective waits for exactly these (see _launch).
+            raw = torch._C._cuda_getCurrentRawStream(self._dev_index)      # (an int: a torch.cuda.current_stream() object per parameter is 1 ms per step)
+            bs = bk.setdefault("streams", {})
+            if raw not in bs:
+                bs[raw] = torch.cuda.current_stream()
+            aux = ops._BWD_AUX_LIVE
+            if aux is not None and raw != self._wgrad_raw:
+                bs[aux.cuda_stream] = aux
         # Collectives must be issued in the same order on every rank: buckets go out strictly in index order (the order in
         # which backward completes them anyway); one whose gradients arrive early waits for its predecessors, one that
         # never completes (frozen / dropped layers) holds the rest back until finish().
@@ -371,15 +387,18 @@ class GradReducer:
         view = self.state.flat_g[bk["lo"]:bk["hi"]]
         h = None
         if self.on_gpu:
-            # the bucket's gradients were enqueued on the compute stream and/or the wgrad side stream, and this call may
-            # come from either context (the last parameter of a bucket decides): wait for all of them
-            cur = torch.cuda.current_stream()
-            streams = {id(cur): cur}
-            if self.compute_stream is not None:
-                streams[id(self.compute_stream)] = self.compute_stream
-            for s2 in self.extra_streams:
-                if s2 is not None:
-                    streams[id(s2)] = s2
+            # The exchange stream waits for the streams this bucket's gradients were enqueued on -- recorded per parameter in _mark() -- and
+            # for nothing else (round 5 recorded an event on the compute, half-batch and weight-gradient streams for every bucket "to be
+            # safe"; A8_BUCKET_WAIT_ALL=1 restores that set).  What the schedule costs on one GPU, 0.35-0.45 ms per step for twelve buckets,
+            # is almost all the event RECORD on the weight-gradient stream (tools/bucket_probe.py: bookkeeping 0, stand-in kernels 0, records
+            # alone 0.30 ms, waits + final join 0.06; device-scope events, another place in the layer's launch order: no change).
+            streams = dict(bk.get("streams", {}))
+            if WAIT_ALL_STREAMS:
+                cur = torch.cuda.current_stream()
+                streams[cur.cuda_stream] = cur
+                for s2 in [self.compute_stream] + list(self.extra_streams):
+                    if s2 is not None:
+                        streams[s2.cuda_stream] = s2
             for st in streams.values():
                 ev = torch.cuda.Event()
                 ev.record(st)
@@ -433,6 +452,7 @@ class GradReducer:
         for bk in self.buckets:
             bk["pending"] = len(bk["members"])
             bk["launched"] = False
+            bk["streams"] = {}
         self.marked = [False] * len(self.state.params)
         self.handles = []
         self.deferred = []
@@ -539,6 +559,7 @@ class Stepper:
         # (the half-batch stream too: a split layer backward leaves the second halves' bias / LayerNorm gradients in flight there)
         self.reducer.extra_streams = [self.wgrad_stream, torch.cuda.current_stream() if self.state.flat_p.is_cuda else None,
                                       ops.half_stream(self.state.flat_p.device) if self.state.flat_p.is_cuda else None]
+        self.reducer._wgrad_raw = self.wgrad_stream.cuda_stream if self.wgrad_stream is not None else None
         self.wcache = None
         if self.state.flat_p.is_cuda and ops.compute_dtype() == torch.bfloat16:
             self.wcache = WeightCache(model, torch.bfloat16)

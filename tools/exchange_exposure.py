@@ -40,13 +40,21 @@ def main():
     x = (0.1 * torch.randn(8, 250000, generator=g)).clamp_(-1, 1).to(dev)
     total_mb = st.state.total * 4 / 1e6
 
+    host = {"bwd": 0.0, "opt": 0.0, "n": 0}
+
     def step():
         st.zero_grad()
         loss = loss_fn(model, x)
+        t0 = time.perf_counter()
         loss.backward()
+        t1 = time.perf_counter()
         W.prefetch_host_draws(model, loss_fn, x.shape, dev)
         v = loss.item()
+        t2 = time.perf_counter()
         st.step()
+        host["bwd"] += t1 - t0
+        host["opt"] += time.perf_counter() - t2
+        host["n"] += 1
         return v
 
     def run(n):
@@ -64,11 +72,14 @@ def main():
     for _ in range(5):
         step()
     res = {v[0]: [] for v in variants}
+    hostt = {}
     for r in range(rounds):
         for name, rate, pl in variants:
             red.fake_gbps, red.payload = rate, pl
             run(2)
+            host.update(bwd=0.0, opt=0.0, n=0)
             res[name].append(run(steps))
+            hostt.setdefault(name, []).append((host["bwd"] / host["n"] * 1e3, host["opt"] / host["n"] * 1e3))
     red.fake_gbps, red.payload = 0.0, "f32"
     print("# tools/exchange_exposure.py: wav2vec2-base 8 x 250k bf16 on one MI355X, %d interleaved rounds x %d steps; gradient payload %.0f MB f32 in %d buckets"
           % (rounds, steps, total_mb, len(red.buckets)))
@@ -79,7 +90,9 @@ def main():
         serial = 0.0 if rate in (0.0, 1e9) else total_mb * (0.5 if pl == "bf16" else 1.0) / rate     # MB / (GB/s) = ms
         exposed = ms - base
         eff = "" if rate == 0.0 else "%.3f" % (base / max(base, ms))
-        print("%-22s %9.3f %9.3f %9.3f   %s   rounds: %s" % (name, ms, exposed, serial, eff, " ".join("%.3f" % v for v in res[name])))
+        hb, ho = (float(np.median([h[k] for h in hostt[name]])) for k in (0, 1))
+        print("%-22s %9.3f %9.3f %9.3f   %s   rounds: %s   host: backward %.2f ms, step() %.2f ms"
+              % (name, ms, exposed, serial, eff, " ".join("%.3f" % v for v in res[name]), hb, ho))
     # when does each bucket go out, relative to the end of backward?  (one traced step at 300 GB/s, f32)
     red.fake_gbps, red.trace = 300.0, []
     st.zero_grad()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Same-process, interleaved A/B of the full bench step under developer knobs (box-to-box and run-to-run noise on this pool is
 several per cent; only interleaved rounds in one process separate 1 % effects).
-usage: step_ab.py "name:key=val,key=val;name2:..."   keys: integers = a8_set_tuning keys; bucketnorm, sidewgrad, groupwgrad = 0/1"""
+usage: step_ab.py "name:key=val,key=val;name2:..."   keys: integers = a8_set_tuning keys; bucketnorm, sidewgrad, groupwgrad ... = 0/1; fakegbps = <rate>"""
 import os
 import sys
 import time
@@ -56,6 +56,7 @@ def apply(d):
     ops.HOST_DELAY_US = d.get("hostdelay", 0)
     ops.SPLITK_SLOTS = d.get("skslots", 512)
     ops.SPLITK_MIN_ROWS = d.get("skrows", 800)
+    st.reducer.fake_gbps = float(d.get("fakegbps", 0))                # > 0: the bucket schedule with a delay standing in for every collective
 
 
 def step():
