@@ -26,6 +26,7 @@ ARGTYPES = {
     "a8_gemm_grouped": [C.c_void_p, C.c_int, C.c_void_p],
     "a8_encoder_layer_fwd": [C.c_void_p, C.c_void_p],
     "a8_encoder_layer_bwd": [C.c_void_p, C.c_void_p],
+    "a8_encoder_layer_bwd_full": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "a8_set_tuning": [C.c_int, C.c_int],
     "a8_get_tuning": [C.c_int, C.c_void_p],
     "a8_delay_us": [C.c_float, C.c_void_p],
@@ -107,12 +108,20 @@ class EncoderLayerBwdDesc(C.Structure):
                                           "df", "dx1_res", "dz1", "dx1_ffn", "dao", "dx_res", "dout_o", "dqkv", "delta", "ln1_partials", "ln2_partials")]
 
 
+class EncoderLayerBwdFullDesc(C.Structure):
+    _fields_ = [("size", C.c_int), ("nhalves", C.c_int), ("half", EncoderLayerBwdDesc * 2), ("M", C.c_int)] + \
+               [(n, C.c_void_p) for n in ("h", "wqkv_t", "dx", "dw2", "dw1", "dwo", "dwqkv")] + \
+               [(n, C.c_int) for n in ("acc_w2", "acc_w1", "acc_wo", "acc_wqkv")] + \
+               [("dbqkv", C.c_void_p), ("ln1_ws", C.c_void_p), ("ln2_ws", C.c_void_p), ("ln_rows", C.c_int)]
+
+
 class WPrepDesc(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("dstT", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("kw", C.c_int),
                 ("tap", C.c_int), ("ld_dst", C.c_int), ("ld_dstT", C.c_int)]
 
 
 GEMM_DESC_SIZE, ENC_DESC_SIZE, ENC_BWD_DESC_SIZE = C.sizeof(GemmDesc), C.sizeof(EncoderLayerDesc), C.sizeof(EncoderLayerBwdDesc)
+ENC_BWD_FULL_DESC_SIZE = C.sizeof(EncoderLayerBwdFullDesc)
 ABI_VERSION = 120            # include/a8hip.h: A8HIP_VERSION
 
 
@@ -173,7 +182,7 @@ def require_cuda(*ts):
 
 
 EXPORTS = [
-    "a8_version", "a8_last_error", "a8_gemm", "a8_gemm_grouped", "a8_set_tuning", "a8_get_tuning", "a8_delay_us", "a8_encoder_layer_fwd", "a8_encoder_layer_bwd", "a8_prepare_weights", "a8_prepare_weights_device",
+    "a8_version", "a8_last_error", "a8_gemm", "a8_gemm_grouped", "a8_set_tuning", "a8_get_tuning", "a8_delay_us", "a8_encoder_layer_fwd", "a8_encoder_layer_bwd", "a8_encoder_layer_bwd_full", "a8_prepare_weights", "a8_prepare_weights_device",
     "a8_conv0_gn_gelu_fwd", "a8_conv0_gn_gelu_bwd", "a8_col2im_gelu_grad",
     "a8_layernorm_fwd", "a8_layernorm_bwd", "a8_layernorm_bwd_partial_rows", "a8_colsum_partials_reduce",
     "a8_cast", "a8_dropout", "a8_mask_fill_rows", "a8_mask_fill_rows_bwd", "a8_mask_zero_cols", "a8_zero_rows",

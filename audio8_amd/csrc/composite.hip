@@ -99,3 +99,77 @@ extern "C" int a8_encoder_layer_bwd(const a8_encoder_layer_bwd_desc* e, void* st
                         dq + (size_t)2 * d * esz, e->delta, nullptr, e->B, e->T, e->H, 3 * d, d, 3 * d, 1.0f / std::sqrt((float)(d / e->H)), e->p,
                         e->seed_attn, e->b0 * e->H, stream);
 }
+
+// The whole backward of one encoder layer behind ONE C call (include/a8hip.h): the host-side form of what audio8_amd/ops.py's
+// EncoderLayerFn._backward issues as ~10 ctypes calls, two stream events and a dozen Python closures per layer.
+namespace {
+struct EventPair { hipEvent_t e[2]; bool ok = false; };
+EventPair& layer_events() {
+    static thread_local EventPair p;
+    if (!p.ok) p.ok = hipEventCreateWithFlags(&p.e[0], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&p.e[1], hipEventDisableTiming) == hipSuccess;
+    return p;
+}
+a8_gemm_desc tn_desc(int dtype, const void* dy, const void* x, float* out, int n_out, int n_in, int m, int accumulate) {
+    a8_gemm_desc d;
+    std::memset(&d, 0, sizeof(d));
+    d.size = (int)sizeof(d);
+    d.dtype = dtype; d.layout = A8_GEMM_TN;
+    d.M = n_out; d.N = n_in; d.K = m;
+    d.A = dy; d.lda = n_out;
+    d.B = x; d.ldb = n_in;
+    d.C = out; d.ldc = n_in;
+    d.ldz = n_in;
+    d.out_f32 = 1; d.accumulate = accumulate; d.splitk = 1; d.alpha = 1.0f;
+    return d;
+}
+}  // namespace
+
+extern "C" int a8_encoder_layer_bwd_full(const a8_encoder_layer_bwd_full_desc* f, void* main_stream, void* aux_stream, void* side_stream) {
+    A8_REQUIRE(f != nullptr, "a8_encoder_layer_bwd_full: null descriptor");
+    A8_REQUIRE(f->size == (int)sizeof(*f), "a8_encoder_layer_bwd_full: descriptor size %d, expected %d", f->size, (int)sizeof(*f));
+    A8_REQUIRE(f->nhalves == 1 || f->nhalves == 2, "a8_encoder_layer_bwd_full: nhalves = %d", f->nhalves);
+    A8_REQUIRE(f->nhalves == 1 || aux_stream != main_stream, "a8_encoder_layer_bwd_full: two ranges need two streams");
+    A8_REQUIRE(side_stream != nullptr && side_stream != main_stream, "a8_encoder_layer_bwd_full: the weight gradients need their own stream");
+    const a8_encoder_layer_bwd_desc& h0 = f->half[0];
+    const int d = h0.d, dff = h0.dff, dtype = h0.dtype;
+    int rows = 0;
+    for (int i = 0; i < f->nhalves; ++i) {
+        A8_REQUIRE(f->half[i].d == d && f->half[i].dff == dff && f->half[i].dtype == dtype && f->half[i].T == h0.T, "a8_encoder_layer_bwd_full: the ranges differ in shape");
+        rows += f->half[i].B * f->half[i].T;
+    }
+    A8_REQUIRE(rows == f->M, "a8_encoder_layer_bwd_full: M = %d, the ranges hold %d rows", f->M, rows);
+    A8_REQUIRE((f->ln1_ws == nullptr) == (f->ln2_ws == nullptr), "a8_encoder_layer_bwd_full: ln1_ws and ln2_ws go together");
+    EventPair& ev = layer_events();
+    if (!ev.ok) return a8_set_error(A8_ERR_LAUNCH, "a8_encoder_layer_bwd_full: could not create its events");
+    hipStream_t sm = (hipStream_t)main_stream, sa = (hipStream_t)aux_stream, ss = (hipStream_t)side_stream;
+    // 1. the data-gradient chains
+    if (int rc = a8_encoder_layer_bwd(&f->half[0], main_stream)) return rc;
+    if (f->nhalves == 2)
+        if (int rc = a8_encoder_layer_bwd(&f->half[1], aux_stream)) return rc;
+    // 2. the weight-gradient stream follows both
+    bool okev = hipEventRecord(ev.e[0], sm) == hipSuccess && hipStreamWaitEvent(ss, ev.e[0], 0) == hipSuccess;
+    if (f->nhalves == 2) okev = okev && hipEventRecord(ev.e[1], sa) == hipSuccess && hipStreamWaitEvent(ss, ev.e[1], 0) == hipSuccess;
+    if (!okev) return a8_set_error(A8_ERR_LAUNCH, "a8_encoder_layer_bwd_full: stream ordering failed: %s", hipGetErrorString(hipGetLastError()));
+    // 3. weight gradients (one grouped launch: df^T h, dz1^T x1, dao^T o, dqkv^T x), then the small column-sum work
+    a8_gemm_desc g[4] = {tn_desc(dtype, h0.df, f->h, f->dw2, d, dff, f->M, f->acc_w2), tn_desc(dtype, h0.dz1, h0.x1, f->dw1, dff, d, f->M, f->acc_w1),
+                         tn_desc(dtype, h0.dao, h0.o, f->dwo, d, d, f->M, f->acc_wo), tn_desc(dtype, h0.dqkv, h0.x, f->dwqkv, 3 * d, d, f->M, f->acc_wqkv)};
+    if (int rc = a8_gemm_grouped(g, 4, side_stream)) return rc;
+    if (f->ln1_ws) {
+        if (int rc = a8_colsum_partials_reduce(f->ln1_ws, f->ln_rows, d, h0.dg1, h0.dbe1, h0.db2, side_stream)) return rc;
+        if (int rc = a8_colsum_partials_reduce(f->ln2_ws, f->ln_rows, d, h0.dg2, h0.dbe2, h0.dbo, side_stream)) return rc;
+    }
+    if (f->dbqkv)
+        if (int rc = a8_gelu_bwd_bias(dtype, h0.dqkv, nullptr, nullptr, f->dbqkv, f->M, 3 * d, side_stream)) return rc;
+    // 4. the QKV data gradient (+ the residual branch's gradient), each range on its stream
+    const int esz = dtype == A8_BF16 ? 2 : 4;
+    int r0 = 0;
+    for (int i = 0; i < f->nhalves; ++i) {
+        const a8_encoder_layer_bwd_desc& hi = f->half[i];
+        const int m = hi.B * hi.T;
+        a8_gemm_desc q = nt_desc(dtype, hi.dqkv, f->wqkv_t, (char*)f->dx + (size_t)r0 * d * esz, m, d, 3 * d, nullptr);
+        q.act = A8_ACT_ADD; q.zin = hi.dx_res; q.ldz = d;
+        if (int rc = a8_gemm(&q, i == 0 ? main_stream : aux_stream)) return rc;
+        r0 += m;
+    }
+    return A8_OK;
+}

@@ -168,6 +168,64 @@ def encoder_layer_bwd(dx2, x, keymask, qkv, o, lse, ao, x1, mean2, rstd2, z1, f,
     return df, dz1, dao, dqkv, dx_res, ws
 
 
+def encoder_layer_bwd_full(dx2, x, keymask, qkv, o, lse, ao, x1, mean2, rstd2, z1, h, f, mean1, rstd1, g1, g2, w2_t, w1_t, wo_t, wqkv_t,
+                           dg1, dbe1, dg2, dbe2, db2, db1, dbo, dw2, dw1, dwo, dwqkv, acc, dbqkv, B, T, H, p, seeds, aux_stream, side_stream):
+    """a8_encoder_layer_bwd_full: the whole backward of one encoder layer in ONE C call -- the data-gradient chains (two utterance ranges on
+    the current stream and aux_stream when one is given), the grouped weight gradients + LayerNorm / bias reductions on side_stream behind
+    both, the QKV data gradient per range.  Same launches, same order per stream as encoder_layer_bwd + the Python that followed it.
+    acc: four flags (accumulate into / store over the weight-gradient targets).  Returns (dx, temporaries): the caller keeps the
+    temporaries alive for the streams that still read them (record_stream) -- they are the operands of the side stream's launches."""
+    M, d = x.shape
+    dff = z1.shape[1]
+    dev, dt = x.device, x.dtype
+    n_d = 7 if p > 0 else 5
+    slab = torch.empty((n_d, M, d), device=dev, dtype=dt)
+    slabs = slab.unbind(0)
+    df, dx1_ffn, dao, dout_o, dx = slabs[:5]
+    dx1_res, dx_res = (slabs[5], slabs[6]) if p > 0 else (df, dao)
+    dz1 = torch.empty((M, dff), device=dev, dtype=dt)
+    dqkv = torch.empty((M, 3 * d), device=dev, dtype=dt)
+    delta = torch.empty((B, H, T), device=dev, dtype=torch.float32)
+    es = x.element_size()
+    split = aux_stream is not None and B >= 2
+    halves = [(0, B // 2), (B // 2, B - B // 2)] if split else [(0, B)]
+    nrows = [L.lib().a8_layernorm_bwd_partial_rows(nb * T) for _, nb in halves]
+    ws = torch.empty((2, sum(nrows), 3, d), device=dev, dtype=torch.float32)
+    fd = L.EncoderLayerBwdFullDesc()
+    fd.size, fd.nhalves, fd.M = L.ENC_BWD_FULL_DESC_SIZE, len(halves), M
+    wsp = ws.data_ptr()
+    prow = 0
+    for i, (b0, nb) in enumerate(halves):
+        r0 = b0 * T
+        rd, rf = r0 * d * es, r0 * dff * es
+        wp0, wp1 = wsp + prow * 3 * d * 4, wsp + (sum(nrows) + prow) * 3 * d * 4
+        prow += nrows[i]
+        fd.half[i] = L.EncoderLayerBwdDesc(
+            L.ENC_BWD_DESC_SIZE, L.dt(x), nb, T, H, d, dff, p, _u32(seeds[0]), _u32(seeds[1]), _u32(seeds[2]), b0,
+            dx2.data_ptr() + rd, x.data_ptr() + rd, qkv.data_ptr() + 3 * rd, o.data_ptr() + rd, ao.data_ptr() + rd,
+            x1.data_ptr() + rd, z1.data_ptr() + rf, f.data_ptr() + rd,
+            keymask.data_ptr() + r0 if keymask is not None else None,
+            lse.data_ptr() + 4 * b0 * H * T, mean2.data_ptr() + 4 * r0, rstd2.data_ptr() + 4 * r0,
+            mean1.data_ptr() + 4 * r0, rstd1.data_ptr() + 4 * r0, g1.data_ptr(), g2.data_ptr(),
+            w2_t.data_ptr(), w1_t.data_ptr(), wo_t.data_ptr(),
+            dg1.data_ptr(), dbe1.data_ptr(), dg2.data_ptr(), dbe2.data_ptr(), db2.data_ptr(), db1.data_ptr(), dbo.data_ptr(),
+            df.data_ptr() + rd, dx1_res.data_ptr() + rd, dz1.data_ptr() + rf, dx1_ffn.data_ptr() + rd, dao.data_ptr() + rd,
+            dx_res.data_ptr() + rd, dout_o.data_ptr() + rd, dqkv.data_ptr() + 3 * rd, delta.data_ptr() + 4 * b0 * H * T, wp0, wp1)
+    fd.h, fd.wqkv_t, fd.dx = h.data_ptr(), wqkv_t.data_ptr(), dx.data_ptr()
+    fd.dw2, fd.dw1, fd.dwo, fd.dwqkv = dw2.data_ptr(), dw1.data_ptr(), dwo.data_ptr(), dwqkv.data_ptr()
+    fd.acc_w2, fd.acc_w1, fd.acc_wo, fd.acc_wqkv = (1 if a else 0 for a in acc)
+    fd.dbqkv = dbqkv.data_ptr()
+    fd.ln1_ws, fd.ln2_ws, fd.ln_rows = wsp, wsp + sum(nrows) * 3 * d * 4, sum(nrows)
+    temps = (slab, dz1, dqkv, delta, ws)
+    for t_ in temps + (dx2,):
+        if split:
+            t_.record_stream(aux_stream)
+        t_.record_stream(side_stream)
+    L.check(L.lib().a8_encoder_layer_bwd_full(C.byref(fd), L.stream(), aux_stream.cuda_stream if split else None, side_stream.cuda_stream),
+            "a8_encoder_layer_bwd_full")
+    return dx, temps
+
+
 def colsum_partials_reduce(ws, out0, out1, out2):
     """out_k += column sums of ws[:, k, :] (ws f32 [rows, 3, cols]: the partial rows of a LayerNorm backward launch); on the current stream."""
     rows, three, cols = ws.shape

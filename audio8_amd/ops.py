@@ -824,6 +824,7 @@ class PosConvFn(torch.autograd.Function):
 ATTN_BIAS_FUSED = False
 COMPOSITE_ENCODER_FWD = True          # one C call per encoder layer forward (host time; the kernels are the same)
 COMPOSITE_ENCODER_BWD = True          # ... and per data-gradient chain of its backward
+COMPOSITE_ENCODER_BWD_FULL = True     # ... or (round 6) ONE call for the whole layer's backward incl. its side-stream work (a8_encoder_layer_bwd_full)
 
 
 class EncoderLayerFn(torch.autograd.Function):
@@ -937,6 +938,22 @@ class EncoderLayerFn(torch.autograd.Function):
             aux = _BWD_AUX_LIVE if (_BWD_AUX_LIVE is not None and _BWD_AUX_LIVE is ctx.half_aux) else None
             if aux is None:
                 _bwd_join()
+            side = WGRAD_SIDE_STREAM
+            if (COMPOSITE_ENCODER_BWD_FULL and side is not None and LN_PARTIALS and SIDE_EXTRAS
+                    and all(t_.is_contiguous() for t_ in (x, qkv, o, ao, x1, z1, h, f))):
+                # the whole layer behind ONE C call (a8_encoder_layer_bwd_full): the chains, the side stream's grouped weight gradients and
+                # column-sum work behind both, the QKV data gradients.  Same launches, same order per stream as the code below.
+                params4 = ((w2,), (w1,), (wo,), (wq, wk, wv))
+                acc = [not _first_touch(*ps) for ps in params4]              # (decided before anything is reported ready)
+                dx, temps = K.encoder_layer_bwd_full(
+                    dx2, x, keymask, qkv, o, lse, ao, x1, mean2, rstd2, z1, h, f, mean1, rstd1, g1, g2, w2_t, w1_t, wo_t, wqkv_t,
+                    dg1, dbe1, dg2, dbe2, tb2, tb1, tbo, _target(w2), _target(w1), _target(wo), _span3(tw[0], (3 * d, d)), acc,
+                    _span3(tb[0], (3 * d,)), B, T, H, p, (seed_a, seed1, seed2), aux, side)
+                for t_ in (x, qkv, o, ao, x1, z1, h, f, lse):               # the saved forward tensors are read on the side stream too
+                    t_.record_stream(side)
+                with torch.cuda.stream(side):                                # every parameter gradient of the layer is final in side-stream order
+                    _ready(w2, w1, wo, wq, wk, wv, pg1, pbe1, b2, b1, pg2, pbe2, bo, bq, bk, bv)
+                return (dx,) + (None,) * 22
             # the LayerNorm / bias column sums leave the chain as per-block partial rows and are added up on the weight-gradient stream
             # (no same-address atomics on the critical streams: LN_PARTIALS)
             lnp = LN_PARTIALS and WGRAD_SIDE_STREAM is not None

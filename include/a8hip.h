@@ -23,7 +23,7 @@ extern "C" {
  * to load (audio8_amd/_lib.py checks a8_version() == the value it was written for).  Since 120 every descriptor struct also starts with
  * `size` = sizeof(the struct as the CALLER compiled it): an entry point returns A8_ERR_ARG instead of reading a shorter or longer struct
  * than its own (120: size fields; a8_ctc_fwd_bwd's scratch grew to A8_CTC_SCRATCH_FLOATS; a8_get_tuning, a8_delay_us,
- * a8_encoder_stack_bwd). */
+ * a8_encoder_layer_bwd_full). */
 #define A8HIP_VERSION 120
 
 enum { A8_DT_F32 = 0, A8_DT_BF16 = 1 };
@@ -233,6 +233,26 @@ typedef struct a8_encoder_layer_bwd_desc {
                                              a8_colsum_partials_reduce on any stream ordered behind this call */
 } a8_encoder_layer_bwd_desc;
 int a8_encoder_layer_bwd(const a8_encoder_layer_bwd_desc* e, void* stream);
+/* The WHOLE backward of that layer as one call (round 6: the host's share -- one Python thread per GPU issues the step, audio8/pretrain.py:171-186):
+ * the chains of one or two utterance ranges (half[0] on `main`, half[1] on `aux`), then -- on `side`, behind both -- the four weight
+ * gradients as one grouped launch, the LayerNorm / bias partial-row reductions and the q / k / v bias column sums, and the QKV data
+ * gradient dx = dqkv Wqkv + dx_res per range on its own stream.  Issues exactly the launches of a8_encoder_layer_bwd + a8_gemm_grouped +
+ * a8_colsum_partials_reduce + a8_gelu_bwd_bias + a8_gemm in the order audio8_amd/ops.py issues them; stream ordering by two events of its
+ * own per call.  half[i] as for a8_encoder_layer_bwd (rows of range i); half[0] starts at the batch's first row, the ranges are adjacent. */
+typedef struct a8_encoder_layer_bwd_full_desc {
+    int size;                                   /* sizeof(a8_encoder_layer_bwd_full_desc) */
+    int nhalves;                                /* 1: the whole batch on `main`; 2: half[1] on `aux` */
+    a8_encoder_layer_bwd_desc half[2];
+    int M;                                      /* rows of the whole batch */
+    const void* h;                              /* [M, dff] FFN activations (operand of the w_2 weight gradient) */
+    const void* wqkv_t;                         /* [d, 3d] transposed working copy of the fused QKV weight */
+    void* dx;                                   /* out [M, d] */
+    float *dw2, *dw1, *dwo, *dwqkv;             /* f32 [d,dff], [dff,d], [d,d], [3d,d] */
+    int acc_w2, acc_w1, acc_wo, acc_wqkv;       /* 1: accumulate (f32 atomics); 0: first gradient into a clean slot, stored */
+    float* dbqkv;                               /* f32 [3d] += column sums of dqkv */
+    const float *ln1_ws, *ln2_ws; int ln_rows;  /* the partial rows of both ranges (what half[i].ln*_partials point into), contiguous; or NULL */
+} a8_encoder_layer_bwd_full_desc;
+int a8_encoder_layer_bwd_full(const a8_encoder_layer_bwd_full_desc* f, void* main_stream, void* aux_stream, void* side_stream);
 /* LayerNorm backward without same-address atomics (audio8/wav2vec2.py:613-623 LayerNorms' weight / bias gradients): the number of
  * partial rows one backward launch over `rows` rows writes, and the reduction out_k[c] += sum_b ws[b][k][c] (ws f32 [nrows][3][cols]; a NULL
  * out_k is skipped).  391 x 2304 same-address atomics per launch forced few, fat, latency-exposed blocks: -0.06 ms per step, and the sums are

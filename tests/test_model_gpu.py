@@ -201,6 +201,51 @@ def test_composite_encoder_calls_match_the_per_launch_path(restore_dtype, dtype)
             torch.testing.assert_close(g, outs[1][1][n], rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("B", [1, 3, 4])
+def test_whole_layer_backward_call_matches_the_per_call_path(restore_dtype, B):
+    """a8_encoder_layer_bwd_full (round 6: ONE C call per encoder layer's backward -- both half-batch chains, the side stream's grouped weight
+    gradients + LayerNorm / bias reductions behind them, the QKV data gradients) issues the launches of the path it replaces in the same
+    order per stream: a training step with dropout gives the bit-identical loss, every gradient equal to the order of its f32 atomic sums
+    and the same parameters after the optimizer step -- whole batch (B = 1), unequal halves (3) and equal halves (4)."""
+    from audio8_amd import ops, wav2vec2 as W
+    from audio8_amd.trainer import Stepper
+    ops.set_compute_dtype(torch.bfloat16)
+    x = synth(B, 24000, 9).cuda()
+    outs = []
+    try:
+        for flag in (False, True):
+            ops.COMPOSITE_ENCODER_BWD_FULL = flag
+            torch.manual_seed(5)
+            np.random.seed(5)
+            ops.reset_seed_stream()
+            m = W.create_model(num_layers=3, dropout=0.1).cuda().train()
+            loss_fn = W.create_loss(640, 100)
+            st = Stepper(m, lr=1e-4, clip=1.0)
+            try:
+                rec = []
+                for _ in range(2):                      # two steps: first-touch stores on the first, the second starts from cleared gradients
+                    st.zero_grad()
+                    loss = loss_fn(m, x)
+                    loss.backward()
+                    st.sync_grads()
+                    torch.cuda.synchronize()
+                    rec.append((float(loss.detach()), st.state.flat_g.clone()))
+                    st.step()
+                torch.cuda.synchronize()
+                outs.append(rec)
+            finally:
+                st.close()
+    finally:
+        ops.COMPOSITE_ENCODER_BWD_FULL = True
+    assert outs[0][0][0] == outs[1][0][0]                                             # same launches, same seeds: the first loss bit for bit
+    for k in (0, 1):
+        # (step 2 starts from parameters that AdamW moved by +-lr wherever a gradient is rounding noise around zero -- its sign is not
+        # information, tests/test_dp_gpu.py -- so its loss agrees to 1e-3 and its gradients to the scale such moves leave)
+        assert abs(outs[0][k][0] - outs[1][k][0]) <= 1e-3 * abs(outs[0][k][0]) * k
+        scale = float(outs[0][k][1].abs().max())
+        assert float((outs[0][k][1] - outs[1][k][1]).abs().max()) <= (1e-4 if k == 0 else 5e-2) * scale, k      # step 1: f32 atomic sums in another order
+
+
 def test_pretrain_step_parity_bf16_full_depth_base(restore_dtype):
     """The benchmark dtype at the benchmark depth against the ORACLE (not against the product's own f32 mode): wav2vec2-base, 12 layers,
     2 x 16 000 samples.  Stated tolerance of the bf16 mode (bf16 activations and residual stream, f32 accumulation / statistics / masters):
