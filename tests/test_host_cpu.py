@@ -291,3 +291,40 @@ def test_flat_layout_keeps_late_gradients_out_of_the_first_buckets():
             if n.endswith("w_Q.layer.weight"):
                 stem = n[:-len("w_Q.layer.weight")]
                 assert order[k:k + 6] == [stem + f"w_{c}.layer.{leaf}" for leaf in ("weight", "bias") for c in "QKV"]
+
+
+def test_abi_descriptor_sizes_and_tuning_round_trip():
+    """ABI 120 (include/a8hip.h): every descriptor starts with its own sizeof and an entry point refuses another layout BEFORE it touches
+    the GPU (status 1 + a8_last_error text, no launch: runs on a box without one); a8_set_tuning / a8_get_tuning round trip, unknown keys
+    are errors; the binding's struct sizes are the library's (the size checks pass for the binding's own structs up to the first
+    argument check)."""
+    import ctypes as C
+    from audio8_amd import _lib as L
+    lib = L.lib()
+    assert lib.a8_version() == L.ABI_VERSION == 120
+    d = L.GemmDesc()
+    d.size = L.GEMM_DESC_SIZE - 8                                   # a binding built against a shorter struct
+    assert lib.a8_gemm(C.byref(d), None) == 1 and b"descriptor size" in lib.a8_last_error()
+    d.size = L.GEMM_DESC_SIZE
+    d.dtype = 7                                                     # the right size gets as far as the argument checks
+    assert lib.a8_gemm(C.byref(d), None) == 1 and b"bad dtype" in lib.a8_last_error()
+    for cls, fn, size in ((L.EncoderLayerDesc, lib.a8_encoder_layer_fwd, L.ENC_DESC_SIZE), (L.EncoderLayerBwdDesc, lib.a8_encoder_layer_bwd, L.ENC_BWD_DESC_SIZE)):
+        e = cls()
+        e.size = size + 8
+        assert fn(C.byref(e), None) == 1 and b"descriptor size" in lib.a8_last_error()
+        e.size = size
+        assert fn(C.byref(e), None) == 1 and b"bad sizes" in lib.a8_last_error()
+    f = L.EncoderLayerBwdFullDesc()
+    f.size = 16
+    assert lib.a8_encoder_layer_bwd_full(C.byref(f), None, None, None) == 1 and b"descriptor size" in lib.a8_last_error()
+    f.size, f.nhalves = L.ENC_BWD_FULL_DESC_SIZE, 3
+    assert lib.a8_encoder_layer_bwd_full(C.byref(f), None, None, None) == 1 and b"nhalves" in lib.a8_last_error()
+    v = C.c_int(-1)
+    assert lib.a8_get_tuning(5, C.addressof(v)) == 0
+    found = v.value
+    try:
+        assert lib.a8_set_tuning(5, 12345) == 0 and lib.a8_get_tuning(5, C.addressof(v)) == 0 and v.value == 12345
+    finally:
+        assert lib.a8_set_tuning(5, found) == 0
+    assert lib.a8_set_tuning(99, 1) == 1 and lib.a8_get_tuning(-1, C.addressof(v)) == 1 and lib.a8_get_tuning(5, None) == 1
+    assert lib.a8_delay_us(C.c_float(-1.0), None) == 1              # (argument check; a positive delay would launch)
