@@ -360,14 +360,17 @@ def ctc_loss_np(log_prob, input_lengths, targets, target_lengths, reduction="sum
         ext[1::2] = lab
         can_skip = np.zeros(L, dtype=bool)
         can_skip[3::2] = lab[1:] != lab[:-1]
+        if Tb == 0:                                   # no frames: only the empty target has an alignment (ATen: loss 0), else -inf likelihood
+            nll[b] = 0.0 if S == 0 else np.inf
+            continue
         la = np.full((Tb, L), NEG)
         la[0, 0] = lp[0, b, blank]
         if L > 1:
             la[0, 1] = lp[0, b, ext[1]]
         for t in range(1, Tb):
             prev = la[t - 1]
-            a1 = np.concatenate([[NEG], prev[:-1]])
-            a2 = np.where(can_skip, np.concatenate([[NEG, NEG], prev[:-2]]), NEG)
+            a1 = np.concatenate([[NEG], prev])[:L]
+            a2 = np.where(can_skip, np.concatenate([[NEG, NEG], prev])[:L], NEG)           # (slices: L = 1, the empty target, included)
             la[t] = np.logaddexp(np.logaddexp(prev, a1), a2) + lp[t, b, ext]
         ll = np.logaddexp(la[Tb - 1, L - 1], la[Tb - 1, L - 2]) if L > 1 else la[Tb - 1, 0]
         nll[b] = -ll
@@ -377,11 +380,11 @@ def ctc_loss_np(log_prob, input_lengths, targets, target_lengths, reduction="sum
         lb[Tb - 1, L - 1] = lp[Tb - 1, b, blank]
         if L > 1:
             lb[Tb - 1, L - 2] = lp[Tb - 1, b, ext[L - 2]]
-        skip_next = np.concatenate([can_skip[2:], [False, False]])
+        skip_next = np.concatenate([can_skip[2:], [False, False]])[:L]
         for t in range(Tb - 2, -1, -1):
             nxt = lb[t + 1]
             b1 = np.concatenate([nxt[1:], [NEG]])
-            b2 = np.where(skip_next, np.concatenate([nxt[2:], [NEG, NEG]]), NEG)
+            b2 = np.where(skip_next, np.concatenate([nxt[2:], [NEG, NEG]])[:L], NEG)
             lb[t] = np.logaddexp(np.logaddexp(nxt, b1), b2) + lp[t, b, ext]
         ab = la + lb                                        # log(alpha*beta), contains lp once extra
         for t in range(Tb):

@@ -685,6 +685,55 @@ def test_ctc_against_golden_and_oracle(golden_dir, tag):
     np.testing.assert_allclose(grad.cpu().numpy(), g[f"{tag}_sum_grad"], rtol=1e-3, atol=atol)
 
 
+@pytest.mark.parametrize("case", ["small-v", "chunk-edges", "one-frame-chunks", "big-v", "states-per-lane"])
+def test_ctc_random_shapes_against_the_f64_oracle(case):
+    """The round-6 CTC kernels (alpha / beta on two waves per utterance with LDS-staged rows, gradient as a parallel launch) over the
+    shapes their staging distinguishes, against the float64 restatement of F.ctc_loss (audio8/ctc.py:186-206): vocabularies that put
+    1 .. 64 frames in a 1024-float chunk, utterance lengths on and next to chunk boundaries, V > 1024 (one frame at a time), every
+    states-per-lane instantiation (2 S + 1 = 1 .. 1023), repeated labels, empty targets, ragged and zero input lengths, infeasible rows."""
+    from audio8_amd import kernels as K
+    from oracle import ref_cpu as R
+    rs = np.random.RandomState({"small-v": 1, "chunk-edges": 2, "one-frame-chunks": 3, "big-v": 4, "states-per-lane": 5}[case])
+    if case == "small-v":
+        configs = [(rs.randint(1, 120), rs.randint(1, 7), V, rs.randint(0, 20)) for V in (3, 5, 16, 17, 33, 100)]
+    elif case == "chunk-edges":                       # V = 32: 32 frames per chunk; V = 16: 64; lengths around multiples of the chunk
+        configs = [(T, 3, 32, 9) for T in (31, 32, 33, 64, 65, 96)] + [(T, 2, 16, 5) for T in (63, 64, 65, 129)]
+    elif case == "one-frame-chunks":                  # 512 < V <= 1024: one frame per chunk
+        configs = [(rs.randint(3, 40), 2, V, 6) for V in (513, 700, 1024)]
+    elif case == "big-v":                             # V > 1024: the synchronous path
+        configs = [(rs.randint(3, 30), 2, V, 5) for V in (1025, 1500, 3000)]
+    else:
+        configs = [(2 * S + 6, 2, 12, S) for S in (0, 1, 31, 32, 33, 64, 100, 160, 255, 300, 448, 511)]
+    for T, B, V, Smax in configs:
+        lp = torch.log_softmax(torch.from_numpy(rs.standard_normal((T, B, V)).astype(np.float32)) * 2.0, -1)
+        tl = rs.randint(0, Smax + 1, B)
+        tl[0] = Smax                                   # (the launch's states-per-lane count follows the longest target)
+        il = rs.randint(0, T + 1, B)
+        il[0] = T
+        if B > 1:
+            il[-1] = min(T, max(0, int(tl[-1]) - 1))   # too short for its target: infeasible (zero_infinity)
+        targets = np.full((B, Smax + 2), 1, dtype=np.int64)
+        for b in range(B):
+            lab = rs.randint(1, V, int(tl[b]))
+            if tl[b] > 3:
+                lab[1] = lab[0]                        # a repeated label (no skip transition across it)
+            lab[lab == 1] = min(3, V - 1) if V > 2 else 1
+            lab[lab == 2] = min(3, V - 1) if V > 3 else lab[lab == 2]
+            targets[b, :tl[b]] = lab
+            targets[b, tl[b]] = 2
+        if V <= 3:
+            continue
+        flat = R.ctc_strip_targets(targets).astype(np.int32)
+        assert flat.size == int(tl.sum())
+        off = np.concatenate([[0], np.cumsum(tl)]).astype(np.int32)
+        nll, grad = K.ctc_fwd_bwd(lp.cuda(), torch.from_numpy(flat).cuda(), torch.from_numpy(off).cuda(), torch.from_numpy(il.astype(np.int32)).cuda(),
+                                  int(max(1, tl.max())))
+        want_nll, want_grad = R.ctc_loss_np(lp.numpy(), il, targets, tl, reduction="none")
+        tag = "T=%d B=%d V=%d Smax=%d il=%s tl=%s" % (T, B, V, Smax, il.tolist(), tl.tolist())
+        np.testing.assert_allclose(nll.cpu().numpy(), want_nll, rtol=3e-5, atol=1e-5, err_msg=tag)
+        np.testing.assert_allclose(grad.cpu().numpy(), want_grad, rtol=1e-3, atol=3e-5, err_msg=tag)
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_log_softmax(dtype):
     from audio8_amd import kernels as K
