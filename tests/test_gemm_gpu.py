@@ -445,3 +445,64 @@ def test_gemm_direct_epilogue_matches_lds_staged():
         return (dx,)
     same(both(conv_dgrad_grouped), "conv dgrad, grouped even + odd")
 
+
+
+def test_gemm_lean_addressing_matches_predicate_form_and_k_zero_takes_it():
+    """(1) a direct bit-identity A/B of the lean operand addressing of the 128 x 128 NT kernels (KFAST: fixed per-lane
+    pointer + block-uniform k offset, clamped tail rows) against the predicate form (a8_set_tuning key 25 = 1) -- whole k-tiles only, M / N
+    tails, split-K, the conv row remap, the grouped launch; (2) K = 0 -- an empty reduction, which satisfies K % 64 == 0 -- must NOT take the
+    lean form (it would address k-tile -1, 128 bytes in front of every row): C = bias with and without the key, no fault."""
+    from audio8_amd import kernels as Kn, _lib as L
+    dev, bf = "cuda", torch.bfloat16
+
+    def both(fn):
+        try:
+            L.check(L.lib().a8_set_tuning(14, 1), "tune")
+            L.check(L.lib().a8_set_tuning(5, 0), "tune")
+            L.check(L.lib().a8_set_tuning(25, 1), "tune")
+            ref = fn()
+            L.check(L.lib().a8_set_tuning(25, 0), "tune")
+            got = fn()
+        finally:
+            for k_, v_ in {14: 1000, 5: 20000, 25: 0}.items():
+                L.check(L.lib().a8_set_tuning(k_, v_), "tune")
+        return ref, got
+
+    for (M, N, K) in [(128, 128, 64), (1000, 768, 768), (3124, 2304, 768), (333, 136, 128), (6248, 768, 3072)]:
+        A, B = _mk((M, K), bf, 1).to(dev), _mk((N, K), bf, 2).to(dev)
+        z = _mk((M, N), bf, 3).to(dev)
+        bias = torch.randn(N, device=dev)
+        for what, fn in (("plain", lambda: Kn.gemm(L.NT, A, B, M, N, K)),
+                         ("bias + gelu", lambda: Kn.gemm(L.NT, A, B, M, N, K, bias=bias, act=L.ACT_GELU)),
+                         ("x gelu'(z)", lambda: Kn.gemm(L.NT, A, B, M, N, K, act=L.ACT_MUL_GELU_GRAD, zin=z)),
+                         ("split-K f32", lambda: Kn.gemm(L.NT, A, B, M, N, K, out_dtype=torch.float32, splitk=2 if K >= 128 else 1,
+                                                         out=torch.zeros(M, N, device=dev)))):
+            r, g_ = both(fn)
+            if what == "split-K f32":                       # (atomic partial sums: equal to the order of two f32 adds)
+                torch.testing.assert_close(r, g_, rtol=1e-6, atol=1e-6)
+            else:
+                assert torch.equal(r, g_), (what, M, N, K)
+    # a strided conv as a GEMM (overlapping rows): Lin = 100, k = 3, s = 2, cin = 64 -> K = 192
+    Bn, Lin, cin, co, kk, st = 3, 101, 64, 128, 3, 2
+    Lout = (Lin - kk) // st + 1
+    x = _mk((Bn, Lin, cin), bf, 5).to(dev)
+    w = _mk((co, kk * cin), bf, 6).to(dev)
+    r, g_ = both(lambda: Kn.gemm(L.NT, x, w, Bn * Lout, co, kk * cin, lda=st * cin, a_rpb=Lout, a_bs=Lin * cin))
+    assert torch.equal(r, g_), "conv row remap"
+    probs = lambda: Kn.gemm_grouped(L.NT, [(_A, _B, m, n, k, {}) for (_A, _B, m, n, k) in grp])       # noqa: E731
+    grp = [(_mk((m, k), bf, 7 + i).to(dev), _mk((n, k), bf, 17 + i).to(dev), m, n, k) for i, (m, n, k) in enumerate([(1000, 256, 128), (1300, 128, 256)])]
+    r, g_ = both(probs)
+    for a_, b_ in zip(r, g_):
+        assert torch.equal(a_, b_), "grouped"
+    # K = 0
+    M, N = 1500, 256
+    A0, B0 = torch.empty((M, 0), device=dev, dtype=bf), torch.empty((N, 0), device=dev, dtype=bf)
+    bias = torch.randn(N, device=dev)
+    for key25 in (0, 1):
+        try:
+            L.check(L.lib().a8_set_tuning(25, key25), "tune")
+            out = Kn.gemm(L.NT, A0, B0, M, N, 0, bias=bias, lda=8, ldb=8)
+            torch.cuda.synchronize()
+        finally:
+            L.check(L.lib().a8_set_tuning(25, 0), "tune")
+        assert torch.equal(out, bias.to(bf).expand(M, N)), key25
