@@ -3,10 +3,10 @@
 #include "../../include/a8hip.h"
 #include <atomic>
 
-// a8_set_tuning table (runtime.hip): [1] ln_bwd geometry NW*100 + rows per wave, [2..4] attention fwd / dK,dV / dQ launch geometry,
+// a8_set_tuning table (runtime.hip): [1] ln_bwd geometry NW*100 + rows per wave, [2..4] attention fwd / dK,dV / dQ launch geometry ([3], [4] = 32: the 32 x 32-MFMA backward kernels),
 // [5] min M for the stream NT GEMM of gemm_stream.hip (0 = off), [7] its forced tile height (0 = per launch), [8] its grid oversubscription, [6] posconv wgrad loop splits, [9] conv layer 0 on the VALU,
 // [14] min M for the asymmetric-ring NT GEMM, [17] ln_bwd geometry of the partial-row form, [19] stream GEMM for plain problems too, [20] / [21] AdamW grid / cache policy,
-// [22] = 1: LDS-staged epilogue in the NT kernels, [23] = 1: residual add in the FFN data gradient's epilogue; the rest spare
+// [22] = 1: LDS-staged epilogue in the NT kernels, [23] = 1: residual add in the FFN data gradient's epilogue, [25] = 1: predicate-form operand addressing; the rest spare
 // process-wide, atomically read and written (runtime.hip); g_a8_tuning[k] reads key k as a plain int
 struct A8TuningTable {
     std::atomic<int> v[32];

@@ -65,7 +65,8 @@ int a8_gemm(const a8_gemm_desc* d, void* stream);
  * per-parameter autograd GEMMs as a8_gemm. */
 int a8_gemm_grouped(const a8_gemm_desc* descs, int n, void* stream);
 /* developer tuning knobs, never needed for correctness (defaults are the measured best): key 1 LayerNorm-backward geometry
- * (waves*100 + rows per wave); 2..4 attention fwd / dK,dV / dQ launch geometry; 5 minimum M for the
+ * (waves*100 + rows per wave); 2..4 attention fwd / dK,dV / dQ launch geometry (2: < 10 = the 32 x 32-MFMA forward kernel, default;
+ * 3 / 4: 41 = the 16 x 16 backward kernels, default; 32 = the round-6 32 x 32-MFMA backward kernels, tested and slower); 5 minimum M for the
  * stream bf16 NT GEMM (N % 256 == 0, K % 128 == 0: BM x 256 tiles on persistent blocks, the conv layers' forward; default 20000, 0 = off),
  * 7 its forced tile height (160 / 192 / 224 / 256; 0 = chosen per launch), 8 its grid in CUs' worths of persistent blocks (default 1: all
  * resident from the start; 2..4: shorter static shares, surplus blocks dispatched as CUs free up -- +0.09 ms alone on the GPU, for runs where
