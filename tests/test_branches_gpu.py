@@ -186,3 +186,34 @@ def test_8khz_feature_extractor_parity_f32(restore_dtype):
     loss16 = loss_fn(model, x.cuda())
     loss16.backward()
     np.testing.assert_allclose(loss16.item(), loss_ref.item(), rtol=3e-2)
+
+
+def test_bf16_eval_without_a_stepper_is_deterministic(restore_dtype):
+    """Round-6 regression: under torch.no_grad() without a Stepper every encoder layer casts its weights to bf16 on the fly; those casts
+    are temporaries, and the half-batch stream still read layer l's while the caching allocator handed their memory to layer l + 1's
+    (half of cfg5's frames decoded differently from run to run).  The same eval forward three times, with allocator churn in between,
+    must give bit-identical log-probs, close to the f32 mode's."""
+    from audio8_amd import ops, wav2vec2 as W
+    from oracle import ref_cpu as R
+    B, L, V, NL = 6, 48000, 32, 8
+    sd = R.init_state_dict(seed=11, num_layers=NL, ctc_labels=V)
+    x = synth(B, L, 3).cuda()
+    pad = R.sequence_mask(torch.tensor([48000, 41000, 30000, 48000, 20000, 35000]), L).cuda()
+    outs = {}
+    for dtype in (torch.float32, torch.bfloat16):
+        ops.set_compute_dtype(dtype)
+        model = W.create_acoustic_model(V, num_layers=NL, dropout=0.0)
+        model.load_state_dict(sd, strict=True)
+        model = model.cuda().eval()
+        model.freeze = False
+        runs = []
+        for i in range(3):
+            with torch.no_grad():
+                lp, _ = model(x, pad)
+            runs.append(lp.float().clone())
+            junk = [torch.empty(int(s), device="cuda") for s in (3e6, 7e5, 1.2e7)[: i + 1]]      # perturb what the allocator hands out next
+            del junk
+        torch.cuda.synchronize()
+        assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2]), dtype
+        outs[dtype] = runs[0]
+    assert float((outs[torch.float32] - outs[torch.bfloat16]).abs().max()) < 0.15

@@ -87,6 +87,10 @@ if __name__ == "__main__":
     ops.set_compute_dtype(torch.bfloat16)
     if os.environ.get("A8_HALF_BATCH", "1") == "0":        # developer A/B: the encoder stack as one whole-batch launch sequence
         ops.HALF_BATCH_STREAMS = False
+    for kv in filter(None, os.environ.get("A8_TUNE", "").split(",")):       # developer knobs, e.g. A8_TUNE=19=1,5=1000
+        from audio8_amd import _lib as L
+        k, v = kv.split("=")
+        L.check(L.lib().a8_set_tuning(int(k), int(v)), "a8_set_tuning")
     if which in ("cfg4", "both"):
         cfg4()
     if which in ("cfg5", "both"):
