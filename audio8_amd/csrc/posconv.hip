@@ -146,10 +146,18 @@ constexpr int WG_TAPS = 8, WG_BT = 64;
 template <typename T, int DG>
 __global__ __launch_bounds__(256) void posconv_wgrad_kernel(const char* __restrict__ xp, const char* __restrict__ dzp, float* __restrict__ dw,
                                                             int B, int Tn, int d, int pad_left) {
-    constexpr int EPC = 16 / (int)sizeof(T), CPX = DG / EPC, XROW = DG * (int)sizeof(T) + 16, NB = DG / 16;
+    constexpr int EPC = 16 / (int)sizeof(T), CPX = DG / EPC, NB = DG / 16;
     constexpr int XR = WG_BT + WG_TAPS - 1;
-    __shared__ __attribute__((aligned(16))) char xs[XR * XROW];
-    __shared__ __attribute__((aligned(16))) char zs[WG_BT * XROW];
+    // LDS image of a window row.  16-bit data is read back transposed (ds_read_b64_tr_b16: the 32 lanes of a group take 32 contiguous bytes of
+    // rows R .. R+3 and R+8 .. R+11, banks (address / 4) mod 64): with rows 96 B (DG = 48) or 160 B (DG = 64) apart and every block of 8 rows
+    // shifted by another 128 B those eight pieces cover the 64 banks exactly once for every R and column block.  (Round 6: the padded-row image
+    // [row][DG * 2 + 16] was 2-way conflicted on every read, 10.4 M conflict cycles per launch in profiles/r05_kernel_sq_counters.txt.)
+    constexpr bool TR = sizeof(T) == 2;
+    constexpr int XROW = TR ? (DG == 48 ? 96 : DG * 2 + 32) : DG * (int)sizeof(T) + 16;
+    auto roff = [](int r) { return TR ? r * XROW + 128 * (r >> 3) : r * XROW; };
+    constexpr int XS_BYTES = XR * XROW + (TR ? 128 * ((XR + 7) / 8) : 0), ZS_BYTES = WG_BT * XROW + (TR ? 128 * (WG_BT / 8) : 0);
+    __shared__ __attribute__((aligned(16))) char xs[XS_BYTES];
+    __shared__ __attribute__((aligned(16))) char zs[ZS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g4 = lane >> 4, li = lane & 15;
     const int grp = blockIdx.y, kk0 = blockIdx.x * WG_TAPS;
     f32x4 acc[2][NB][NB];
@@ -163,20 +171,44 @@ __global__ __launch_bounds__(256) void posconv_wgrad_kernel(const char* __restri
     // blockIdx.z splits the (utterance, 64-frame chunk) loop: 256 (group, tap-block) pairs alone leave one 4-wave block per CU
     const int per = (B * nt + (int)gridDim.z - 1) / (int)gridDim.z;
     const int it_end = min(B * nt, ((int)blockIdx.z + 1) * per);
-    for (int it = blockIdx.z * per; it < it_end; ++it) {
+    // The operands of iteration it + 1 are requested into registers before iteration it's MFMAs (round 6: the loop was load -> store -> barrier ->
+    // compute, one exposed global-memory round trip per 64 frames: ~35 of them per block were the kernel's 115 us).
+    constexpr int XL = (XR * CPX + 255) / 256, ZL = (WG_BT * CPX + 255) / 256;
+    u32x4 xr[XL], zr[ZL];
+    auto request = [&](int it) {
         const int b = it / nt, t0 = (it % nt) * WG_BT;
         const T* xb = reinterpret_cast<const T*>(xp) + (long long)b * Tn * d + grp * DG;
         const T* zb = reinterpret_cast<const T*>(dzp) + (long long)b * Tn * d + grp * DG;
-        __syncthreads();
-        for (int c = tid; c < XR * CPX; c += 256) {
-            const int r = c / CPX, cc = c % CPX, ts = t0 + r + kk0 - pad_left;
-            st16(xs + r * XROW + cc * 16, (ts >= 0 && ts < Tn) ? ld16(xb + (long long)ts * d + cc * EPC) : (u32x4){0u, 0u, 0u, 0u});
+#pragma unroll
+        for (int j = 0; j < XL; ++j) {
+            const int c = tid + 256 * j, r = c / CPX, cc = c % CPX, ts = t0 + r + kk0 - pad_left;
+            xr[j] = (c < XR * CPX && ts >= 0 && ts < Tn) ? ld16(xb + (long long)ts * d + cc * EPC) : (u32x4){0u, 0u, 0u, 0u};
         }
-        for (int c = tid; c < WG_BT * CPX; c += 256) {
-            const int r = c / CPX, cc = c % CPX, ts = t0 + r;
-            st16(zs + r * XROW + cc * 16, ts < Tn ? ld16(zb + (long long)ts * d + cc * EPC) : (u32x4){0u, 0u, 0u, 0u});
+#pragma unroll
+        for (int j = 0; j < ZL; ++j) {
+            const int c = tid + 256 * j, r = c / CPX, cc = c % CPX, ts = t0 + r;
+            zr[j] = (c < WG_BT * CPX && ts < Tn) ? ld16(zb + (long long)ts * d + cc * EPC) : (u32x4){0u, 0u, 0u, 0u};
         }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int j = 0; j < XL; ++j) {
+            const int c = tid + 256 * j, r = c / CPX, cc = c % CPX;
+            if (c < XR * CPX) st16(xs + roff(r) + cc * 16, xr[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < ZL; ++j) {
+            const int c = tid + 256 * j, r = c / CPX, cc = c % CPX;
+            if (c < WG_BT * CPX) st16(zs + roff(r) + cc * 16, zr[j]);
+        }
+    };
+    const int it_beg = blockIdx.z * per;
+    if (it_beg < it_end) request(it_beg);
+    for (int it = it_beg; it < it_end; ++it) {
+        __syncthreads();                              // every wave is done reading the previous iteration's image
+        commit();
         __syncthreads();
+        if (it + 1 < it_end) request(it + 1);
         if constexpr (sizeof(T) == 2) {
             const int q = li >> 2, p = li & 3;
 #pragma unroll
@@ -185,8 +217,8 @@ __global__ __launch_bounds__(256) void posconv_wgrad_kernel(const char* __restri
                 const int r0 = ks * 32 + 8 * g4 + q;
 #pragma unroll
                 for (int cb = 0; cb < NB; ++cb) {
-                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, zs + r0 * XROW + (16 * cb + 4 * p) * 2));
-                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, zs + (r0 + 4) * XROW + (16 * cb + 4 * p) * 2));
+                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, zs + roff(r0) + (16 * cb + 4 * p) * 2));
+                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, zs + roff(r0 + 4) + (16 * cb + 4 * p) * 2));
                     typedef short s16x8 __attribute__((ext_vector_type(8)));
                     s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     za[cb] = __builtin_bit_cast(bf16x8, v);
@@ -196,8 +228,8 @@ __global__ __launch_bounds__(256) void posconv_wgrad_kernel(const char* __restri
                     const int kk = wv * 2 + a;
 #pragma unroll
                     for (int ib = 0; ib < NB; ++ib) {
-                        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, xs + (r0 + kk) * XROW + (16 * ib + 4 * p) * 2));
-                        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, xs + (r0 + kk + 4) * XROW + (16 * ib + 4 * p) * 2));
+                        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, xs + roff(r0 + kk) + (16 * ib + 4 * p) * 2));
+                        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, xs + roff(r0 + kk + 4) + (16 * ib + 4 * p) * 2));
                         typedef short s16x8 __attribute__((ext_vector_type(8)));
                         s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                         const bf16x8 xbv = __builtin_bit_cast(bf16x8, v);
@@ -212,13 +244,13 @@ __global__ __launch_bounds__(256) void posconv_wgrad_kernel(const char* __restri
                 float za[NB];
                 const int r0 = ks * 4 + g4;
 #pragma unroll
-                for (int cb = 0; cb < NB; ++cb) za[cb] = *reinterpret_cast<const float*>(zs + r0 * XROW + (16 * cb + li) * 4);
+                for (int cb = 0; cb < NB; ++cb) za[cb] = *reinterpret_cast<const float*>(zs + roff(r0) + (16 * cb + li) * 4);
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
                     const int kk = wv * 2 + a;
 #pragma unroll
                     for (int ib = 0; ib < NB; ++ib) {
-                        const float xbv = *reinterpret_cast<const float*>(xs + (r0 + kk) * XROW + (16 * ib + li) * 4);
+                        const float xbv = *reinterpret_cast<const float*>(xs + roff(r0 + kk) + (16 * ib + li) * 4);
 #pragma unroll
                         for (int cb = 0; cb < NB; ++cb) acc[a][cb][ib] = Mma<float>::mma(za[cb], xbv, acc[a][cb][ib]);
                     }

@@ -268,7 +268,9 @@ def test_buckets_go_out_under_backward_and_a_slow_exchange_is_mostly_hidden():
     st = Stepper(model, clip=1.0)
     red = st.reducer
     cpus = sorted(os.sched_getaffinity(0))
+    nthreads = torch.get_num_threads()
     os.sched_setaffinity(0, cpus[:4])            # the launching thread placed as bench.py places it: unpinned, the step is host-bound in this process
+    torch.set_num_threads(4)                     # (and no wider OpenMP pool than cores: earlier CPU-side tests of the same process leave one per visible core)
     try:
         x = (0.1 * torch.randn(8, 250000, generator=torch.Generator().manual_seed(1))).clamp_(-1, 1).cuda()
 
@@ -314,6 +316,7 @@ def test_buckets_go_out_under_backward_and_a_slow_exchange_is_mostly_hidden():
         assert slow - base < 0.5 * serial, (base, slow, serial)
     finally:
         os.sched_setaffinity(0, cpus)
+        torch.set_num_threads(nthreads)
         red.fake_gbps, red.trace = 0.0, None
         st.close()
         ops.set_compute_dtype(old)
