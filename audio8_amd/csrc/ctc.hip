@@ -4,12 +4,14 @@
 // The alpha / beta recurrences over the 2S+1 extended labels are serial in time and tiny per step: the loss is LATENCY, and it
 // sits between the model's forward and its backward with nothing to overlap it (round 5: one wave per utterance running alpha,
 // then beta + gradient, with a global-memory round trip per frame in each: 6.5 ms of the 21.4 ms cfg5 step).  Round 6:
-//   * alpha and beta run CONCURRENTLY, one wave each per utterance (grid B x 2), and only recurse; both store their per-frame
+//   * alpha and beta run CONCURRENTLY, one block each per utterance (grid B x 2), and only recurse; both store their per-frame
 //     normalised log2 values; the posteriors and the gradient are a third, fully parallel launch (one wave per frame);
 //   * no memory round trip on the recurrence: the utterance's log-probability rows are staged through LDS in chunks of
-//     1024 floats (32 frames at V = 32), the next chunk's global loads in flight in registers while the current one is walked;
-//   * each lane keeps a CONTIGUOUS run of SPL states in registers (SPL = ceil((2 Smax + 1) / 64), one instantiation per value),
-//     the s-1 / s-2 neighbours of a run's ends come from the adjacent lane by wave shuffle;
+//     1024 floats (32 frames at V = 32), the next chunk's global loads in flight in registers while the current one is walked,
+//     and a frame's emissions are read from LDS one frame ahead of their use;
+//   * each thread keeps a CONTIGUOUS run of Q states in registers; the s-1 / s-2 neighbours of a run's ends come from the adjacent
+//     lane as DPP wave shifts.  Up to 128 extended labels one wave does it all; beyond, FOUR waves (one per SIMD) split the states and
+//     meet at one barrier per frame (ctc_ab_kernel's comment): 1.02 -> 0.56 us per frame at cfg5's 601 states;
 //   * log2(2^a + 2^b + 2^c) as max3 / med3 / min3 + two v_exp_f32 + one v_log_f32.
 // Numerics: ATen recurses on raw log-alpha, whose f32 values reach about -2000 at T = 624 (one ulp = 1.2e-4, so its own
 // gradients carry ~1e-3 of noise).  Here both recursions run in the log2 domain on PER-FRAME-NORMALISED values: after every
@@ -32,21 +34,25 @@ A8_DEV float lse2_3(float a, float b, float c) {           // log2(2^a + 2^b + 2
     const float r = m + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(mid - m) + __builtin_amdgcn_exp2f(lo - m));
     return m == NEG ? NEG : r;                              // (m = -inf: the differences are NaN)
 }
+// whole-wave shifts by one lane as DPP modifiers (wave_shr:1 / wave_shl:1: gfx9 family only); the lane shifted in from outside reads 0 -- callers replace it
+A8_DEV float wave_shr1(float v) { return dpp_f<0x138>(v); }
+A8_DEV float wave_shl1(float v) { return dpp_f<0x130>(v); }
 A8_DEV float lse2_2(float a, float b) {
     const float m = fmaxf(a, b), lo = fminf(a, b);
     const float r = m + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(lo - m));
     return m == NEG ? NEG : r;
 }
 
-// The staged log-probability rows of one utterance, walked forwards (alpha) or backwards (beta).  V <= CTC_CHUNK: chunks of
-// F = CTC_CHUNK / V whole frames (at most 64), double-buffered, chunk k + 1 requested (16 loads per lane, addresses clamped to the
-// utterance's last row) before chunk k is walked and written to the other buffer behind it.  V > CTC_CHUNK (BPE vocabularies):
-// one frame at a time, synchronously.
-struct LpStage {
+// The staged log-probability rows of one utterance, walked forwards (alpha) or backwards (beta) by a block of NT threads.  V <= CTC_CHUNK:
+// chunks of F = CTC_CHUNK / V whole frames (at most 64), double-buffered, chunk k + 1 requested (CTC_CHUNK / NT loads per thread, addresses
+// clamped to the utterance's last row) before chunk k is walked and written to the other buffer behind it.  V > CTC_CHUNK (BPE
+// vocabularies): one frame at a time, synchronously.
+template <int NT> struct LpStage {
+    static constexpr int R = CTC_CHUNK / NT;
     const float* lp; float* sm;
     long long rowstride;         // floats between frames of this utterance: B * V
     int V, F, Tmax, nchunk, big;
-    float r[16];
+    float r[R];
     A8_DEV void init(const float* lp_b, float* sm_, int V_, int B, int Tmax_, int Tb) {
         lp = lp_b; sm = sm_; V = V_; Tmax = Tmax_; rowstride = (long long)B * V_;
         big = V_ > CTC_CHUNK;
@@ -54,132 +60,196 @@ struct LpStage {
         nchunk = (Tb + F - 1) / F;
     }
     A8_DEV void request(int k) {                                  // chunk k -> registers (small V only)
-        const int lane = threadIdx.x, n = F * V;
+        const int tid = threadIdx.x, n = F * V;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int e = lane + 64 * i;
+        for (int i = 0; i < R; ++i) {
+            const int e = tid + NT * i;
             const int f = e / V, c = e - f * V;
             const int t = min(k * F + f, Tmax - 1);
             r[i] = e < n ? lp[(long long)t * rowstride + c] : 0.f;
         }
     }
     A8_DEV void commit(int buf) {                                 // registers -> LDS buffer, in log2 units
-        const int lane = threadIdx.x, n = F * V;
-        __syncthreads();                                          // (one wave: orders the LDS reads of this buffer's last user)
+        const int tid = threadIdx.x, n = F * V;
+        __syncthreads();                                          // every wave is done reading this buffer's previous contents
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int e = lane + 64 * i;
+        for (int i = 0; i < R; ++i) {
+            const int e = tid + NT * i;
             if (e < n) sm[buf * CTC_CHUNK + e] = r[i] * LOG2E;
         }
         __syncthreads();
     }
     A8_DEV const float* frame_big(int t) {                        // V > CTC_CHUNK: frame t synchronously into the single buffer
         __syncthreads();
-        for (int c = threadIdx.x; c < V; c += 64) sm[c] = lp[(long long)t * rowstride + c] * LOG2E;
+        for (int c = threadIdx.x; c < V; c += NT) sm[c] = lp[(long long)t * rowstride + c] * LOG2E;
         __syncthreads();
         return sm;
     }
 };
 
-// dir = blockIdx.y: 0 = alpha (frames ascending), 1 = beta (descending).  ab / bb: [B][Tmax][64 SPL] normalised log2 values, element
-// (lane, j) = state lane * SPL + j at index j * 64 + lane (coalesced).  status[b] = 1 when the utterance has a valid alignment.
-template <int SPL>
-__global__ __launch_bounds__(64) void ctc_ab_kernel(const float* __restrict__ lp, const int32_t* __restrict__ targets,
-                                                    const int32_t* __restrict__ tgt_off, const int32_t* __restrict__ in_len,
-                                                    float* __restrict__ nll, float* __restrict__ abuf, float* __restrict__ bbuf,
-                                                    int32_t* __restrict__ status, int Tmax, int B, int V, int blank, int zero_infinity) {
+// dir = blockIdx.y: 0 = alpha (frames ascending), 1 = beta (descending).  A block of NW waves per (utterance, direction); thread tid keeps the
+// Q CONSECUTIVE states tid Q .. tid Q + Q - 1 in registers.  ab / bb: [B][Tmax][pitch] normalised log2 values, state s at index s.
+// status[b] = 1 when the utterance has a valid alignment.
+// NW = 1 (2 S + 1 <= 128): the s - 1 / s - 2 neighbours of a run's ends come from the adjacent lane by wave shuffle; nothing else is shared.
+// NW = 4 (longer label sequences; round 6, second pass): a frame of the one-wave kernel at 9-10 states per lane is ~300 instructions, 27 of them
+// quarter-rate transcendentals, issued by ONE SIMD -- ~1 us per frame, 640 us at cfg5 with the other 255 CUs idle.  Four waves (one per SIMD of the CU)
+// take a quarter of the states each and meet at ONE barrier per frame: before it every wave leaves its frame maximum and the two RAW values at its end
+// that its neighbour needs (alpha: its last two states; beta: its first two) in a double-buffered LDS record; behind it every thread reads the four maxima
+// (the frame's normalisation) and its neighbour wave's pair, which -- minus the maximum -- are its s - 1 / s - 2 (s + 1 / s + 2) inputs of the next frame.
+template <int Q, int NW>
+__global__ __launch_bounds__(64 * NW) void ctc_ab_kernel(const float* __restrict__ lp, const int32_t* __restrict__ targets,
+                                                         const int32_t* __restrict__ tgt_off, const int32_t* __restrict__ in_len,
+                                                         float* __restrict__ nll, float* __restrict__ abuf, float* __restrict__ bbuf,
+                                                         int32_t* __restrict__ status, int Tmax, int B, int V, int pitch, int blank, int zero_infinity) {
     extern __shared__ float sm[];
-    const int b = blockIdx.x, dir = blockIdx.y, lane = threadIdx.x;
+    __shared__ float xch[2][NW][4];              // per frame parity and wave: {frame maximum of the wave, raw boundary value 1, 2}
+    constexpr int NT = 64 * NW;
+    const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int S = tgt_off[b + 1] - tgt_off[b];
     const int L = 2 * S + 1;
     const int Tb = min(in_len[b], Tmax);
     const int32_t* lab = targets + tgt_off[b];
-    if (Tb <= 0 || L > 64 * SPL) {
-        if (dir == 0 && lane == 0) { nll[b] = zero_infinity ? 0.f : INFINITY; status[b] = 0; }
+    if (Tb <= 0 || L > NT * Q) {                 // (block-uniform)
+        if (dir == 0 && tid == 0) { nll[b] = zero_infinity ? 0.f : INFINITY; status[b] = 0; }
         return;
     }
-    constexpr int PITCH = 64 * SPL;
-    float* const out = (dir == 0 ? abuf : bbuf) + (long long)b * Tmax * PITCH;
+    float* const out = (dir == 0 ? abuf : bbuf) + (long long)b * Tmax * pitch;
+    auto ext_of = [&](int s) { return (s < L && (s & 1)) ? lab[s >> 1] : blank; };
 
-    int ext[SPL];
-    bool valid[SPL], skip[SPL];          // skip[j]: alpha may come from s - 2 (dir 0) / beta may go to s + 2 (dir 1)
+    int ext[Q];
+    bool valid[Q], skip[Q];              // skip[j]: alpha may come from s - 2 (dir 0) / beta may go to s + 2 (dir 1)
 #pragma unroll
-    for (int j = 0; j < SPL; ++j) {
-        const int s = lane * SPL + j;
+    for (int j = 0; j < Q; ++j) {
+        const int s = tid * Q + j;
         valid[j] = s < L;
-        ext[j] = (valid[j] && (s & 1)) ? lab[s >> 1] : blank;
+        ext[j] = ext_of(s);
         if (dir == 0) skip[j] = valid[j] && (s & 1) && s >= 3 && lab[s >> 1] != lab[(s >> 1) - 1];
         else skip[j] = (s + 2 < L) && (s & 1) && lab[(s + 2) >> 1] != lab[s >> 1];
     }
-    LpStage st;
+    // beta across waves: the emissions of the two states behind this thread's run (state (tid + 1) Q and the one after it; Q = 1: tid + 1, tid + 2)
+    const int sq1 = (tid + 1) * Q, sq2 = Q >= 2 ? sq1 + 1 : tid + 2;
+    const int extq1 = ext_of(sq1), extq2 = ext_of(sq2);
+    LpStage<NT> st;
     st.init(lp + (long long)b * V, sm, V, B, Tmax, Tb);
 
-    float a[SPL];
+    float a[Q];
     // alpha: the virtual frame -1 holds all mass in state 0 with the emission-free step into frame 0 (alpha_0(0) = p(blank),
     // alpha_0(1) = p(l_1)); beta_{T-1} (own emission excluded) = 1 on the last two states
+    auto init_of = [&](int s) { return dir == 0 ? (s == 0 ? 0.f : NEG) : ((s < L && (s == L - 1 || s == L - 2)) ? 0.f : NEG); };
 #pragma unroll
-    for (int j = 0; j < SPL; ++j) {
-        const int s = lane * SPL + j;
-        a[j] = dir == 0 ? (s == 0 ? 0.f : NEG) : ((valid[j] && (s == L - 1 || s == L - 2)) ? 0.f : NEG);
+    for (int j = 0; j < Q; ++j) a[j] = init_of(tid * Q + j);
+    // the neighbour WAVE's boundary pair, normalised: alpha -- the previous wave's last and second-last state; beta -- the next wave's first and second
+    float x1 = NEG, x2 = NEG;
+    if (NW > 1) {
+        if (dir == 0 && w >= 1) { x1 = init_of(64 * Q * w - 1); x2 = init_of(64 * Q * w - 2); }
+        if (dir == 1 && w + 1 < NW) { x1 = init_of(64 * Q * (w + 1)); x2 = init_of(64 * Q * (w + 1) + 1); }
     }
+    int par = 0;
     float ll2 = 0.f;                         // log2-likelihood accumulated from the per-frame shifts (alpha)
     bool dead = false;
 
-    auto alpha_frame = [&](const float* pr, int t) {
-        const float up1 = __shfl_up(a[SPL - 1], 1, 64);
-        const float up2 = SPL >= 2 ? __shfl_up(a[SPL >= 2 ? SPL - 2 : 0], 1, 64) : __shfl_up(a[0], 2, 64);
-        const float p1 = lane >= 1 ? up1 : NEG;
-        const float p2 = SPL >= 2 ? (lane >= 1 ? up2 : NEG) : (lane >= 2 ? up2 : NEG);
-        float na[SPL];
-        float mx = NEG;
+    // the frame's maximum over the block and (NW > 1) the neighbour wave's raw pair minus it; r1 / r2: this wave's raw pair (held by the lanes named below)
+    auto frame_max = [&](float lm, float r1, float r2, bool first_pair) -> float {
+        if constexpr (NW == 1) return lm;
+        const int l1 = first_pair ? 0 : 63, l2 = Q >= 2 ? l1 : (first_pair ? 1 : 62);
+        if (lane == l1) { xch[par][w][0] = lm; xch[par][w][1] = r1; }
+        if (lane == l2) xch[par][w][2] = r2;
+        __syncthreads();
+        float mx = xch[par][0][0];
 #pragma unroll
-        for (int j = 0; j < SPL; ++j) {
-            const float m1 = j >= 1 ? a[j >= 1 ? j - 1 : 0] : p1;
-            const float m2 = j >= 2 ? a[j >= 2 ? j - 2 : 0] : (j == 1 ? p1 : p2);
-            const float v = lse2_3(a[j], m1, skip[j] ? m2 : NEG);
-            na[j] = valid[j] ? v + pr[ext[j]] : NEG;
-            mx = fmaxf(mx, na[j]);
-        }
-        mx = wave_max(mx);
-        if (mx == NEG) { dead = true; return; }                   // no alignment survives (wave-uniform)
-        ll2 += mx;
-#pragma unroll
-        for (int j = 0; j < SPL; ++j) {
-            a[j] = na[j] - mx;
-            out[(long long)t * PITCH + j * 64 + lane] = a[j];
-        }
-    };
-    auto beta_frame = [&](const float* pr, int t) {
-#pragma unroll
-        for (int j = 0; j < SPL; ++j) out[(long long)t * PITCH + j * 64 + lane] = a[j];
-        if (t == 0) return;
-        // beta_{t-1}(s) = sum_{s' in {s, s+1, s+2 if skip}} beta_t(s') p_t(s')
-        float w[SPL];
-#pragma unroll
-        for (int j = 0; j < SPL; ++j) w[j] = valid[j] ? a[j] + pr[ext[j]] : NEG;
-        const float dn1 = __shfl_down(w[0], 1, 64);
-        const float dn2 = SPL >= 2 ? __shfl_down(w[SPL >= 2 ? 1 : 0], 1, 64) : __shfl_down(w[0], 2, 64);
-        const float q1 = lane < 63 ? dn1 : NEG;
-        const float q2 = SPL >= 2 ? (lane < 63 ? dn2 : NEG) : (lane < 62 ? dn2 : NEG);
-        float nb[SPL];
-        float bm = NEG;
-#pragma unroll
-        for (int j = 0; j < SPL; ++j) {
-            const float n1 = j + 1 < SPL ? w[j + 1 < SPL ? j + 1 : 0] : q1;
-            const float n2 = j + 2 < SPL ? w[j + 2 < SPL ? j + 2 : 0] : (j + 1 < SPL ? q1 : q2);
-            nb[j] = valid[j] ? lse2_3(w[j], n1, skip[j] ? n2 : NEG) : NEG;
-            bm = fmaxf(bm, nb[j]);
-        }
-        bm = wave_max(bm);                     // keep beta near 0 (any per-frame shift cancels in the posterior)
-#pragma unroll
-        for (int j = 0; j < SPL; ++j) a[j] = bm == NEG ? NEG : nb[j] - bm;
+        for (int q = 1; q < NW; ++q) mx = fmaxf(mx, xch[par][q][0]);
+        const int nbw = first_pair ? w + 1 : w - 1;          // beta reads the NEXT wave's first pair, alpha the PREVIOUS wave's last pair
+        if (nbw >= 0 && nbw < NW) { x1 = xch[par][nbw][1] - mx; x2 = xch[par][nbw][2] - mx; }
+        par ^= 1;
+        return mx;
     };
 
+    // The emissions of a frame: read UNCONDITIONALLY (ext[j] is the blank for the states beyond the utterance's last: always a valid index; a read
+    // under `valid[j] ? .. : ..` gets its own basic block and its own s_waitcnt lgkmcnt(0)) and ONE FRAME AHEAD of their use wherever the next frame
+    // sits in the same staged chunk -- an LDS round trip is as long as the rest of a frame's dependency chain.  em[Q], em[Q + 1]: beta's two states
+    // behind the thread's run.
+    // A state beyond the utterance's last gets the emission -inf: its alpha / beta then stay -inf through plain arithmetic, with no `valid ? .. : ..`
+    // around the log-sum-exp (which the compiler turns into an exec-mask branch per state: ~10 scalar instructions and a taken-or-not branch each).
+    auto emissions = [&](const float* pr, float (&em)[Q + 2]) {
+#pragma unroll
+        for (int j = 0; j < Q; ++j) { const float e = pr[ext[j]]; em[j] = valid[j] ? e : NEG; }
+        if (dir == 1) {
+            const float e1 = pr[extq1], e2 = pr[extq2];
+            em[Q] = sq1 < L ? e1 : NEG; em[Q + 1] = sq2 < L ? e2 : NEG;
+        }
+    };
+    auto alpha_frame = [&](const float (&em)[Q + 2], int t) {
+        float na[Q];
+        const float up1 = wave_shr1(a[Q - 1]);                    // lane l <- lane l - 1 (DPP: no LDS-crossbar round trip on the recurrence)
+        const float up2 = Q >= 2 ? wave_shr1(a[Q >= 2 ? Q - 2 : 0]) : wave_shr1(up1);
+        const float p1 = lane >= 1 ? up1 : x1;
+        const float p2 = Q >= 2 ? (lane >= 1 ? up2 : x2) : (lane >= 2 ? up2 : (lane == 1 ? x1 : x2));
+        float mx = NEG;
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+            const float m1 = j >= 1 ? a[j >= 1 ? j - 1 : 0] : p1;
+            const float m2 = j >= 2 ? a[j >= 2 ? j - 2 : 0] : (j == 1 ? p1 : p2);
+            na[j] = lse2_3(a[j], m1, skip[j] ? m2 : NEG) + em[j];
+            mx = fmaxf(mx, na[j]);
+        }
+        // raw pair for the next wave: this wave's last state (lane 63's na[Q-1]) and the one before it (Q >= 2: lane 63's na[Q-2]; Q = 1: lane 62's na[0])
+        mx = frame_max(wave_max(mx), na[Q - 1], na[Q >= 2 ? Q - 2 : 0], false);
+        if (mx == NEG) { dead = true; return; }                   // no alignment survives (block-uniform)
+        ll2 += mx;
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+            a[j] = na[j] - mx;
+            if (valid[j]) out[(long long)t * pitch + tid * Q + j] = a[j];
+        }
+    };
+    auto beta_frame = [&](const float (&em)[Q + 2], int t) {
+#pragma unroll
+        for (int j = 0; j < Q; ++j)
+            if (valid[j]) out[(long long)t * pitch + tid * Q + j] = a[j];
+        if (t == 0) return;
+        // beta_{t-1}(s) = sum_{s' in {s, s+1, s+2 if skip}} beta_t(s') p_t(s')
+        float wv[Q];
+        const float eq1 = em[Q], eq2 = em[Q + 1];
+#pragma unroll
+        for (int j = 0; j < Q; ++j) wv[j] = a[j] + em[j];
+        const float dn1 = wave_shl1(wv[0]);                       // lane l <- lane l + 1
+        const float dn2 = Q >= 2 ? wave_shl1(wv[Q >= 2 ? 1 : 0]) : wave_shl1(dn1);
+        // across the wave boundary: the next wave's first two states, (normalised beta_t) + their emission
+        const float y1 = x1 + eq1;                                // state (tid + 1) Q     = the next wave's first state when lane == 63
+        float q1, q2;
+        if (Q >= 2) {
+            const float y2 = x2 + eq2;
+            q1 = lane < 63 ? dn1 : y1;
+            q2 = lane < 63 ? dn2 : y2;
+        } else {
+            // Q = 1: state tid + 2 is the next wave's FIRST state for lane 62 and its SECOND for lane 63
+            const float y2 = (lane == 62 ? x1 : x2) + eq2;
+            q1 = lane < 63 ? dn1 : y1;
+            q2 = lane < 62 ? dn2 : y2;
+        }
+        float nb[Q];
+        float bm = NEG;
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+            const float n1 = j + 1 < Q ? wv[j + 1 < Q ? j + 1 : 0] : q1;
+            const float n2 = j + 2 < Q ? wv[j + 2 < Q ? j + 2 : 0] : (j + 1 < Q ? q1 : q2);
+            nb[j] = lse2_3(wv[j], n1, skip[j] ? n2 : NEG);        // (a state beyond the last: every input is -inf)
+            bm = fmaxf(bm, nb[j]);
+        }
+        // raw pair for the previous wave: this wave's first state (lane 0's nb[0]) and second (Q >= 2: lane 0's nb[1]; Q = 1: lane 1's nb[0])
+        bm = frame_max(wave_max(bm), nb[0], nb[Q >= 2 ? 1 : 0], true);       // keep beta near 0 (any per-frame shift cancels in the posterior)
+#pragma unroll
+        for (int j = 0; j < Q; ++j) a[j] = bm == NEG ? NEG : nb[j] - bm;
+        if (bm == NEG) { x1 = NEG; x2 = NEG; }
+    };
+
+    float em[Q + 2], en[Q + 2];
     if (st.big) {
         for (int i = 0; i < Tb && !dead; ++i) {
             const int t = dir == 0 ? i : Tb - 1 - i;
-            const float* pr = st.frame_big(t);
-            if (dir == 0) alpha_frame(pr, t); else beta_frame(pr, t);
+            emissions(st.frame_big(t), em);
+            if (dir == 0) alpha_frame(em, t); else beta_frame(em, t);
         }
     } else {
         const int F = st.F, nch = st.nchunk;
@@ -193,9 +263,21 @@ __global__ __launch_bounds__(64) void ctc_ab_kernel(const float* __restrict__ lp
             const float* base = sm + buf * CTC_CHUNK;
             const int f_end = min(F, Tb - k * F);
             if (dir == 0) {
-                for (int f = 0; f < f_end && !dead; ++f) alpha_frame(base + f * V, k * F + f);
+                emissions(base, em);
+                for (int f = 0; f < f_end && !dead; ++f) {
+                    if (f + 1 < f_end) emissions(base + (f + 1) * V, en);
+                    alpha_frame(em, k * F + f);
+#pragma unroll
+                    for (int j = 0; j < Q + 2; ++j) em[j] = en[j];
+                }
             } else {
-                for (int f = f_end - 1; f >= 0; --f) beta_frame(base + f * V, k * F + f);
+                emissions(base + (f_end - 1) * V, em);
+                for (int f = f_end - 1; f >= 0; --f) {
+                    if (f >= 1) emissions(base + (f - 1) * V, en);
+                    beta_frame(em, k * F + f);
+#pragma unroll
+                    for (int j = 0; j < Q + 2; ++j) em[j] = en[j];
+                }
             }
             if (more) st.commit(buf ^ 1);
             buf ^= 1;
@@ -204,20 +286,35 @@ __global__ __launch_bounds__(64) void ctc_ab_kernel(const float* __restrict__ lp
     }
     if (dir != 0) return;
     if (dead) {
-        if (lane == 0) { nll[b] = zero_infinity ? 0.f : INFINITY; status[b] = 0; }
+        if (tid == 0) { nll[b] = zero_infinity ? 0.f : INFINITY; status[b] = 0; }
         return;
     }
-    // termination: log2 Z = log2(alpha_{T-1}(L-1) + alpha_{T-1}(L-2)) in normalised units
+    // termination: log2 Z = log2(alpha_{T-1}(L-1) + alpha_{T-1}(L-2)) in normalised units; the two states may sit in different waves
     float zt = NEG;
 #pragma unroll
-    for (int j = 0; j < SPL; ++j) { const int s = lane * SPL + j; if (valid[j] && (s == L - 1 || s == L - 2)) zt = lse2_2(zt, a[j]); }
-    const float zm = wave_max(zt);
+    for (int j = 0; j < Q; ++j) { const int s = tid * Q + j; if (valid[j] && (s == L - 1 || s == L - 2)) zt = lse2_2(zt, a[j]); }
+    float zm = wave_max(zt);
+    if constexpr (NW > 1) {
+        __syncthreads();
+        if (lane == 0) xch[0][w][0] = zm;
+        __syncthreads();
+        zm = xch[0][0][0];
+#pragma unroll
+        for (int q = 1; q < NW; ++q) zm = fmaxf(zm, xch[0][q][0]);
+    }
     if (zm == NEG) {
-        if (lane == 0) { nll[b] = zero_infinity ? 0.f : INFINITY; status[b] = 0; }
+        if (tid == 0) { nll[b] = zero_infinity ? 0.f : INFINITY; status[b] = 0; }
         return;
     }
-    const float z2 = zm + log2f(wave_sum(zt == NEG ? 0.f : exp2f(zt - zm)));
-    if (lane == 0) { nll[b] = -(ll2 + z2) * LN2; status[b] = 1; }
+    float zs = wave_sum(zt == NEG ? 0.f : exp2f(zt - zm));
+    if constexpr (NW > 1) {
+        if (lane == 0) xch[1][w][0] = zs;
+        __syncthreads();
+        zs = xch[1][0][0];
+#pragma unroll
+        for (int q = 1; q < NW; ++q) zs += xch[1][q][0];
+    }
+    if (tid == 0) { nll[b] = -(ll2 + zm + log2f(zs)) * LN2; status[b] = 1; }
 }
 
 // grad[t, b, :] = softmax probabilities of the frame - the posterior occupancy of its classes; one wave per (frame, utterance).
@@ -227,38 +324,31 @@ __global__ __launch_bounds__(64) void ctc_grad_kernel(const float* __restrict__ 
                                                       const int32_t* __restrict__ tgt_off, const int32_t* __restrict__ in_len,
                                                       const float* __restrict__ abuf, const float* __restrict__ bbuf,
                                                       const int32_t* __restrict__ status, float* __restrict__ grad,
-                                                      int Tmax, int B, int V, int spl, int blank) {
+                                                      int Tmax, int B, int V, int pitch, int blank) {
     extern __shared__ float occ[];           // [V]
     const int t = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     float* const grow = grad + ((long long)t * B + b) * V;
     const int Tb = min(in_len[b], Tmax);
     const int S = tgt_off[b + 1] - tgt_off[b], L = 2 * S + 1;
-    if (t >= Tb || L > 64 * spl || status[b] == 0) {
+    if (t >= Tb || L > pitch || status[b] == 0) {
         for (int c = lane; c < V; c += 64) grow[c] = 0.f;
         return;
     }
-    const int pitch = 64 * spl;
     const float* ar = abuf + ((long long)b * Tmax + t) * pitch;
     const float* br = bbuf + ((long long)b * Tmax + t) * pitch;
     const int32_t* lab = targets + tgt_off[b];
     for (int c = lane; c < V; c += 64) occ[c] = 0.f;
     float mx = NEG;
-    for (int j = 0; j < spl; ++j) {
-        const int s = lane * spl + j;
-        if (s < L) mx = fmaxf(mx, ar[j * 64 + lane] + br[j * 64 + lane]);
-    }
+    for (int s = lane; s < L; s += 64) mx = fmaxf(mx, ar[s] + br[s]);
     mx = wave_max(mx);                       // finite: the utterance has an alignment, so every frame carries mass
     __syncthreads();
     float sum = 0.f;
-    for (int j = 0; j < spl; ++j) {
-        const int s = lane * spl + j;
-        if (s < L) {
-            const float g = ar[j * 64 + lane] + br[j * 64 + lane];
-            if (g != NEG) {
-                const float p = exp2f(g - mx);
-                sum += p;
-                atomicAdd(&occ[(s & 1) ? lab[s >> 1] : blank], p);
-            }
+    for (int s = lane; s < L; s += 64) {
+        const float g = ar[s] + br[s];
+        if (g != NEG) {
+            const float p = exp2f(g - mx);
+            sum += p;
+            atomicAdd(&occ[(s & 1) ? lab[s >> 1] : blank], p);
         }
     }
     const float inv = 1.0f / wave_sum(sum);
@@ -355,23 +445,26 @@ extern "C" int a8_ctc_fwd_bwd(const float* lp, const int32_t* targets, const int
     A8_REQUIRE(Smax >= 0 && Lmax <= 64 * 16, "a8_ctc_fwd_bwd: Smax=%d exceeds the supported 511 labels", Smax);
     A8_REQUIRE(V <= 8192, "a8_ctc_fwd_bwd: V=%d labels exceed the 8192 the per-frame LDS rows hold", V);
     A8_REQUIRE(B <= 65535, "a8_ctc_fwd_bwd: B=%d exceeds the grid's second dimension", B);
-    const int spl = (Lmax + 63) / 64;
-    // scratch (A8_CTC_SCRATCH_FLOATS): alpha [B][T][64 spl] | beta [B][T][64 spl] | status i32 [B]
-    const size_t plane = (size_t)B * T_ * 64 * spl;
+    const int spl = (Lmax + 63) / 64, pitch = 64 * spl;
+    // scratch (A8_CTC_SCRATCH_FLOATS): alpha [B][T][pitch] | beta [B][T][pitch] | status i32 [B]; state s of a frame at index s
+    const size_t plane = (size_t)B * T_ * pitch;
     float* abuf = scratch;
     float* bbuf = scratch + plane;
     int32_t* status = reinterpret_cast<int32_t*>(scratch + 2 * plane);
     const size_t shm_ab = sizeof(float) * (V > CTC_CHUNK ? (size_t)V : 2 * (size_t)CTC_CHUNK);
     hipStream_t s = (hipStream_t)stream;
-#define A8_CTC_LAUNCH(N) case N: hipLaunchKernelGGL(ctc_ab_kernel<N>, dim3(B, 2), dim3(64), shm_ab, s, lp, targets, tgt_off, in_len, nll, abuf, bbuf, status, T_, B, V, blank, zero_infinity); break;
-    switch (spl) {
-        A8_CTC_LAUNCH(1) A8_CTC_LAUNCH(2) A8_CTC_LAUNCH(3) A8_CTC_LAUNCH(4) A8_CTC_LAUNCH(5) A8_CTC_LAUNCH(6) A8_CTC_LAUNCH(7) A8_CTC_LAUNCH(8)
-        A8_CTC_LAUNCH(9) A8_CTC_LAUNCH(10) A8_CTC_LAUNCH(11) A8_CTC_LAUNCH(12) A8_CTC_LAUNCH(13) A8_CTC_LAUNCH(14) A8_CTC_LAUNCH(15)
-        default: hipLaunchKernelGGL(ctc_ab_kernel<16>, dim3(B, 2), dim3(64), shm_ab, s, lp, targets, tgt_off, in_len, nll, abuf, bbuf, status, T_, B, V, blank, zero_infinity); break;
-    }
+    // one wave per (utterance, direction) up to 128 extended labels, four waves beyond (states per thread = ceil(Lmax / 256) <= 4)
+#define A8_CTC_LAUNCH(Q, NW) hipLaunchKernelGGL((ctc_ab_kernel<Q, NW>), dim3(B, 2), dim3(64 * NW), shm_ab, s, lp, targets, tgt_off, in_len, nll, abuf, bbuf, \
+                                                status, T_, B, V, pitch, blank, zero_infinity)
+    if (Lmax <= 64) A8_CTC_LAUNCH(1, 1);
+    else if (Lmax <= 128) A8_CTC_LAUNCH(2, 1);
+    else if (Lmax <= 256) A8_CTC_LAUNCH(1, 4);
+    else if (Lmax <= 512) A8_CTC_LAUNCH(2, 4);
+    else if (Lmax <= 768) A8_CTC_LAUNCH(3, 4);
+    else A8_CTC_LAUNCH(4, 4);
 #undef A8_CTC_LAUNCH
     if (int e = a8_check_launch("a8_ctc_fwd_bwd (alpha / beta)")) return e;
-    hipLaunchKernelGGL(ctc_grad_kernel, dim3(T_, B), dim3(64), sizeof(float) * V, s, lp, targets, tgt_off, in_len, abuf, bbuf, status, grad, T_, B, V, spl, blank);
+    hipLaunchKernelGGL(ctc_grad_kernel, dim3(T_, B), dim3(64), sizeof(float) * V, s, lp, targets, tgt_off, in_len, abuf, bbuf, status, grad, T_, B, V, pitch, blank);
     return a8_check_launch("a8_ctc_fwd_bwd (gradient)");
 }
 

@@ -316,8 +316,8 @@ int a8_contrastive_bwd(int dtype, const void* ctx, const void* lat, const int32_
  * lp f32 [T,B,V] log-probs; targets i32 flat (PAD/EOS already stripped), tgt_off i32 [B+1]; nll f32 [B];
  * grad f32 [T,B,V] = d nll_b / d lp (zero_infinity applied); scratch: A8_CTC_SCRATCH_FLOATS(T, B, Smax) floats (the per-frame
  * normalised log2 alpha and beta of every utterance + a feasibility flag each).  Two launches: alpha and beta recurse concurrently
- * (one wave each per utterance, the log-probability rows staged through LDS ahead of the recurrence), then one wave per frame forms
- * the posteriors and the gradient. */
+ * (one block each per utterance -- one wave up to 128 extended labels 2 Smax + 1, four waves meeting at one barrier per frame beyond --, the
+ * log-probability rows staged through LDS ahead of the recurrence), then one wave per frame forms the posteriors and the gradient. */
 #define A8_CTC_SCRATCH_FLOATS(T, B, Smax) (2 * (size_t)(B) * (size_t)(T) * (64 * ((2 * (size_t)(Smax) + 1 + 63) / 64)) + (size_t)(B))
 /* targets i64 [B,S] padded with PAD / EOS (audio8/ctc.py:193-194 `targets.masked_select(pad_mask)`) -> flat i32 [<= B*S] and
  * tgt_off i32 [B+1] = exclusive prefix sum of target_lengths i32 [B]; everything on the device (the reference's masked_select
