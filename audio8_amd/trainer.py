@@ -411,17 +411,23 @@ class GradReducer:
                     nbytes = (bk["hi"] - bk["lo"]) * (2 if self.payload == "bf16" else 4)
                     from . import _lib as L
                     L.check(L.lib().a8_delay_us(nbytes / (self.fake_gbps * 1e3), self.side.cuda_stream), "a8_delay_us")
+                # RCCL: the BLOCKING form (async_op=False).  Since torch 2.7 ProcessGroupNCCL enqueues a blocking-form collective on the CURRENT
+                # stream -- here the exchange stream -- and returns without waiting on the host; the async form runs on a stream of its own and
+                # hands back a handle.  That fifth stream matters on this hardware: HIP multiplexes streams over four hardware queues, the step
+                # already uses four (caller, half-batch, weight-gradient, exchange), so the collective's own stream would share a queue with one
+                # of them and its kernels would run IN ORDER with that queue's compute launches (profiles/r06_stream_priority.txt: a fifth
+                # hardware queue is worse still).  On the exchange stream the collectives sit where tools/exchange_exposure.py measured them.
+                # (An older torch runs the blocking form on its own stream and makes the current stream wait for it: same results, same order.)
                 if self.enabled and self.payload == "bf16":
                     sv = self._stage_view(bk)
                     sv.copy_(view)                                            # f32 -> bf16 (round to nearest even)
-                    h = dist.all_reduce(sv, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
                     if self.stream_ordered:
-                        h.wait()                                              # the exchange stream (not the host) waits for the collective
+                        dist.all_reduce(sv, op=dist.ReduceOp.SUM, group=self.pg, async_op=False)
                         view.copy_(sv)                                        # bf16 SUM over ranks back into the f32 slot
-                        h = None
                     else:
-                        self.deferred.append((h, view, sv))
-                        h = None
+                        self.deferred.append((dist.all_reduce(sv, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), view, sv))
+                elif self.enabled and self.stream_ordered:
+                    dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=False)
                 elif self.enabled:
                     h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
                 if self.norm_sq is not None and self.stream_ordered:      # stream order: behind this bucket's collective
@@ -476,7 +482,10 @@ class GradReducer:
         if self.on_gpu:
             self.side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.side):
-                self.handles.append(dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                if self.stream_ordered:              # RCCL: on the exchange stream itself (see _launch)
+                    dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.pg, async_op=False)
+                else:
+                    self.handles.append(dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
             counts.record_stream(self.side)
         else:
             self.handles.append(dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
