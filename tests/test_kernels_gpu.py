@@ -687,10 +687,11 @@ def test_ctc_against_golden_and_oracle(golden_dir, tag):
 
 @pytest.mark.parametrize("case", ["small-v", "chunk-edges", "one-frame-chunks", "big-v", "states-per-lane"])
 def test_ctc_random_shapes_against_the_f64_oracle(case):
-    """The round-6 CTC kernels (alpha / beta on two waves per utterance with LDS-staged rows, gradient as a parallel launch) over the
-    shapes their staging distinguishes, against the float64 restatement of F.ctc_loss (audio8/ctc.py:186-206): vocabularies that put
-    1 .. 64 frames in a 1024-float chunk, utterance lengths on and next to chunk boundaries, V > 1024 (one frame at a time), every
-    states-per-lane instantiation (2 S + 1 = 1 .. 1023), repeated labels, empty targets, ragged and zero input lengths, infeasible rows."""
+    """The round-6 CTC kernels (alpha / beta on one or four waves per utterance and direction with LDS-staged rows, gradient as a parallel launch)
+    over the shapes their staging distinguishes, against the float64 restatement of F.ctc_loss (audio8/ctc.py:186-206): vocabularies that put
+    1 .. 64 frames in a 1024-float chunk, utterance lengths on and next to chunk boundaries, V > 1024 (one frame at a time, one- and four-wave),
+    every <states per thread, waves> instantiation (2 S + 1 = 1 .. 1023) incl. label counts whose last two states sit in DIFFERENT waves
+    (2 S + 1 = 129, 257, 385, 577, 769), repeated labels, empty targets, ragged and zero input lengths, infeasible rows."""
     from audio8_amd import kernels as K
     from oracle import ref_cpu as R
     rs = np.random.RandomState({"small-v": 1, "chunk-edges": 2, "one-frame-chunks": 3, "big-v": 4, "states-per-lane": 5}[case])
@@ -701,9 +702,9 @@ def test_ctc_random_shapes_against_the_f64_oracle(case):
     elif case == "one-frame-chunks":                  # 512 < V <= 1024: one frame per chunk
         configs = [(rs.randint(3, 40), 2, V, 6) for V in (513, 700, 1024)]
     elif case == "big-v":                             # V > 1024: the synchronous path
-        configs = [(rs.randint(3, 30), 2, V, 5) for V in (1025, 1500, 3000)]
+        configs = [(rs.randint(3, 30), 2, V, 5) for V in (1025, 1500, 3000)] + [(230, 2, 1500, 100)]
     else:
-        configs = [(2 * S + 6, 2, 12, S) for S in (0, 1, 31, 32, 33, 64, 100, 160, 255, 300, 448, 511)]
+        configs = [(2 * S + 6, 2, 12, S) for S in (0, 1, 31, 32, 33, 63, 64, 100, 128, 160, 192, 255, 288, 300, 384, 448, 511)]
     for T, B, V, Smax in configs:
         lp = torch.log_softmax(torch.from_numpy(rs.standard_normal((T, B, V)).astype(np.float32)) * 2.0, -1)
         tl = rs.randint(0, Smax + 1, B)
