@@ -589,6 +589,7 @@ class ConvStackFn(torch.autograd.Function):
                 akw = dict(a_off=pad * co, a_rpb=Lout, a_bs=dzrows * co) if pad else {}
                 a_prev = acts[i - 1][b0:b1]
                 tgt = _target(ws[i])
+                deferred = None
                 if tgt is not None:
                     # off the critical path: wgrad GEMM + re-layout [co][k][cin] -> [co][cin][k] + accumulate on the side stream
                     def run(dz=dz, a=a_prev, co=co, k=k, cin=cin, M=M, s=s, Lout=Lout, Lin=Lin, akw=akw, tgt=tgt, p=ws[i]):
@@ -603,7 +604,10 @@ class ConvStackFn(torch.autograd.Function):
                         K.conv_wgrad_fold_(dw2, tgt, co, cin, k)
                         if last:                       # the gradient is complete once the last chunk's share is enqueued
                             _ready(p)
-                    _on_side(run, dz, a_prev)
+                    if fusable and (CONV_WGRAD_DEFER == 2 or (CONV_WGRAD_DEFER == 1 and i == 1)):
+                        deferred = (run, dz, a_prev)   # handed to the side stream BEHIND this layer's data gradient (see CONV_WGRAD_DEFER)
+                    else:
+                        _on_side(run, dz, a_prev)
                 else:
                     dw2 = wgrad(dz, a_prev, co, k * cin, M, ldb=s * cin, b_rpb=Lout, b_bs=Lin * cin, lda=co, **akw)
                     gi = dw2.view(co, k, cin).permute(0, 2, 1).contiguous()
@@ -645,6 +649,8 @@ class ConvStackFn(torch.autograd.Function):
                     else:
                         for A_, B_, m_, n_, k_, kw_ in (even, odd):
                             K.gemm(L.NT, A_, B_, m_, n_, k_, **kw_)
+                if deferred is not None:
+                    _on_side(*deferred)
                 dz, pad = dx, npad
             return dz, pad
 
@@ -744,6 +750,10 @@ CONV_CHUNK_UTTS = 0
 CONV_CHUNK_LAYERS = 3
 # even / odd halves of a k = 3, stride 2 conv data gradient as ONE grouped launch (A/B knob)
 CONV_DGRAD_GROUPED = True
+# When a conv layer's weight gradient is handed to the side stream: 0 = ahead of the layer's data gradient (both MFMA-bound, they share the chip);
+# 1 = layer 1's BEHIND its data gradient, so that it runs beside conv layer 0's backward (VALU-bound, the matrix cores idle: the last 0.25 ms of
+# backward had nothing beside it); 2 = every layer's behind its own data gradient.
+CONV_WGRAD_DEFER = 0
 
 
 def _conv_chunking(B, nl):

@@ -46,6 +46,7 @@ def apply(d):
     ops.CONV_CHUNK_UTTS = d.get("convchunk", 0)
     ops.SIDE_EXTRAS = bool(d.get("sidex", 1))
     ops.CONV_DGRAD_GROUPED = bool(d.get("dgroup", 1))
+    ops.CONV_WGRAD_DEFER = d.get("wdefer", 0)
     ops.WPREP_SPLIT = bool(d.get("wsplit", 1))
     ops.COMPOSITE_ENCODER_FWD = bool(d.get("compfwd", 1))
     ops.COMPOSITE_ENCODER_BWD = bool(d.get("compbwd", 1))

@@ -50,6 +50,15 @@ def analyse(step, label):
             ce = max(ce, e)
     u += ce - cs
     print(f"  GPU busy (union of all queues): {u / 1e6:.3f} ms of {(t1 - t0) / 1e6:.3f} ms")
+    # the tail of backward: what each queue runs in the last 1.2 ms before the gradient norm (which waits for all of them)
+    sq = next((r for r in step if "sumsq_kernel" in r["Kernel_Name"]), None)
+    if sq is not None:
+        ts = int(sq["Start_Timestamp"])
+        print("  the last 1.2 ms before the gradient norm (queue: kernel, start .. end in us before it):")
+        for r in step:
+            e = int(r["End_Timestamp"])
+            if e <= ts and ts - e < 1200000:
+                print(f"    q{r['Queue_Id']}  {(ts - int(r['Start_Timestamp'])) / 1e3:7.1f} .. {(ts - e) / 1e3:6.1f}  {r['Kernel_Name'][:70]}")
     if len(sys.argv) > 3:      # every dispatch of one kernel in the step: duration, grid, what ran before it
         key = sys.argv[3]
         for i, r in enumerate(step):
