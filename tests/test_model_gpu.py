@@ -246,6 +246,41 @@ def test_whole_layer_backward_call_matches_the_per_call_path(restore_dtype, B):
         assert float((outs[0][k][1] - outs[1][k][1]).abs().max()) <= (1e-4 if k == 0 else 5e-2) * scale, k      # step 1: f32 atomic sums in another order
 
 
+def test_conv_weight_gradients_behind_their_data_gradients_give_the_same_step(restore_dtype):
+    """ops.CONV_WGRAD_DEFER only moves the point at which a conv layer's weight gradient is handed to the side stream (ahead of / behind the
+    layer's data gradient): the same launches on the same operands -- first loss bit for bit, gradients equal up to the order of the
+    split-K f32 atomic sums."""
+    from audio8_amd import ops, wav2vec2 as W
+    from audio8_amd.trainer import Stepper
+    ops.set_compute_dtype(torch.bfloat16)
+    x = synth(2, 24000, 9).cuda()
+    outs = []
+    try:
+        for mode in (0, 1, 2):
+            ops.CONV_WGRAD_DEFER = mode
+            torch.manual_seed(5)
+            np.random.seed(5)
+            ops.reset_seed_stream()
+            m = W.create_model(num_layers=2, dropout=0.1).cuda().train()
+            loss_fn = W.create_loss(640, 100)
+            st = Stepper(m, lr=1e-4, clip=1.0)
+            try:
+                st.zero_grad()
+                loss = loss_fn(m, x)
+                loss.backward()
+                st.sync_grads()
+                torch.cuda.synchronize()
+                outs.append((float(loss.detach()), st.state.flat_g.clone()))
+            finally:
+                st.close()
+    finally:
+        ops.CONV_WGRAD_DEFER = 0
+    scale = float(outs[0][1].abs().max())
+    for mode in (1, 2):
+        assert outs[mode][0] == outs[0][0], mode
+        assert float((outs[mode][1] - outs[0][1]).abs().max()) <= 1e-4 * scale, mode
+
+
 def test_pretrain_step_parity_bf16_full_depth_base(restore_dtype):
     """The benchmark dtype at the benchmark depth against the ORACLE (not against the product's own f32 mode): wav2vec2-base, 12 layers,
     2 x 16 000 samples.  Stated tolerance of the bf16 mode (bf16 activations and residual stream, f32 accumulation / statistics / masters):
